@@ -1,0 +1,213 @@
+/*
+ * pixtrack_hip.h -- C ABI of the MI355X (gfx950) hot path of the pixtrack tracker.
+ *
+ * The reference (GiantAI/pixtrack) has no C ABI: its per-frame path is Python that
+ * calls three third-party engines (pixloc's optimizer and UNet in PyTorch-CUDA, and
+ * instant-ngp's Testbed through pyngp).  Each entry point below replaces ONE of the
+ * Python-level interfaces that path goes through; the citation names the reference
+ * line where pixtrack crosses that interface.  The Python host side
+ * (pixtrack_amd/*.py) binds these with ctypes and keeps the reference's own
+ * class/method names on top (INTEGRATION.md shows the stub a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer; the library keeps no reference after return
+ *     (work is enqueued on `stream`; buffers must stay alive until it completes);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - return value: 0 = enqueued OK; negative = PXT_E_* (argument / HIP error).
+ *     Algorithmic failure of the optimiser (fewer than 10 valid points) is NOT an
+ *     error: it is reported in the `failed` field of the output record, exactly like
+ *     pixloc's `(T, failed)` return.
+ *   - poses are 12 floats: row-major R (9) then t (3)   [pixloc Pose._data];
+ *   - cameras are 10 floats: w,h,fx,fy,cx,cy,k1,k2,p1,p2 with the pixel-centre
+ *     origin of pixloc Camera (cx,cy already shifted by -0.5), plus `ndist` in
+ *     {0,2,4} saying how many distortion terms are live.
+ *   - dense feature maps are HWC float32: map[(y*W + x)*cstride + c]; channels
+ *     [0,C) are the descriptor, channel C is the confidence; cstride % 4 == 0 and
+ *     cstride >= C+1.  Sparse reference features use the same record per point.
+ */
+#ifndef PIXTRACK_HIP_H
+#define PIXTRACK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXT_OK 0
+#define PXT_E_ARG -1     /* bad argument (null pointer, size, alignment) */
+#define PXT_E_HIP -2     /* a HIP runtime call failed (pxt_last_error() has text) */
+#define PXT_E_TIMEOUT -3 /* in-kernel spin bound exceeded (reported via status words) */
+#define PXT_E_STATE -4   /* context misuse */
+
+#define PXT_MAX_LEVELS 8
+#define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
+
+/* Library / device info ---------------------------------------------------- */
+int pxt_version(void);               /* ABI version, bumps on any signature change */
+const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
+int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
+
+/* -------------------------------------------------------------------------
+ * Levenberg-Marquardt feature-metric pose refinement.
+ *
+ * Replaces, in one persistent launch and with no host round trip per iteration:
+ *   for level in coarse..fine:  T, failed = opt[level].run(p3d, F_ref, F_q, T,
+ *                                            camera.scale(s), W_ref_query=...)
+ * i.e. pixloc BaseRefiner.refine_pose_using_features -> LearnedOptimizer._run,
+ * reached from pixtrack/localization/pixloc_pose_refiners.py:260-262, with
+ * pixtrack's early-stop-every-iteration rule
+ * (pixtrack/optimizers/pixtrack_optimizer.py:5-18) and the per-iteration
+ * masked-mean cost that DebugTracker logs (pixtrack/localization/tracker.py:32-46).
+ * A single-level call (n_levels = 1) is exactly one `opt.run(...)`.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const float* fmap;   /* query map of this level, HWC, [h][w][cstride]; descriptor
+                          channels already L2-normalised over C (A.4) */
+  const float* fref;   /* reference observations [n_points][cstride]; descriptor
+                          L2-normalised; channel C = reference confidence */
+  int32_t h, w, C, cstride;
+  float cam[10];       /* query camera ALREADY scaled to this level */
+  int32_t ndist;
+  float lambda[6];     /* damping 10^(lo + sigmoid(const)*(hi-lo)) of this level */
+} pxt_lm_level;
+
+typedef struct {
+  int32_t num_iters;        /* per-level cap (pixloc_tracker_r9.py:47 -> 150) */
+  int32_t pad;              /* interpolation border (pixloc_tracker_r9.py:48 -> 1) */
+  int32_t loss;             /* 0 squared, 1 huber, 2 barron(alpha) */
+  float loss_alpha;         /* barron alpha (0 = Cauchy-like) */
+  float loss_scale;         /* pre/post scale `a` of pixloc scaled_loss */
+  float grad_stop;          /* ||g|| < grad_stop            -> stop */
+  float dt_stop, dR_stop;   /* dt < dt_stop AND dR(deg) < dR_stop -> stop */
+  int32_t min_valid;        /* failed |= n_valid < min_valid (10) */
+  int32_t n_workgroups;     /* persistent grid size; 0 = library default */
+} pxt_lm_conf;
+
+/* Output record (device, floats):
+ *   out[0..11]  T_refined (12)        out[12] failed (0/1)
+ *   out[13]     status (0 ok, PXT_E_TIMEOUT as float if a spin bound tripped)
+ *   out[14]     total iterations      out[15] reserved
+ *   out[16 + l] iterations run at level l (execution order), l < n_levels
+ * Log (device, optional, may be NULL): log[(l*num_iters + i)*PXT_LM_LOG_STRIDE + k]
+ *   k=0 masked-mean cost BEFORE the update of iteration i (tracker.py:40-41)
+ *   k=1 number of valid points   k=2 dR (deg) of the step   k=3 dt of the step
+ *   k=4 ||g||                    k=5 1 if the solve fell back from Cholesky to LU
+ *   k=8..19 pose after the update (12)
+ */
+int pxt_lm_refine(const float* p3d, const uint8_t* point_mask /* may be NULL */,
+                  int32_t n_points, const pxt_lm_level* levels_host, int32_t n_levels,
+                  const float* T_init /* device, 12 */, const pxt_lm_conf* conf_host,
+                  float* out /* device, 16+PXT_MAX_LEVELS */, float* log /* device or NULL */,
+                  void* workspace /* device, pxt_lm_workspace_bytes() */, void* stream);
+
+/* Bytes of scratch pxt_lm_refine needs (partials + counters), independent of N. */
+int64_t pxt_lm_workspace_bytes(void);
+
+/* -------------------------------------------------------------------------
+ * Sparse reference observations.
+ *
+ * Replaces PoseTrackerRefiner.interp_sparse_observations
+ * (pixtrack/localization/pixloc_pose_refiners.py:327-368) plus the per-point
+ * stacking/normalisation that refine_pose_using_features does afterwards (A.4):
+ * transform the reference image's 3-D points with `T`, project into the reference
+ * camera of each level, bilinearly sample the RAW (un-normalised) HWC map, L2-
+ * normalise the C descriptor channels of the sample, keep the sampled confidence in
+ * channel C.  valid[n] = 1 iff the point is visible and inside the padded image on
+ * EVERY level (line :356).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const float* fmap;  /* raw reference map, HWC [h][w][cstride] */
+  float* out;         /* [n_points][cstride] */
+  int32_t h, w, C, cstride;
+  float cam[10];      /* reference camera scaled by reference_scale and level scale */
+  int32_t ndist;
+} pxt_sample_level;
+
+int pxt_sample_sparse(const float* p3d, int32_t n_points, const float* T /* device, 12 */,
+                      const pxt_sample_level* levels_host, int32_t n_levels, int32_t pad,
+                      int32_t normalize, uint8_t* valid /* [n_points] */, void* stream);
+
+/* -------------------------------------------------------------------------
+ * UNet feature pyramid (pixloc `UNet`, experiment pixloc_megadepth).
+ *
+ * Replaces `pred = self.model({"image": image_tensor})`
+ * (pixtrack/localization/feature_extractor.py:48) including prepare_input's
+ * HWC->CHW, /255 (:31-32).  Weights live in an opaque context created from a flat
+ * host blob (layout documented in pixtrack_amd/unet.py: pack_unet_weights).
+ * ---------------------------------------------------------------------- */
+typedef struct pxt_unet pxt_unet;
+
+int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_unet** out_ctx);
+int pxt_unet_destroy(pxt_unet* ctx);
+/* Scratch the forward pass needs for an H x W input. */
+int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W);
+
+/* image: HWC, 3 channels, values 0..255 (float32 if image_is_u8 == 0, else uint8).
+ * mask: optional H x W uint8 (0/1) multiplied into the image first
+ *       (pixloc_tracker_r9.py:224-225), NULL for none.
+ * out_maps[l]: HWC float32 [h_l][w_l][cstride_l], l = 0..2 (strides 1,4,16);
+ *       channel C_l is sigmoid(-uncertainty) (A.5); if normalize != 0 the C_l
+ *       descriptor channels are L2-normalised per pixel (A.4, query side). */
+int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8, const uint8_t* mask,
+                     int32_t H, int32_t W, float* const out_maps[3], const int32_t out_cstride[3],
+                     int32_t normalize, void* workspace, void* stream);
+
+/* -------------------------------------------------------------------------
+ * instant-ngp style NeRF inference renderer.
+ *
+ * Replaces `testbed.render(width, height, spp, True)` and the setters pixtrack
+ * drives around it (pixtrack/visualization/run_vis_on_poses.py:38-56,
+ * pixtrack/utils/ingp_utils.py:22-44).
+ * ---------------------------------------------------------------------- */
+typedef struct pxt_ngp pxt_ngp;
+
+typedef struct {
+  int32_t n_levels, n_features, log2_hashmap, base_res;
+  float per_level_scale;
+  int32_t grid_cascades;   /* occupancy cascades, 128^3 each */
+  float aabb_scale;        /* scene box = [0.5 - s/2, 0.5 + s/2]^3 */
+  float cone_angle;        /* dt growth (1/256 when aabb_scale > 1) */
+  float depth_scale;       /* colour written in Depth mode = depth * depth_scale */
+} pxt_ngp_model;
+
+int pxt_ngp_create(const pxt_ngp_model* model_host, const void* grid_params_f16_host,
+                   int64_t n_grid_params, const void* mlp_params_f16_host, int64_t n_mlp_params,
+                   const uint8_t* occupancy_bits_host, int64_t n_occ_bytes, pxt_ngp** out_ctx);
+int pxt_ngp_destroy(pxt_ngp* ctx);
+
+typedef struct {
+  float cam[12];        /* camera-to-world 3x4 row-major, ALREADY in ngp coordinates */
+  float focal;          /* pixels; fov_axis = 0 (run_vis_on_poses.py:38) */
+  float k1;             /* render_with_camera_distortion (ingp_utils.py:34) */
+  float aabb_min[3], aabb_max[3]; /* render_aabb (ingp_utils.py:41-42) */
+  float background[4];  /* ingp_utils.py:23-24 */
+  float min_transmittance; /* ingp_utils.py:37 */
+  int32_t width, height, spp;
+  int32_t mode;         /* 0 Shade, 1 Depth (run_vis_on_poses.py:49-56) */
+} pxt_ngp_view;
+
+/* out_rgba: float32 [height][width][4], linear colour (render(..., linear=True)). */
+int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
+                   uint64_t* stats /* device, 4 counters or NULL */, void* stream);
+
+/* -------------------------------------------------------------------------
+ * Small image ops on the path (host cv2/numpy calls in the reference).
+ * ---------------------------------------------------------------------- */
+/* get_mask (pixloc_tracker_r9.py:207-214): depth RGBA -> uint8((d*255)) != 0 ->
+ * erode 5x5 x n_erode -> dilate 5x5 x n_dilate.  tmp: 2*H*W bytes. */
+int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int32_t n_erode,
+                   int32_t n_dilate, uint8_t* mask_out, uint8_t* tmp, void* stream);
+/* get_nerf_image tail (run_vis_on_poses.py:52-54): alpha threshold, *255, ->uint8. */
+int pxt_rgba_to_u8(const float* rgba, int32_t H, int32_t W, float alpha_thresh, uint8_t* rgb_out,
+                   void* stream);
+/* pixloc resize(image, size, max, "linear") == cv2.INTER_LINEAR on float32 HWC
+ * (feature_extractor.py:45). */
+int pxt_resize_linear(const float* src, int32_t H, int32_t W, int32_t C, float* dst, int32_t Ho,
+                      int32_t Wo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXTRACK_HIP_H */

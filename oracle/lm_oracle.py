@@ -1,0 +1,448 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the LM feature-metric
+pose refinement of the pixtrack hot path.
+
+PARITY UNPINNED: the arithmetic restated here lives in cvg/pixloc, an
+un-vendored, un-pinned submodule that is absent from /root/reference
+(.gitmodules:4-6).  The reference holds no tests or golden
+vectors for it.  This file restates pixloc's published
+algorithm in plain PyTorch-CPU, in the same operation
+order pixloc uses (grid_sample taps, einsum system build, Cholesky solve), so it
+doubles as "the reference PyTorch-CPU path" that BASELINE.json asks to be timed.
+It is anchored on the reference's own call sites:
+
+* optimizer entry  ``opt.run(p3d, F_ref, F_q, T, camera, W_ref_query=...)``
+  reached from pixtrack/localization/pixloc_pose_refiners.py:260-262 through
+  pixloc ``BaseRefiner.refine_pose_using_features``;
+* ``early_stop`` every iteration: pixtrack/optimizers/pixtrack_optimizer.py:5-18;
+* per-iteration masked-mean cost: pixtrack/localization/tracker.py:32-46;
+* sparse reference sampling: pixtrack/localization/pixloc_pose_refiners.py:327-368.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Everything is self-contained (no import from pixtrack_amd).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------
+# geometry (pixloc pixlib/geometry/{wrappers,utils}.py)
+# --------------------------------------------------------------------------
+
+
+def skew(v: torch.Tensor) -> torch.Tensor:
+    z = torch.zeros_like(v[..., 0])
+    return torch.stack(
+        [z, -v[..., 2], v[..., 1], v[..., 2], z, -v[..., 0], -v[..., 1], v[..., 0], z], -1
+    ).reshape(v.shape[:-1] + (3, 3))
+
+
+def so3exp(w: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    theta = w.norm(p=2, dim=-1, keepdim=True)
+    small = theta < eps
+    div = torch.where(small, torch.ones_like(theta), theta)
+    W = skew(w / div)
+    theta = theta[..., None]
+    res = W * torch.sin(theta) + (W @ W) * (1 - torch.cos(theta))
+    res = torch.where(small[..., None], W, res)
+    return torch.eye(3, dtype=w.dtype) + res
+
+
+def pose_transform(R, t, p3d):
+    return p3d @ R.transpose(-1, -2) + t.unsqueeze(-2)
+
+
+def pose_compose(Ra, ta, Rb, tb):
+    return Ra @ Rb, ta + (Ra @ tb.unsqueeze(-1)).squeeze(-1)
+
+
+def pose_inv(R, t):
+    Ri = R.transpose(-1, -2)
+    return Ri, -(Ri @ t.unsqueeze(-1)).squeeze(-1)
+
+
+def pose_magnitude(R, t):
+    """(dR in degrees, dt) -- pixloc Pose.magnitude()."""
+    trace = torch.diagonal(R, dim1=-1, dim2=-2).sum(-1)
+    cos = torch.clamp((trace - 1) / 2, -1, 1)
+    return torch.acos(cos).abs() / math.pi * 180, torch.norm(t, dim=-1)
+
+
+def J_transform(p3d_out):
+    return torch.cat([torch.diag_embed(torch.ones_like(p3d_out)), -skew(p3d_out)], -1)
+
+
+CAM_EPS = 1e-3
+
+
+def camera_scale(cam: torch.Tensor, s) -> torch.Tensor:
+    """cam = (w,h,fx,fy,cx,cy,dist...), pixel-centre origin; pixloc Camera.scale."""
+    if isinstance(s, (int, float)):
+        s = (s, s)
+    s = cam.new_tensor(s)
+    return torch.cat([cam[:2] * s, cam[2:4] * s, (cam[4:6] + 0.5) * s - 0.5, cam[6:]], -1)
+
+
+def _undistort(pts, dist):
+    ndist = dist.shape[-1]
+    und = pts
+    valid = torch.ones(pts.shape[:-1], dtype=torch.bool)
+    if ndist > 0:
+        k1, k2 = dist[0], dist[1]
+        r2 = torch.sum(pts**2, -1, keepdim=True)
+        radial = k1 * r2 + k2 * r2**2
+        und = und + pts * radial
+        limited = ((k2 > 0) & ((9 * k1**2 - 20 * k2) > 0)) | ((k2 <= 0) & (k1 > 0))
+        limit = torch.abs(
+            torch.where(
+                k2 > 0,
+                (torch.sqrt((9 * k1**2 - 20 * k2).clamp(min=0)) - 3 * k1) / (10 * k2),
+                1 / (3 * k1),
+            )
+        )
+        valid = valid & torch.squeeze(~limited | (r2 < limit), -1)
+        if ndist > 2:
+            p12 = dist[2:4]
+            p21 = p12.flip(-1)
+            uv = torch.prod(pts, -1, keepdim=True)
+            und = und + 2 * p12 * uv + p21 * (r2 + 2 * pts**2)
+    return und, valid
+
+
+def _J_undistort(pts, dist):
+    ndist = dist.shape[-1]
+    Jd = torch.ones_like(pts)
+    Jc = torch.zeros_like(pts)
+    if ndist > 0:
+        k1, k2 = dist[0], dist[1]
+        r2 = torch.sum(pts**2, -1, keepdim=True)
+        uv = torch.prod(pts, -1, keepdim=True)
+        radial = k1 * r2 + k2 * r2**2
+        d_radial = 2 * k1 + 4 * k2 * r2
+        Jd = Jd + radial + (pts**2) * d_radial
+        Jc = Jc + uv * d_radial
+        if ndist > 2:
+            p12 = dist[2:4]
+            p21 = p12.flip(-1)
+            Jd = Jd + 2 * p12 * pts.flip(-1) + 6 * p21 * pts
+            Jc = Jc + 2 * p12 * pts + 2 * p21 * pts.flip(-1)
+    return torch.diag_embed(Jd) + torch.diag_embed(Jc).flip(-1)
+
+
+def world2image(cam: torch.Tensor, p3d: torch.Tensor):
+    z = p3d[..., -1]
+    visible = z > CAM_EPS
+    zc = z.clamp(min=CAM_EPS)
+    pn = p3d[..., :-1] / zc.unsqueeze(-1)
+    pd, mask = _undistort(pn, cam[6:])
+    p2d = pd * cam[2:4] + cam[4:6]
+    in_img = torch.all((p2d >= 0) & (p2d <= (cam[:2] - 1)), -1)
+    return p2d, visible & mask & in_img
+
+
+def J_world2image(cam: torch.Tensor, p3d: torch.Tensor):
+    x, y, z = p3d[..., 0], p3d[..., 1], p3d[..., 2]
+    zero = torch.zeros_like(z)
+    zc = z.clamp(min=CAM_EPS)
+    Jp = torch.stack([1 / zc, zero, -x / zc**2, zero, 1 / zc, -y / zc**2], -1).reshape(
+        p3d.shape[:-1] + (2, 3)
+    )
+    pn = p3d[..., :-1] / zc.unsqueeze(-1)
+    return torch.diag_embed(cam[2:4]).unsqueeze(-3) @ _J_undistort(pn, cam[6:]) @ Jp
+
+
+# --------------------------------------------------------------------------
+# interpolation (pixloc pixlib/geometry/interpolation.py; Appendix A.3 step 2)
+# --------------------------------------------------------------------------
+
+
+def interpolate_bilinear(tensor: torch.Tensor, pts: torch.Tensor, return_gradients: bool = False):
+    """tensor C x H x W, pts N x 2 (x, y) in pixels; align_corners=True taps with
+    zero padding; gradient = central difference of the interpolant at +-1 px."""
+    c, h, w = tensor.shape
+    tensor = tensor[None]
+    scale = torch.tensor([w - 1, h - 1]).to(pts)
+    p = ((pts / scale) * 2 - 1).clamp(min=-2, max=2)[None]
+    interp = torch.nn.functional.grid_sample(tensor, p[:, None], mode="bilinear", align_corners=True)
+    interp = interp.reshape(1, c, -1).transpose(-1, -2)[0]
+    if return_gradients:
+        dxdy = torch.tensor([[1, 0], [0, 1]])[:, None].to(p) / scale * 2
+        dx, dy = dxdy.chunk(2, dim=0)
+        pts_d = torch.cat([p - dx, p + dx, p - dy, p + dy], 1)
+        td = torch.nn.functional.grid_sample(tensor, pts_d[:, None], mode="bilinear", align_corners=True)
+        td = td.reshape(1, c, -1).transpose(-1, -2)
+        x0, x1, y0, y1 = td.chunk(4, dim=1)
+        grads = torch.stack([(x1 - x0) / 2, (y1 - y0) / 2], dim=-1)[0]
+    else:
+        grads = torch.zeros(pts.shape[0], c, 2).to(tensor)
+    return interp, grads
+
+
+def mask_in_image(pts, w: int, h: int, pad: int):
+    lim = torch.tensor([w - pad - 1, h - pad - 1]).to(pts)
+    return torch.all((pts >= pad) & (pts <= lim), -1)
+
+
+def interpolator(tensor, pts, pad: int, return_gradients: bool = False):
+    h, w = tensor.shape[-2:]
+    interp, grads = interpolate_bilinear(tensor, pts, return_gradients)
+    return interp, mask_in_image(pts, w, h, pad), grads
+
+
+# --------------------------------------------------------------------------
+# robust losses (pixloc pixlib/geometry/losses.py; Appendix A.3 step 5)
+# --------------------------------------------------------------------------
+
+
+def squared_loss(x):
+    return x, torch.ones_like(x)
+
+
+def huber_loss(x):
+    mask = x <= 1
+    sx = torch.sqrt(x)
+    isx = torch.max(sx.new_tensor(torch.finfo(torch.float).eps), 1 / sx)
+    return torch.where(mask, x, 2 * sx - 1), torch.where(mask, torch.ones_like(x), isx)
+
+
+def barron_loss(x, alpha: float, eps: float = 1e-7):
+    """Barron's general robust loss on already squared+scaled input; returns
+    (loss, d loss / dx)."""
+    if alpha == 0:
+        return 2 * torch.log1p(torch.clamp(0.5 * x, max=33e37)), 2 / (x + 2)
+    if alpha == 2:
+        return x, torch.ones_like(x)
+    beta = max(abs(alpha - 2.0), eps)
+    a_safe = (1.0 if alpha >= 0 else -1.0) * max(abs(alpha), eps)
+    loss = 2 * (beta / a_safe) * (torch.pow(x / beta + 1.0, 0.5 * alpha) - 1.0)
+    return loss, torch.pow(x / beta + 1.0, 0.5 * alpha - 1.0)
+
+
+def make_loss(kind: str, alpha: float = 0.0, scale: float = 0.1):
+    """kind in {'squared','huber','barron'}; 'barron' == pixloc scaled_barron(alpha, scale)."""
+    if kind == "squared":
+        return squared_loss
+
+    def scaled(x, fn):
+        a2 = scale**2
+        l, d1 = fn(x / a2)
+        return l * a2, d1
+
+    if kind == "huber":
+        return lambda x: scaled(x, huber_loss)
+    if kind == "barron":
+        return lambda x: scaled(x, lambda y: barron_loss(y, alpha))
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------
+# the optimizer (pixloc learned_optimizer.py / base_optimizer.py / costs.py /
+# optimization.py; Appendix A.3)
+# --------------------------------------------------------------------------
+
+
+@dataclass
+class LMConf:
+    num_iters: int = 150  # pixloc_tracker_r9.py:47
+    pad: int = 1  # pixloc_tracker_r9.py:48 (builder decision)
+    loss: str = "barron"
+    loss_alpha: float = 0.0
+    loss_scale: float = 0.1
+    grad_stop_criteria: float = 1e-4
+    dt_stop_criteria: float = 5e-3
+    dR_stop_criteria: float = 5e-2  # degrees
+    log_range: Tuple[float, float] = (-6.0, 5.0)
+    min_valid: int = 10
+    early_stop_every: int = 1  # pixtrack_optimizer.py:8 ("% 1")
+
+
+def damping_lambda(const: torch.Tensor, log_range=(-6.0, 5.0)) -> torch.Tensor:
+    lo, hi = log_range
+    return 10.0 ** (lo + torch.sigmoid(const) * (hi - lo))
+
+
+def residual_jacobian(R, t, cam, p3d, F_ref, F_q, W_ref, W_q, pad):
+    p3d_q = pose_transform(R, t, p3d)
+    p2d, visible = world2image(cam, p3d_q)
+    F_p2d, valid, grads = interpolator(F_q, p2d, pad, return_gradients=True)
+    valid = valid & visible
+    if W_ref is not None:
+        C_q, _, _ = interpolator(W_q, p2d, pad, return_gradients=False)
+        weight = (W_ref * C_q).squeeze(-1).masked_fill(~valid, 0.0)
+    else:
+        weight = None
+    res = F_p2d - F_ref
+    J_p2d_T = J_world2image(cam, p3d_q) @ J_transform(p3d_q)
+    J = grads @ J_p2d_T
+    return res, valid, weight, J
+
+
+def build_system(J, res, weights):
+    grad = torch.einsum("...ndi,...nd->...ni", J, res)
+    grad = (weights[..., None] * grad).sum(-2)
+    Hess = torch.einsum("...ijk,...ijl->...ikl", J, J)
+    Hess = (weights[..., None, None] * Hess).sum(-3)
+    return grad, Hess
+
+
+def optimizer_step(g, H, lambda_, ok: bool, eps: float = 1e-6):
+    diag = H.diagonal(dim1=-2, dim2=-1) * lambda_
+    H = H + diag.clamp(min=eps).diag_embed()
+    if not ok:
+        H = torch.eye(H.shape[-1]).to(H)
+        g = torch.zeros_like(g)
+    try:
+        U = torch.linalg.cholesky(H)
+        delta = -torch.cholesky_solve(g[..., None], U)[..., 0]
+    except RuntimeError:
+        delta = -torch.linalg.solve(H, g[..., None])[..., 0]
+    return delta
+
+
+@dataclass
+class LMLog:
+    """What DebugTracker.log_optim_iter records (tracker.py:32-46), per level."""
+
+    costs: List[List[float]] = field(default_factory=list)
+    T: List[List[Tuple[torch.Tensor, torch.Tensor]]] = field(default_factory=list)
+    dt: List[List[float]] = field(default_factory=list)
+    dR: List[List[float]] = field(default_factory=list)
+    num_iters: List[int] = field(default_factory=list)
+
+
+def lm_run(
+    p3d: torch.Tensor,
+    F_ref: torch.Tensor,
+    F_q: torch.Tensor,
+    R: torch.Tensor,
+    t: torch.Tensor,
+    cam: torch.Tensor,
+    W_ref: Optional[torch.Tensor],
+    W_q: Optional[torch.Tensor],
+    lambda_: torch.Tensor,
+    conf: LMConf,
+    mask: Optional[torch.Tensor] = None,
+    log: Optional[LMLog] = None,
+):
+    """One ``LearnedOptimizer._run`` (one pyramid level).  p3d N x 3, F_ref N x C,
+    F_q C x h x w, W_ref N x 1, W_q 1 x h x w.  Returns (R, t, failed)."""
+    loss_fn = make_loss(conf.loss, conf.loss_alpha, conf.loss_scale)
+    failed = False
+    if log is not None:
+        log.costs.append([])
+        log.T.append([])
+        log.dt.append([])
+        log.dR.append([])
+        log.num_iters.append(0)
+    for i in range(conf.num_iters):
+        res, valid, w_unc, J = residual_jacobian(R, t, cam, p3d, F_ref, F_q, W_ref, W_q, conf.pad)
+        if mask is not None:
+            valid = valid & mask
+        failed = failed or bool(valid.long().sum(-1) < conf.min_valid)
+        cost = (res**2).sum(-1)
+        cost, w_loss = loss_fn(cost)
+        weights = w_loss * valid.to(res.dtype)
+        if w_unc is not None:
+            weights = weights * w_unc
+        g, H = build_system(J, res, weights)
+        delta = optimizer_step(g, H, lambda_, ok=not failed)
+        dt_, dw = delta.split([3, 3], dim=-1)
+        Rd = so3exp(dw)
+        R, t = pose_compose(Rd, dt_, R, t)
+        dR_mag, dt_mag = pose_magnitude(Rd, dt_)
+        if log is not None:
+            v = valid.to(res.dtype)
+            log.costs[-1].append(float((v * cost).sum(-1) / v.sum(-1)))
+            log.T[-1].append((R.clone(), t.clone()))
+            log.dt[-1].append(float(dt_mag))
+            log.dR[-1].append(float(dR_mag))
+            log.num_iters[-1] = i + 1
+        if (i % conf.early_stop_every) == 0:
+            small_grad = torch.norm(g, dim=-1) < conf.grad_stop_criteria
+            small_step = (dt_mag < conf.dt_stop_criteria) & (dR_mag < conf.dR_stop_criteria)
+            if bool(small_step | small_grad):
+                break
+    return R, t, failed
+
+
+def l2_normalize(x: torch.Tensor, dim: int, eps: float = 1e-12):
+    return x / x.norm(p=2, dim=dim, keepdim=True).clamp_min(eps)
+
+
+def refine_pose_using_features(
+    features_query: Sequence[torch.Tensor],
+    scales_query: Sequence[Tuple[float, float]],
+    qcamera: torch.Tensor,
+    R_init: torch.Tensor,
+    t_init: torch.Tensor,
+    features_ref: Sequence[torch.Tensor],
+    p3d: torch.Tensor,
+    lambdas: Sequence[torch.Tensor],
+    conf: LMConf,
+    mask: Optional[torch.Tensor] = None,
+    log: Optional[LMLog] = None,
+    dtype=torch.float32,
+):
+    """pixloc BaseRefiner.refine_pose_using_features.
+
+    features_query[l]: (C_l+1) x h x w with the confidence as LAST channel
+    (dense_feature_extraction's cat); features_ref[l]: N x (C_l+1).
+    Levels are run coarse -> fine with optimizer[level].  Returns dict with
+    success, R, t (float64), diff_R (deg), diff_t.
+    """
+    L = len(features_query)
+    R, t = R_init.to(dtype), t_init.to(dtype)
+    p3d = p3d.to(dtype)
+    for level in reversed(range(L)):
+        fr = features_ref[level].to(dtype)
+        F_ref, W_ref = fr[:, :-1], fr[:, -1:]
+        F_ref = l2_normalize(F_ref, dim=1)
+        fq = features_query[level].to(dtype)
+        W_q, F_q = fq[-1:], l2_normalize(fq[:-1], dim=0)
+        cam = camera_scale(qcamera.to(dtype), scales_query[level])
+        R, t, fail = lm_run(
+            p3d, F_ref, F_q, R, t, cam, W_ref, W_q, lambdas[level].to(dtype), conf, mask=mask, log=log
+        )
+        if fail:
+            return {"success": False, "R_init": R_init, "t_init": t_init}
+    R, t = R.double(), t.double()
+    Ri, ti = pose_inv(R_init.double(), t_init.double())
+    dRm, dtm = pose_magnitude(*pose_compose(Ri, ti, R, t))
+    return {"success": True, "R": R, "t": t, "diff_R": float(dRm), "diff_t": float(dtm)}
+
+
+def interp_sparse_observations(
+    feature_maps: Sequence[torch.Tensor],
+    feature_scales: Sequence[Tuple[float, float]],
+    ref_camera: torch.Tensor,
+    reference_scale: float,
+    R: torch.Tensor,
+    t: torch.Tensor,
+    p3d: torch.Tensor,
+    pad: int,
+):
+    """pixloc_pose_refiners.py:327-368: project the reference image's 3-D points
+    with ``pose`` into the reference camera (scaled by reference_scale, then by the
+    level scale) and bilinearly sample every level; a point is kept only if it is
+    valid on ALL levels.  feature_maps[l]: (C_l+1) x h x w (raw, un-normalised).
+    Returns (list of N x (C_l+1) observations, valid[N])."""
+    cam = camera_scale(ref_camera, reference_scale)
+    p3d_cam = pose_transform(R.to(p3d), t.to(p3d), p3d)
+    obs_l, masks = [], []
+    for feats, sc in zip(feature_maps, feature_scales):
+        p2d, valid = world2image(camera_scale(cam, sc), p3d_cam)
+        obs, m, _ = interpolator(feats, p2d.to(feats), pad)
+        obs_l.append(obs)
+        masks.append(m & valid)
+    return obs_l, torch.all(torch.stack(masks, 0), 0)
+
+
+def rotation_angle_rad(Ra: torch.Tensor, Rb: torch.Tensor) -> float:
+    """Geodesic distance used by the parity tolerance (1e-3 rad)."""
+    Rd = Ra.double() @ Rb.double().T
+    c = ((torch.trace(Rd) - 1) / 2).clamp(-1, 1)
+    return float(torch.acos(c))

@@ -1,0 +1,102 @@
+// Shared host/device helpers for the gfx950 kernels of the pixtrack hot path.
+// HIP/CDNA4 only: 64-lane wavefronts are assumed throughout (no other target).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pixtrack_hip.h"
+
+#define PXT_WAVE 64
+
+namespace pxt {
+
+// ---- error plumbing --------------------------------------------------------
+void set_last_error(const char* what, hipError_t e);
+#define PXT_HIP_CHECK(expr)                         \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) {                         \
+      ::pxt::set_last_error(#expr, _e);             \
+      return PXT_E_HIP;                             \
+    }                                               \
+  } while (0)
+
+// ---- camera model (pixloc Camera.world2image / J_world2image) ---
+struct Cam {
+  float w, h, fx, fy, cx, cy, k1, k2, p1, p2;
+  int ndist;
+};
+
+__host__ __device__ inline Cam make_cam(const float* c10, int ndist) {
+  Cam c;
+  c.w = c10[0]; c.h = c10[1]; c.fx = c10[2]; c.fy = c10[3]; c.cx = c10[4]; c.cy = c10[5];
+  c.k1 = c10[6]; c.k2 = c10[7]; c.p1 = c10[8]; c.p2 = c10[9];
+  c.ndist = ndist;
+  return c;
+}
+
+constexpr float kCamEps = 1e-3f;
+
+// Projects a camera-frame point.  Returns validity (z > eps, inside the
+// distortion model's monotone range, inside the image); writes pixel coords and,
+// if J != nullptr, the 2x3 Jacobian d(u,v)/d(p) in row-major order.
+__device__ inline bool project_point(const Cam& c, float x, float y, float z, float& u, float& v,
+                                     float* J /* 6 or nullptr */) {
+  bool visible = z > kCamEps;
+  float zc = fmaxf(z, kCamEps);
+  float iz = 1.0f / zc;
+  float xn = x * iz, yn = y * iz;
+  float xd = xn, yd = yn;
+  bool dist_ok = true;
+  float Jd00 = 1.f, Jd01 = 0.f, Jd10 = 0.f, Jd11 = 1.f;
+  if (c.ndist > 0) {
+    float r2 = xn * xn + yn * yn;
+    float radial = c.k1 * r2 + c.k2 * r2 * r2;
+    xd = xn + xn * radial;
+    yd = yn + yn * radial;
+    float disc = 9.f * c.k1 * c.k1 - 20.f * c.k2;
+    bool limited = ((c.k2 > 0.f) && (disc > 0.f)) || ((c.k2 <= 0.f) && (c.k1 > 0.f));
+    if (limited) {
+      float limit = (c.k2 > 0.f) ? (sqrtf(fmaxf(disc, 0.f)) - 3.f * c.k1) / (10.f * c.k2)
+                                 : 1.f / (3.f * c.k1);
+      dist_ok = r2 < fabsf(limit);
+    }
+    float uv = xn * yn;
+    float d_radial = 2.f * c.k1 + 4.f * c.k2 * r2;
+    Jd00 += radial + xn * xn * d_radial;
+    Jd11 += radial + yn * yn * d_radial;
+    Jd01 += uv * d_radial;
+    Jd10 += uv * d_radial;
+    if (c.ndist > 2) {
+      xd += 2.f * c.p1 * uv + c.p2 * (r2 + 2.f * xn * xn);
+      yd += 2.f * c.p2 * uv + c.p1 * (r2 + 2.f * yn * yn);
+      Jd00 += 2.f * c.p1 * yn + 6.f * c.p2 * xn;
+      Jd11 += 2.f * c.p2 * xn + 6.f * c.p1 * yn;
+      Jd01 += 2.f * c.p1 * xn + 2.f * c.p2 * yn;
+      Jd10 += 2.f * c.p2 * yn + 2.f * c.p1 * xn;
+    }
+  }
+  u = xd * c.fx + c.cx;
+  v = yd * c.fy + c.cy;
+  bool in_img = (u >= 0.f) && (v >= 0.f) && (u <= c.w - 1.f) && (v <= c.h - 1.f);
+  if (J) {
+    // J_project rows: [1/z, 0, -x/z^2], [0, 1/z, -y/z^2] with the clamped z.
+    float a = iz, bx = -x * iz * iz, by = -y * iz * iz;
+    // (diag(f) * Jd) * Jproj
+    float m00 = c.fx * Jd00, m01 = c.fx * Jd01, m10 = c.fy * Jd10, m11 = c.fy * Jd11;
+    J[0] = m00 * a; J[1] = m01 * a; J[2] = m00 * bx + m01 * by;
+    J[3] = m10 * a; J[4] = m11 * a; J[5] = m10 * bx + m11 * by;
+  }
+  return visible && dist_ok && in_img;
+}
+
+// Wave-level butterfly sum over `width` consecutive lanes (width a power of two).
+template <int WIDTH>
+__device__ inline float group_allreduce_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < WIDTH; m <<= 1) v += __shfl_xor(v, m, PXT_WAVE);
+  return v;
+}
+
+}  // namespace pxt

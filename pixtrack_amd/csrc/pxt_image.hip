@@ -1,0 +1,127 @@
+// Small image kernels on the tracking path (cv2 / numpy calls in the reference).
+// All are HBM-bound elementwise / stencil passes over at most a few MB.
+#include "pxt_common.h"
+
+namespace pxt {
+
+// get_mask head (pixloc_tracker_r9.py:210-212 with run_vis_on_poses.py:53-54):
+// depth image = float RGBA * 255 cast to uint8 (C truncation, wraps mod 256), then
+// `!= 0` per channel.  All three colour channels carry the same depth, so one plane
+// is kept.
+__global__ void depth_nonzero_kernel(const float* __restrict__ rgba, int n, uint8_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = rgba[4 * (size_t)i] * 255.0f;
+  // numpy float32 -> uint8 astype: truncate toward zero then keep the low 8 bits
+  // (values are non-negative here).
+  long long t = (long long)v;
+  out[i] = ((t & 255) != 0) ? 1 : 0;
+}
+
+// 5x5 erosion / dilation with an all-ones kernel, OpenCV default border handling:
+// erode pads with +inf (border pixels ignore the outside), dilate pads with -inf.
+template <bool ERODE>
+__global__ void morph5_kernel(const uint8_t* __restrict__ src, int H, int W, uint8_t* __restrict__ dst) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) return;
+  uint8_t r = ERODE ? 255 : 0;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      uint8_t v = src[(size_t)yy * W + xx];
+      r = ERODE ? min(r, v) : max(r, v);
+    }
+  }
+  dst[(size_t)y * W + x] = r;
+}
+
+// get_nerf_image tail (run_vis_on_poses.py:52-54): zero where alpha < thresh, *255,
+// astype(uint8).
+__global__ void rgba_to_u8_kernel(const float* __restrict__ rgba, int n, float alpha_thresh,
+                                  uint8_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = *(const float4*)(rgba + 4 * (size_t)i);
+  if (p.w < alpha_thresh) p.x = p.y = p.z = 0.f;
+  out[3 * (size_t)i + 0] = (uint8_t)((long long)(p.x * 255.0f) & 255);
+  out[3 * (size_t)i + 1] = (uint8_t)((long long)(p.y * 255.0f) & 255);
+  out[3 * (size_t)i + 2] = (uint8_t)((long long)(p.z * 255.0f) & 255);
+}
+
+// cv2.resize(..., interpolation=INTER_LINEAR) on float32 HWC: half-pixel centres,
+// source coordinate clamped so both taps stay inside, no antialiasing.
+__global__ void resize_linear_kernel(const float* __restrict__ src, int H, int W, int C,
+                                     float* __restrict__ dst, int Ho, int Wo) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= Wo || y >= Ho) return;
+  const float sx = (float)W / (float)Wo, sy = (float)H / (float)Ho;
+  float fx = ((float)x + 0.5f) * sx - 0.5f;
+  float fy = ((float)y + 0.5f) * sy - 0.5f;
+  int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+  float ax = fx - (float)x0, ay = fy - (float)y0;
+  if (x0 < 0) { x0 = 0; ax = 0.f; }
+  if (x0 >= W - 1) { x0 = W - 1; ax = 0.f; }
+  if (y0 < 0) { y0 = 0; ay = 0.f; }
+  if (y0 >= H - 1) { y0 = H - 1; ay = 0.f; }
+  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  for (int c = 0; c < C; ++c) {
+    float a = src[((size_t)y0 * W + x0) * C + c], b = src[((size_t)y0 * W + x1) * C + c];
+    float d = src[((size_t)y1 * W + x0) * C + c], e = src[((size_t)y1 * W + x1) * C + c];
+    float top = a * (1.f - ax) + b * ax;
+    float bot = d * (1.f - ax) + e * ax;
+    dst[((size_t)y * Wo + x) * C + c] = top * (1.f - ay) + bot * ay;
+  }
+}
+
+}  // namespace pxt
+
+using namespace pxt;
+
+extern "C" int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int32_t n_erode,
+                              int32_t n_dilate, uint8_t* mask_out, uint8_t* tmp, void* stream) {
+  if (!depth_rgba || !mask_out || !tmp || H < 1 || W < 1 || n_erode < 0 || n_dilate < 0)
+    return PXT_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = H * W;
+  uint8_t* a = tmp;
+  uint8_t* b = tmp + n;
+  hipLaunchKernelGGL(depth_nonzero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, depth_rgba, n, a);
+  dim3 blk(64, 4), grd((W + 63) / 64, (H + 3) / 4);
+  for (int i = 0; i < n_erode; ++i) {
+    hipLaunchKernelGGL(morph5_kernel<true>, grd, blk, 0, s, a, H, W, b);
+    uint8_t* t = a; a = b; b = t;
+  }
+  for (int i = 0; i < n_dilate; ++i) {
+    hipLaunchKernelGGL(morph5_kernel<false>, grd, blk, 0, s, a, H, W, b);
+    uint8_t* t = a; a = b; b = t;
+  }
+  PXT_HIP_CHECK(hipMemcpyAsync(mask_out, a, n, hipMemcpyDeviceToDevice, s));
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_rgba_to_u8(const float* rgba, int32_t H, int32_t W, float alpha_thresh,
+                              uint8_t* rgb_out, void* stream) {
+  if (!rgba || !rgb_out || H < 1 || W < 1) return PXT_E_ARG;
+  const int n = H * W;
+  hipLaunchKernelGGL(rgba_to_u8_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     rgba, n, alpha_thresh, rgb_out);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_resize_linear(const float* src, int32_t H, int32_t W, int32_t C, float* dst,
+                                 int32_t Ho, int32_t Wo, void* stream) {
+  if (!src || !dst || H < 1 || W < 1 || C < 1 || Ho < 1 || Wo < 1) return PXT_E_ARG;
+  dim3 blk(64, 4), grd((Wo + 63) / 64, (Ho + 3) / 4);
+  hipLaunchKernelGGL(resize_linear_kernel, grd, blk, 0, (hipStream_t)stream, src, H, W, C, dst, Ho, Wo);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}

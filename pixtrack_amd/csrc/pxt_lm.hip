@@ -1,0 +1,728 @@
+// Fused Levenberg-Marquardt feature-metric pose refinement for gfx950 (MI355X).
+//
+// One PERSISTENT launch runs every iteration of every pyramid level: project the
+// 3-D points, gather the 12-texel cross footprint of the 5 bilinear taps from the
+// HWC query map, form residuals / robust + confidence weights / the 6x6 normal
+// equations, solve the damped system, update the pose, test the stop criteria --
+// with no host round trip (the reference path syncs twice per iteration: H,g to
+// the CPU for Cholesky and the early-stop test).
+//
+// What it replaces: pixloc LearnedOptimizer._run / DirectAbsoluteCost /
+// optimizer_step as driven by pixtrack/localization/pixloc_pose_refiners.py:260-262
+// with pixtrack/optimizers/pixtrack_optimizer.py:5-18 (stop test every iteration)
+// and pixtrack/localization/tracker.py:32-46 (masked-mean cost per iteration).
+//
+// Mapping to the machine
+//  * A point is owned by a lane GROUP of LG lanes (8 for C<=32, 32 otherwise);
+//    each lane owns 4 consecutive channels, so one texel of the HWC map is read
+//    by the group as one contiguous LG*16 B segment (dwordx4 per lane).
+//  * Because J = gradF (C x 2) * Jp (2 x 6), J^T J = Jp^T (gradF^T gradF) Jp:
+//    only SIX scalars per point (sum r^2, gradF^T r (2), gradF^T gradF (3)) are
+//    reduced across the group's lanes (xor butterflies); the 6+21 entries of g/H
+//    are then formed once per point and accumulated in registers.
+//  * Workgroups are persistent and co-resident (grid <= #CUs).  Per iteration
+//    each publishes 32 floats (g, upper H, cost sum, valid count) with
+//    write-through (sc1) stores, arrives on one monotonic counter, and then EVERY
+//    workgroup reads all partials (sc1 loads), reduces them in a fixed order and
+//    redundantly solves the 6x6 system, so a single arrive/wait per iteration is
+//    the only inter-workgroup synchronisation (cdna_hip_programming.md G16 R1;
+//    results are bit-identical across workgroups and across runs).
+#include "pxt_common.h"
+
+namespace pxt {
+
+constexpr int kLmBlock = 512;
+constexpr int kLmWaves = kLmBlock / PXT_WAVE;
+constexpr int kLmMaxGrid = 256;
+constexpr int kNAcc = 32;  // 6 g + 21 H + cost sum + n_valid + pad
+constexpr int kGrpStride = 33;  // padded: leaders of one wave hit distinct banks
+constexpr unsigned kSpinLimit = 1u << 24;
+
+struct LmLevelDev {
+  const float* fmap;
+  const float* fref;
+  int h, w, C, cs;
+  float cam[10];
+  int ndist;
+  float lambda[6];
+};
+
+struct LmParams {
+  const float* p3d;
+  const uint8_t* mask;
+  int n, n_levels;
+  LmLevelDev lv[PXT_MAX_LEVELS];
+  const float* T_init;
+  pxt_lm_conf conf;
+  float* out;
+  float* log;
+  float* partials;     // [2][grid][kNAcc]
+  unsigned* counter;   // monotonic arrivals
+  unsigned* err;       // sticky error word
+};
+
+__device__ inline void robust_loss(int kind, float alpha, float scale, float x, float& loss,
+                                   float& w) {
+  // pixloc losses.py: scaled_loss(x, fn, a) = (a^2 fn(x/a^2), fn'(x/a^2)).
+  if (kind == 0) {
+    loss = x;
+    w = 1.f;
+    return;
+  }
+  float a2 = scale * scale;
+  float y = x / a2;
+  float l, d;
+  if (kind == 1) {  // huber
+    if (y <= 1.f) {
+      l = y;
+      d = 1.f;
+    } else {
+      float sy = sqrtf(y);
+      l = 2.f * sy - 1.f;
+      d = fmaxf(1.1920929e-07f, 1.f / sy);
+    }
+  } else {  // barron(alpha)
+    if (alpha == 0.f) {
+      l = 2.f * log1pf(fminf(0.5f * y, 33e37f));
+      d = 2.f / (y + 2.f);
+    } else if (alpha == 2.f) {
+      l = y;
+      d = 1.f;
+    } else {
+      float beta = fmaxf(fabsf(alpha - 2.f), 1e-7f);
+      float as = (alpha >= 0.f ? 1.f : -1.f) * fmaxf(fabsf(alpha), 1e-7f);
+      l = 2.f * (beta / as) * (powf(y / beta + 1.f, 0.5f * alpha) - 1.f);
+      d = powf(y / beta + 1.f, 0.5f * alpha - 1.f);
+    }
+  }
+  loss = l * a2;
+  w = d;
+}
+
+// Accumulates this workgroup's share of one LM iteration at one level.
+// acc[0..5] = g, acc[6..26] = upper-triangular H (row-major), acc[27] = sum of
+// valid robust costs, acc[28] = number of valid points.
+// LG (lanes per point) is 8 or 32, wave-uniform at run time.
+__device__ inline float lm_group_sum(float v, bool wide) {
+  v += __shfl_xor(v, 1, PXT_WAVE);
+  v += __shfl_xor(v, 2, PXT_WAVE);
+  v += __shfl_xor(v, 4, PXT_WAVE);
+  if (wide) {
+    v += __shfl_xor(v, 8, PXT_WAVE);
+    v += __shfl_xor(v, 16, PXT_WAVE);
+  }
+  return v;
+}
+
+__device__ inline void lm_accumulate(const LmParams& P, const LmLevelDev& L, const float* T,
+                                     float* acc, const int LG) {
+  const bool wide = LG == 32;
+  const int GPW = PXT_WAVE / LG;  // groups per wave
+  const int lane = threadIdx.x & (PXT_WAVE - 1);
+  const int sub = lane & (LG - 1);
+  const int grp = wide ? (lane >> 5) : (lane >> 3);
+  const int wave = threadIdx.x / PXT_WAVE;
+  const int wave_global = blockIdx.x * kLmWaves + wave;
+  const int stride = gridDim.x * kLmWaves * GPW;
+  const Cam cam = make_cam(L.cam, L.ndist);
+  const int W = L.w, H = L.h, C = L.C, cs = L.cs;
+  const float pad = (float)P.conf.pad;
+
+#pragma unroll 1
+  for (int base = wave_global * GPW; base < P.n; base += stride) {
+    const int n = base + grp;
+    bool valid = n < P.n;
+    float X = 0.f, Y = 0.f, Z = 1.f;
+    if (valid) {
+      X = P.p3d[3 * n];
+      Y = P.p3d[3 * n + 1];
+      Z = P.p3d[3 * n + 2];
+      if (P.mask) valid = P.mask[n] != 0;
+    }
+    const float px = T[0] * X + T[1] * Y + T[2] * Z + T[9];
+    const float py = T[3] * X + T[4] * Y + T[5] * Z + T[10];
+    const float pz = T[6] * X + T[7] * Y + T[8] * Z + T[11];
+    float u, v, Jw[6];
+    valid = project_point(cam, px, py, pz, u, v, Jw) && valid;
+    valid = valid && (u >= pad) && (v >= pad) && (u <= (float)(W - 1) - pad) &&
+            (v <= (float)(H - 1) - pad);
+    if (!valid) continue;  // group-uniform: contributes nothing (weight 0, not counted)
+
+    const float fu = floorf(u), fv = floorf(v);
+    const int ix0 = (int)fu, iy0 = (int)fv;
+    const float ax = u - fu, ay = v - fv;
+    const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay,
+                w11 = ax * ay;
+    // Column / row indices of the 4x4 neighbourhood, clamped for addressing; texels
+    // outside the map count as zero (grid_sample padding_mode='zeros').
+    int xi[4], yi[4];
+    float xm[4], ym[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int xx = ix0 - 1 + k, yy = iy0 - 1 + k;
+      xm[k] = (xx >= 0 && xx < W) ? 1.f : 0.f;
+      ym[k] = (yy >= 0 && yy < H) ? 1.f : 0.f;
+      xi[k] = min(max(xx, 0), W - 1);
+      yi[k] = min(max(yy, 0), H - 1);
+    }
+    const float* row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) row[k] = L.fmap + (size_t)yi[k] * W * cs;
+
+    float s_cost = 0.f, A0 = 0.f, A1 = 0.f, B00 = 0.f, B01 = 0.f, B11 = 0.f;
+#pragma unroll 1
+    for (int c0 = 4 * sub; c0 < C; c0 += 4 * LG) {
+      // 12-texel cross footprint: rows 0,3 use columns 1,2; rows 1,2 use columns 0..3.
+      float4 t01 = *(const float4*)(row[0] + (size_t)xi[1] * cs + c0);
+      float4 t02 = *(const float4*)(row[0] + (size_t)xi[2] * cs + c0);
+      float4 t10 = *(const float4*)(row[1] + (size_t)xi[0] * cs + c0);
+      float4 t11 = *(const float4*)(row[1] + (size_t)xi[1] * cs + c0);
+      float4 t12 = *(const float4*)(row[1] + (size_t)xi[2] * cs + c0);
+      float4 t13 = *(const float4*)(row[1] + (size_t)xi[3] * cs + c0);
+      float4 t20 = *(const float4*)(row[2] + (size_t)xi[0] * cs + c0);
+      float4 t21 = *(const float4*)(row[2] + (size_t)xi[1] * cs + c0);
+      float4 t22 = *(const float4*)(row[2] + (size_t)xi[2] * cs + c0);
+      float4 t23 = *(const float4*)(row[2] + (size_t)xi[3] * cs + c0);
+      float4 t31 = *(const float4*)(row[3] + (size_t)xi[1] * cs + c0);
+      float4 t32 = *(const float4*)(row[3] + (size_t)xi[2] * cs + c0);
+      float4 fr = *(const float4*)(L.fref + (size_t)n * cs + c0);
+      const float m01 = ym[0] * xm[1], m02 = ym[0] * xm[2];
+      const float m10 = ym[1] * xm[0], m11 = ym[1] * xm[1], m12 = ym[1] * xm[2],
+                  m13 = ym[1] * xm[3];
+      const float m20 = ym[2] * xm[0], m21 = ym[2] * xm[1], m22 = ym[2] * xm[2],
+                  m23 = ym[2] * xm[3];
+      const float m31 = ym[3] * xm[1], m32 = ym[3] * xm[2];
+#define PXT_LM_CH(q)                                                                          \
+  {                                                                                           \
+    const float a01 = t01.q * m01, a02 = t02.q * m02, a10 = t10.q * m10, a11 = t11.q * m11,   \
+                a12 = t12.q * m12, a13 = t13.q * m13, a20 = t20.q * m20, a21 = t21.q * m21,   \
+                a22 = t22.q * m22, a23 = t23.q * m23, a31 = t31.q * m31, a32 = t32.q * m32;   \
+    const float F = w00 * a11 + w10 * a12 + w01 * a21 + w11 * a22;                            \
+    const float Fxp = w00 * a12 + w10 * a13 + w01 * a22 + w11 * a23;                          \
+    const float Fxm = w00 * a10 + w10 * a11 + w01 * a20 + w11 * a21;                          \
+    const float Fyp = w00 * a21 + w10 * a22 + w01 * a31 + w11 * a32;                          \
+    const float Fym = w00 * a01 + w10 * a02 + w01 * a11 + w11 * a12;                          \
+    const float gx = 0.5f * (Fxp - Fxm), gy = 0.5f * (Fyp - Fym);                             \
+    const float r = F - fr.q;                                                                 \
+    s_cost += r * r;                                                                          \
+    A0 += r * gx;                                                                             \
+    A1 += r * gy;                                                                             \
+    B00 += gx * gx;                                                                           \
+    B01 += gx * gy;                                                                           \
+    B11 += gy * gy;                                                                           \
+  }
+      PXT_LM_CH(x) PXT_LM_CH(y) PXT_LM_CH(z) PXT_LM_CH(w)
+#undef PXT_LM_CH
+    }
+    // Confidence: bilinear sample of channel C (same address for the whole group).
+    const float q11 = row[1][(size_t)xi[1] * cs + C] * (ym[1] * xm[1]);
+    const float q12 = row[1][(size_t)xi[2] * cs + C] * (ym[1] * xm[2]);
+    const float q21 = row[2][(size_t)xi[1] * cs + C] * (ym[2] * xm[1]);
+    const float q22 = row[2][(size_t)xi[2] * cs + C] * (ym[2] * xm[2]);
+    const float wq = w00 * q11 + w10 * q12 + w01 * q21 + w11 * q22;
+    const float wref = L.fref[(size_t)n * cs + C];
+
+    s_cost = lm_group_sum(s_cost, wide);
+    A0 = lm_group_sum(A0, wide);
+    A1 = lm_group_sum(A1, wide);
+    B00 = lm_group_sum(B00, wide);
+    B01 = lm_group_sum(B01, wide);
+    B11 = lm_group_sum(B11, wide);
+
+    float rcost, wl;
+    robust_loss(P.conf.loss, P.conf.loss_alpha, P.conf.loss_scale, s_cost, rcost, wl);
+    const float wgt = wl * (wref * wq);
+
+    // Jp = d(u,v)/d(delta) = Jw (2x3) * [I | -[p]x] (3x6), translation columns first.
+    float J0[6], J1[6];
+    J0[0] = Jw[0]; J0[1] = Jw[1]; J0[2] = Jw[2];
+    J1[0] = Jw[3]; J1[1] = Jw[4]; J1[2] = Jw[5];
+    // -[p]x = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
+    J0[3] = -Jw[1] * pz + Jw[2] * py;
+    J0[4] = Jw[0] * pz - Jw[2] * px;
+    J0[5] = -Jw[0] * py + Jw[1] * px;
+    J1[3] = -Jw[4] * pz + Jw[5] * py;
+    J1[4] = Jw[3] * pz - Jw[5] * px;
+    J1[5] = -Jw[3] * py + Jw[4] * px;
+    float M0[6], M1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      M0[k] = B00 * J0[k] + B01 * J1[k];
+      M1[k] = B01 * J0[k] + B11 * J1[k];
+      acc[k] += wgt * (J0[k] * A0 + J1[k] * A1);
+    }
+    int idx = 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int l = k; l < 6; ++l) acc[idx++] += wgt * (J0[k] * M0[l] + J1[k] * M1[l]);
+    acc[27] += rcost;
+    acc[28] += 1.f;
+  }
+}
+
+__device__ inline unsigned ld_relaxed_u32(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Damped 6x6 solve (pixloc optimizer_step): H += diag(clamp(diag(H)*lambda, 1e-6));
+// Cholesky, falling back to pivoted LU if a pivot is not positive.
+__device__ inline bool solve6(const float* tot, const float* lambda, bool ok, float* delta) {
+  float Hm[6][6], g[6];
+  int idx = 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    g[k] = tot[k];
+#pragma unroll
+    for (int l = k; l < 6; ++l) {
+      Hm[k][l] = tot[idx];
+      Hm[l][k] = tot[idx];
+      ++idx;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Hm[k][k] += fmaxf(Hm[k][k] * lambda[k], 1e-6f);
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      g[k] = 0.f;
+#pragma unroll
+      for (int l = 0; l < 6; ++l) Hm[k][l] = (k == l) ? 1.f : 0.f;
+    }
+  }
+  // Cholesky H = L L^T, fully unrolled so every entry stays in a register.
+  float Lm[6][6];
+  bool chol_ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = Hm[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
+    chol_ok = chol_ok && (d > 0.f);
+    const float dj = sqrtf(d);
+    Lm[j][j] = dj;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float s = Hm[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
+      Lm[i][j] = s / dj;
+    }
+  }
+  if (chol_ok) {
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float s = g[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= Lm[i][k] * y[k];
+      y[i] = s / Lm[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      float s = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) s -= Lm[k][i] * delta[k];
+      delta[i] = s / Lm[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) delta[i] = -delta[i];
+    return true;
+  }
+  // LU with partial pivoting on [H | g].
+  float A[6][7];
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) A[i][j] = Hm[i][j];
+    A[i][6] = g[i];
+  }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    float best = fabsf(A[c][c]);
+    for (int r = c + 1; r < 6; ++r)
+      if (fabsf(A[r][c]) > best) {
+        best = fabsf(A[r][c]);
+        piv = r;
+      }
+    if (piv != c)
+      for (int j = 0; j < 7; ++j) {
+        float tmp = A[c][j];
+        A[c][j] = A[piv][j];
+        A[piv][j] = tmp;
+      }
+    for (int r = c + 1; r < 6; ++r) {
+      float f = A[r][c] / A[c][c];
+      for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  for (int i = 5; i >= 0; --i) {
+    float s = A[i][6];
+    for (int k = i + 1; k < 6; ++k) s -= A[i][k] * delta[k];
+    delta[i] = s / A[i][i];
+  }
+  for (int i = 0; i < 6; ++i) delta[i] = -delta[i];
+  return false;
+}
+
+// T <- (so3exp(dw), dt) @ T ; returns (dR deg, dt) of the step (pixloc Pose.magnitude).
+__device__ inline void apply_delta(const float* delta, float* T, float& dR_deg, float& dt_mag) {
+  const float wx = delta[3], wy = delta[4], wz = delta[5];
+  const float theta = sqrtf(wx * wx + wy * wy + wz * wz);
+  float Rd[9];
+  if (theta < 1e-7f) {
+    Rd[0] = 1.f; Rd[1] = -wz; Rd[2] = wy;
+    Rd[3] = wz;  Rd[4] = 1.f; Rd[5] = -wx;
+    Rd[6] = -wy; Rd[7] = wx;  Rd[8] = 1.f;
+  } else {
+    const float x = wx / theta, y = wy / theta, z = wz / theta;
+    const float s = sinf(theta), c1 = 1.f - cosf(theta);
+    // W = [[0,-z,y],[z,0,-x],[-y,x,0]],  W^2 = w w^T - I (unit w)
+    Rd[0] = 1.f + c1 * (x * x - 1.f);
+    Rd[1] = -s * z + c1 * (x * y);
+    Rd[2] = s * y + c1 * (x * z);
+    Rd[3] = s * z + c1 * (x * y);
+    Rd[4] = 1.f + c1 * (y * y - 1.f);
+    Rd[5] = -s * x + c1 * (y * z);
+    Rd[6] = -s * y + c1 * (x * z);
+    Rd[7] = s * x + c1 * (y * z);
+    Rd[8] = 1.f + c1 * (z * z - 1.f);
+  }
+  float Tn[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      Tn[3 * i + j] = Rd[3 * i] * T[j] + Rd[3 * i + 1] * T[3 + j] + Rd[3 * i + 2] * T[6 + j];
+    Tn[9 + i] = Rd[3 * i] * T[9] + Rd[3 * i + 1] * T[10] + Rd[3 * i + 2] * T[11] + delta[i];
+  }
+  for (int i = 0; i < 12; ++i) T[i] = Tn[i];
+  const float tr = Rd[0] + Rd[4] + Rd[8];
+  const float cs = fminf(fmaxf((tr - 1.f) * 0.5f, -1.f), 1.f);
+  dR_deg = fabsf(acosf(cs)) / 3.14159265358979323846f * 180.f;
+  dt_mag = sqrtf(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+}
+
+__global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
+  __shared__ float s_grp[(kLmBlock / 8) * kGrpStride];
+  __shared__ float s_red[kLmMaxGrid * kNAcc];
+  __shared__ float s_tot[kNAcc];
+  __shared__ float s_T[12];
+  __shared__ int s_flags[4];  // 0 stop level, 1 failed, 2 abort
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (PXT_WAVE - 1);
+  const int wave = tid / PXT_WAVE;
+  const int G = gridDim.x;
+
+  if (tid < 12) s_T[tid] = P.T_init[tid];
+  if (tid == 0) {
+    s_flags[0] = 0;
+    s_flags[1] = 0;
+    s_flags[2] = 0;
+  }
+  __syncthreads();
+
+  unsigned epoch = 0;
+  int total_iters = 0;
+  bool failed = false;
+  bool aborted = false;
+
+  for (int li = 0; li < P.n_levels && !failed && !aborted; ++li) {
+    const LmLevelDev& L = P.lv[li];
+    int iters_done = 0;
+    for (int it = 0; it < P.conf.num_iters; ++it) {
+      float T[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) T[i] = s_T[i];
+
+      float acc[kNAcc];
+#pragma unroll
+      for (int i = 0; i < kNAcc; ++i) acc[i] = 0.f;
+      const int LGr = (L.C <= 32) ? 8 : 32;
+      lm_accumulate(P, L, T, acc, LGr);
+
+      // Every lane of a group holds the same sums: the group leader parks them in
+      // LDS and 32 threads fold the groups of the block in a fixed order.
+      const int n_groups = kLmBlock / LGr;
+      if ((lane & (LGr - 1)) == 0) {
+        float* dst = s_grp + (tid / LGr) * kGrpStride;
+#pragma unroll
+        for (int i = 0; i < 29; ++i) dst[i] = acc[i];
+      }
+      __syncthreads();
+
+      float* part = P.partials + ((size_t)(epoch & 1u) * G + blockIdx.x) * kNAcc;
+      if (wave == 0) {
+        if (lane < kNAcc) {
+          float s = 0.f;
+          if (lane < 29)
+            for (int q = 0; q < n_groups; ++q) s += s_grp[q * kGrpStride + lane];
+          // write-through store: visible to every XCD without a release fence
+          __hip_atomic_store(part + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          __hip_atomic_fetch_add(P.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned target = (unsigned)G * (epoch + 1u);
+          unsigned spins = 0;
+          while (ld_relaxed_u32(P.counter) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit || (((spins & 1023u) == 0u) && ld_relaxed_u32(P.err) != 0u)) {
+              __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              s_flags[2] = 1;
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (s_flags[2]) {
+        aborted = true;
+        break;
+      }
+
+      // All-gather of the partials (sc1 loads bypass this CU's L1).
+      const float* all = P.partials + (size_t)(epoch & 1u) * G * kNAcc;
+      for (int i = tid; i < G * kNAcc; i += kLmBlock)
+        s_red[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (tid < kNAcc) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += s_red[g * kNAcc + tid];
+        s_tot[tid] = s;
+      }
+      __syncthreads();
+
+      if (tid == 0) {
+        const float n_valid = s_tot[28];
+        bool fl = (s_flags[1] != 0) || (n_valid < (float)P.conf.min_valid);
+        float delta[6];
+        const bool chol = solve6(s_tot, L.lambda, !fl, delta);
+        float Tn[12];
+        for (int i = 0; i < 12; ++i) Tn[i] = s_T[i];
+        float dR, dt;
+        apply_delta(delta, Tn, dR, dt);
+        for (int i = 0; i < 12; ++i) s_T[i] = Tn[i];
+        float gn = 0.f;
+        for (int i = 0; i < 6; ++i) gn += s_tot[i] * s_tot[i];
+        gn = sqrtf(gn);
+        const bool small_step = (dt < P.conf.dt_stop) && (dR < P.conf.dR_stop);
+        const bool small_grad = gn < P.conf.grad_stop;
+        s_flags[0] = (small_step || small_grad) ? 1 : 0;
+        s_flags[1] = fl ? 1 : 0;
+        if (blockIdx.x == 0 && P.log) {
+          float* lg = P.log + ((size_t)li * P.conf.num_iters + it) * PXT_LM_LOG_STRIDE;
+          lg[0] = s_tot[27] / n_valid;
+          lg[1] = n_valid;
+          lg[2] = dR;
+          lg[3] = dt;
+          lg[4] = gn;
+          lg[5] = chol ? 0.f : 1.f;
+          lg[6] = 0.f;
+          lg[7] = 0.f;
+          for (int i = 0; i < 12; ++i) lg[8 + i] = Tn[i];
+        }
+      }
+      __syncthreads();
+      ++epoch;
+      ++iters_done;
+      ++total_iters;
+      failed = s_flags[1] != 0;
+      if (s_flags[0]) break;
+    }
+    if (blockIdx.x == 0 && tid == 0) P.out[16 + li] = (float)iters_done;
+  }
+
+  if (blockIdx.x == 0 && tid == 0) {
+    for (int i = 0; i < 12; ++i) P.out[i] = s_T[i];
+    P.out[12] = failed ? 1.f : 0.f;
+    P.out[13] = aborted ? (float)PXT_E_TIMEOUT : 0.f;
+    P.out[14] = (float)total_iters;
+    P.out[15] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sparse reference observations (pixloc_pose_refiners.py:327-368 + A.4).
+// ---------------------------------------------------------------------------
+struct SampleLevelDev {
+  const float* fmap;
+  float* out;
+  int h, w, C, cs;
+  float cam[10];
+  int ndist;
+};
+
+struct SampleParams {
+  const float* p3d;
+  const float* T;
+  int n, n_levels, pad, normalize;
+  SampleLevelDev lv[PXT_MAX_LEVELS];
+  uint8_t* valid;
+};
+
+template <int LG>
+__device__ inline bool sample_level(const SampleParams& P, const SampleLevelDev& L, int n,
+                                    bool active, float px, float py, float pz, int sub) {
+  const Cam cam = make_cam(L.cam, L.ndist);
+  const int W = L.w, H = L.h, C = L.C, cs = L.cs;
+  const float pad = (float)P.pad;
+  float u = 0.f, v = 0.f;
+  bool valid = project_point(cam, px, py, pz, u, v, nullptr) && active;
+  valid = valid && (u >= pad) && (v >= pad) && (u <= (float)(W - 1) - pad) &&
+          (v <= (float)(H - 1) - pad);
+  if (!active) return false;
+  float* o = L.out + (size_t)n * cs;
+  if (!valid) {
+    for (int c0 = 4 * sub; c0 < cs; c0 += 4 * LG) *(float4*)(o + c0) = make_float4(0, 0, 0, 0);
+    return false;
+  }
+  const float fu = floorf(u), fv = floorf(v);
+  const int ix0 = (int)fu, iy0 = (int)fv;
+  const float ax = u - fu, ay = v - fv;
+  const int x1 = min(ix0 + 1, W - 1), y1 = min(iy0 + 1, H - 1);
+  const float mx = (ix0 + 1 < W) ? 1.f : 0.f, my = (iy0 + 1 < H) ? 1.f : 0.f;
+  const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay) * mx, w01 = (1.f - ax) * ay * my,
+              w11 = ax * ay * mx * my;
+  const float* p00 = L.fmap + ((size_t)iy0 * W + ix0) * cs;
+  const float* p10 = L.fmap + ((size_t)iy0 * W + x1) * cs;
+  const float* p01 = L.fmap + ((size_t)y1 * W + ix0) * cs;
+  const float* p11 = L.fmap + ((size_t)y1 * W + x1) * cs;
+  float ss = 0.f;
+  // first pass: sum of squares of the interpolated descriptor
+  for (int c0 = 4 * sub; c0 < C; c0 += 4 * LG) {
+    float4 a = *(const float4*)(p00 + c0), b = *(const float4*)(p10 + c0),
+           c = *(const float4*)(p01 + c0), d = *(const float4*)(p11 + c0);
+    float4 f;
+    f.x = w00 * a.x + w10 * b.x + w01 * c.x + w11 * d.x;
+    f.y = w00 * a.y + w10 * b.y + w01 * c.y + w11 * d.y;
+    f.z = w00 * a.z + w10 * b.z + w01 * c.z + w11 * d.z;
+    f.w = w00 * a.w + w10 * b.w + w01 * c.w + w11 * d.w;
+    ss += f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w;
+    *(float4*)(o + c0) = f;
+  }
+  ss = group_allreduce_sum<LG>(ss);
+  if (P.normalize) {
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c0 = 4 * sub; c0 < C; c0 += 4 * LG) {
+      float4 f = *(float4*)(o + c0);
+      f.x *= inv; f.y *= inv; f.z *= inv; f.w *= inv;
+      *(float4*)(o + c0) = f;
+    }
+  }
+  if (sub == 0) {
+    o[C] = w00 * p00[C] + w10 * p10[C] + w01 * p01[C] + w11 * p11[C];
+    for (int c = C + 1; c < cs; ++c) o[c] = 0.f;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void sample_sparse_kernel(const SampleParams P) {
+  constexpr int LG = 32;
+  constexpr int GPW = PXT_WAVE / LG;
+  const int lane = threadIdx.x & (PXT_WAVE - 1);
+  const int sub = lane % LG, grp = lane / LG;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) / PXT_WAVE;
+  const int n = wave_global * GPW + grp;
+  const bool active = n < P.n;
+  float X = 0.f, Y = 0.f, Z = 1.f;
+  if (active) {
+    X = P.p3d[3 * n];
+    Y = P.p3d[3 * n + 1];
+    Z = P.p3d[3 * n + 2];
+  }
+  const float* T = P.T;
+  const float px = T[0] * X + T[1] * Y + T[2] * Z + T[9];
+  const float py = T[3] * X + T[4] * Y + T[5] * Z + T[10];
+  const float pz = T[6] * X + T[7] * Y + T[8] * Z + T[11];
+  bool all_valid = active;
+  for (int l = 0; l < P.n_levels; ++l)
+    all_valid = sample_level<LG>(P, P.lv[l], n, active, px, py, pz, sub) && all_valid;
+  if (active && sub == 0) P.valid[n] = all_valid ? 1 : 0;
+}
+
+}  // namespace pxt
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace pxt;
+
+extern "C" int64_t pxt_lm_workspace_bytes(void) {
+  return (int64_t)(2 * kLmMaxGrid * kNAcc) * sizeof(float) + 256;
+}
+
+extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_t n_points,
+                             const pxt_lm_level* levels, int32_t n_levels, const float* T_init,
+                             const pxt_lm_conf* conf, float* out, float* log, void* workspace,
+                             void* stream) {
+  if (!p3d || !levels || !T_init || !conf || !out || !workspace) return PXT_E_ARG;
+  if (n_levels < 1 || n_levels > PXT_MAX_LEVELS || n_points < 1) return PXT_E_ARG;
+  if (conf->num_iters < 1 || conf->pad < 0) return PXT_E_ARG;
+  LmParams P;
+  P.p3d = p3d;
+  P.mask = point_mask;
+  P.n = n_points;
+  P.n_levels = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    const pxt_lm_level& s = levels[l];
+    if (!s.fmap || !s.fref || s.C < 4 || (s.C % 4) != 0 || (s.cstride % 4) != 0 ||
+        s.cstride < s.C + 1 || s.h < 2 || s.w < 2)
+      return PXT_E_ARG;
+    if (((uintptr_t)s.fmap % 16) != 0 || ((uintptr_t)s.fref % 16) != 0) return PXT_E_ARG;
+    if (s.ndist != 0 && s.ndist != 2 && s.ndist != 4) return PXT_E_ARG;
+    LmLevelDev& d = P.lv[l];
+    d.fmap = s.fmap;
+    d.fref = s.fref;
+    d.h = s.h; d.w = s.w; d.C = s.C; d.cs = s.cstride;
+    for (int i = 0; i < 10; ++i) d.cam[i] = s.cam[i];
+    d.ndist = s.ndist;
+    for (int i = 0; i < 6; ++i) d.lambda[i] = s.lambda[i];
+  }
+  P.T_init = T_init;
+  P.conf = *conf;
+  P.out = out;
+  P.log = log;
+  char* ws = (char*)workspace;
+  P.partials = (float*)ws;
+  P.counter = (unsigned*)(ws + (size_t)2 * kLmMaxGrid * kNAcc * sizeof(float));
+  P.err = P.counter + 16;
+  int grid = conf->n_workgroups;
+  if (grid <= 0) grid = 64;
+  if (grid > kLmMaxGrid) grid = kLmMaxGrid;
+  hipStream_t s = (hipStream_t)stream;
+  PXT_HIP_CHECK(hipMemsetAsync(P.counter, 0, 256, s));
+  hipLaunchKernelGGL(lm_refine_kernel, dim3(grid), dim3(kLmBlock), 0, s, P);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_sample_sparse(const float* p3d, int32_t n_points, const float* T,
+                                 const pxt_sample_level* levels, int32_t n_levels, int32_t pad,
+                                 int32_t normalize, uint8_t* valid, void* stream) {
+  if (!p3d || !T || !levels || !valid) return PXT_E_ARG;
+  if (n_levels < 1 || n_levels > PXT_MAX_LEVELS || n_points < 1 || pad < 0) return PXT_E_ARG;
+  SampleParams P;
+  P.p3d = p3d;
+  P.T = T;
+  P.n = n_points;
+  P.n_levels = n_levels;
+  P.pad = pad;
+  P.normalize = normalize;
+  P.valid = valid;
+  for (int l = 0; l < n_levels; ++l) {
+    const pxt_sample_level& s = levels[l];
+    if (!s.fmap || !s.out || s.C < 4 || (s.C % 4) != 0 || (s.cstride % 4) != 0 ||
+        s.cstride < s.C + 1 || s.h < 2 || s.w < 2)
+      return PXT_E_ARG;
+    if (((uintptr_t)s.fmap % 16) != 0 || ((uintptr_t)s.out % 16) != 0) return PXT_E_ARG;
+    SampleLevelDev& d = P.lv[l];
+    d.fmap = s.fmap;
+    d.out = s.out;
+    d.h = s.h; d.w = s.w; d.C = s.C; d.cs = s.cstride;
+    for (int i = 0; i < 10; ++i) d.cam[i] = s.cam[i];
+    d.ndist = s.ndist;
+  }
+  const int groups_per_block = 256 / 32;
+  const int grid = (n_points + groups_per_block - 1) / groups_per_block;
+  hipLaunchKernelGGL(sample_sparse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}

@@ -1,0 +1,347 @@
+"""Host mirror of the optimizer interface pixtrack drives.
+
+Reference: ``PixTrackOptimizer(LearnedOptimizer)`` -- pixtrack/optimizers/
+pixtrack_optimizer.py:5-18 -- objects are created by pixloc's ``load_experiment`` and
+class-swizzled at pixtrack/localization/pixloc_pose_refiners.py:71-72; pixtrack then
+uses ``opt.run(p3d, F_ref, F_q, T_init, camera, W_ref_query=...) -> (T, failed)``
+(through pixloc BaseRefiner, :260-262), ``opt.interpolator(feats, p2d)`` (:351),
+``opt.conf.{grad,dt,dR}_stop_criteria`` / ``opt.training`` (pixtrack_optimizer.py:8-14)
+and ``opt.logging_fn`` (tracker hook, pixtrack/localization/tracker.py:32-46).
+
+Here the whole iteration loop runs inside ONE persistent HIP kernel
+(csrc/pxt_lm.hip via ``pxt_lm_refine``); this class only packs arguments and replays
+the per-iteration log into ``logging_fn`` afterwards.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .geometry import Camera, Pose
+from .utils.conf import Conf, merge
+
+LOSS_KINDS = {"squared": 0, "huber": 1, "barron": 2}
+
+
+def parse_loss_fn(spec: str) -> Tuple[int, float, float]:
+    """pixloc names losses by expression: 'squared_loss', 'scaled_loss(huber_loss, a)',
+    'scaled_barron(alpha, a)'.  Returns (kind, alpha, scale)."""
+    spec = spec.replace(" ", "")
+    if spec == "squared_loss":
+        return 0, 2.0, 1.0
+    m = re.fullmatch(r"scaled_barron\(([-+.\de]+),([-+.\de]+)\)", spec)
+    if m:
+        return 2, float(m.group(1)), float(m.group(2))
+    m = re.fullmatch(r"scaled_huber\(([-+.\de]+)\)", spec)
+    if m:
+        return 1, 0.0, float(m.group(1))
+    if spec == "huber_loss":
+        return 1, 0.0, 1.0
+    raise ValueError(f"unsupported loss_fn '{spec}'")
+
+
+def round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def cstride_for(C_: int) -> int:
+    """Channel stride of the packed HWC records: C descriptor + 1 confidence, padded to 4."""
+    return round4(C_ + 1)
+
+
+@dataclass
+class LevelPack:
+    """One pyramid level in the layout the kernels read (include/pixtrack_hip.h)."""
+
+    fmap: torch.Tensor  # [h, w, cstride] float32, descriptor normalised, conf at [C]
+    fref: torch.Tensor  # [N, cstride]   float32, descriptor normalised, W_ref at [C]
+    C: int
+    camera: Camera  # query camera scaled to this level
+    lambda_: torch.Tensor  # [6] host float32
+
+
+@dataclass
+class LMResult:
+    T: Pose
+    failed: bool
+    iters: List[int]
+    costs: List[List[float]]  # per level, per iteration masked-mean cost
+    log: torch.Tensor  # host [n_levels, num_iters, 20]
+    total_iters: int = 0
+
+
+class Interpolator:
+    """pixloc Interpolator surface: ``obs, mask, grads = interp(tensor[C,h,w], pts[N,2])``.
+    Implemented on the sparse-sampling kernel with an identity camera (u = x, v = y)."""
+
+    def __init__(self, mode: str = "linear", pad: int = 4):
+        assert mode == "linear", "only bilinear interpolation is on the tracking path"
+        self.mode = mode
+        self.pad = pad
+
+    def __call__(self, tensor: torch.Tensor, pts: torch.Tensor, return_gradients: bool = False):
+        if return_gradients:
+            raise NotImplementedError("gradients are only formed inside the fused LM kernel")
+        _lib.require_gpu(tensor, "tensor")
+        Cc, h, w = tensor.shape
+        cs = round4(Cc + 1)
+        fmap = torch.zeros(h, w, cs, device=tensor.device, dtype=torch.float32)
+        fmap[..., :Cc] = tensor.permute(1, 2, 0)
+        # treat ALL Cc channels as "descriptor" channels of a (Cc4 = round4) record
+        obs, valid = sample_sparse_points2d(fmap, Cc, pts.to(tensor.device, torch.float32), self.pad)
+        return obs, valid, torch.zeros(pts.shape[0], Cc, 2, device=tensor.device)
+
+
+def sample_sparse_points2d(fmap: torch.Tensor, Cc: int, pts: torch.Tensor, pad: int):
+    """Bilinear sample an HWC map at pixel coordinates through pxt_sample_sparse."""
+    L = _lib.lib()
+    h, w, cs = fmap.shape
+    N = pts.shape[0]
+    # round the descriptor width down to a multiple of 4 is not possible in general, so
+    # sample a padded record: channels [0, C4) are "descriptor", the record is C4+4 wide.
+    C4 = round4(Cc)
+    if cs < C4 + 4:
+        fm = torch.zeros(h, w, C4 + 4, device=fmap.device, dtype=torch.float32)
+        fm[..., :cs] = fmap
+        fmap, cs = fm, C4 + 4
+    p3d = torch.cat([pts, torch.ones(N, 1, device=pts.device)], -1).contiguous()
+    T = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=pts.device)
+    out = torch.empty(N, cs, device=pts.device, dtype=torch.float32)
+    valid = torch.empty(N, device=pts.device, dtype=torch.uint8)
+    lv = _lib.SampleLevel()
+    lv.fmap, lv.out = fmap.data_ptr(), out.data_ptr()
+    lv.h, lv.w, lv.C, lv.cstride = h, w, C4, cs
+    lv.cam[:] = [w, h, 1, 1, 0, 0, 0, 0, 0, 0]
+    lv.ndist = 0
+    _lib.check(
+        L.pxt_sample_sparse(p3d.data_ptr(), N, T.data_ptr(), C.byref(lv), 1, pad, 0,
+                            valid.data_ptr(), _lib.stream_ptr(pts.device)),
+        "pxt_sample_sparse",
+    )
+    return out[:, :Cc], valid.bool()
+
+
+class DampingNet:
+    """Learned constant damping: lambda = 10^(lo + sigmoid(const) (hi - lo))."""
+
+    def __init__(self, conf, num_params: int = 6):
+        self.conf = conf
+        self.const = torch.zeros(num_params)
+
+    def __call__(self) -> torch.Tensor:
+        lo, hi = self.conf.log_range
+        return 10.0 ** (lo + torch.sigmoid(self.const.float().cpu()) * (hi - lo))
+
+    forward = __call__
+
+
+class PixTrackOptimizer:
+    """Same name and public surface as the reference class; HIP-only implementation."""
+
+    default_conf = dict(
+        num_iters=100,
+        loss_fn="scaled_barron(0, 0.1)",
+        jacobi_scaling=False,
+        normalize_features=False,
+        lambda_=0.0,
+        interpolation=dict(mode="linear", pad=4),
+        pad=None,  # pixtrack passes optimizer.pad (pixloc_tracker_r9.py:48); honoured if set
+        grad_stop_criteria=1e-4,
+        dt_stop_criteria=5e-3,
+        dR_stop_criteria=5e-2,
+        damping=dict(type="constant", log_range=[-6, 5]),
+        learned_damping=True,
+        min_valid=10,
+        n_workgroups=0,
+    )
+
+    def __init__(self, conf=None, device: Optional[torch.device] = None):
+        self.conf = merge(self.default_conf, conf or {})
+        assert not self.conf.jacobi_scaling and not self.conf.normalize_features
+        pad = self.conf.pad if self.conf.pad is not None else self.conf.interpolation.pad
+        self.interpolator = Interpolator(self.conf.interpolation.mode, int(pad))
+        self.dampingnet = DampingNet(self.conf.damping)
+        self.training = False
+        self.logging_fn: Optional[Callable] = None
+        self.device = device
+        self._ws = None
+        self._ws_dev = None
+
+    # ---- pixloc module-ish helpers ---------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def load_state_dict(self, sd):
+        self.dampingnet.const = torch.as_tensor(sd["dampingnet.const"]).float().cpu()
+
+    def state_dict(self):
+        return {"dampingnet.const": self.dampingnet.const.clone()}
+
+    # ---- reference semantics kept for API parity ---------------------------
+    def early_stop(self, **args) -> bool:
+        """pixtrack_optimizer.py:5-18, verbatim semantics.  The kernel applies this same
+        rule on-device after every iteration; this method exists for callers/tests."""
+        stop = False
+        if not self.training and (args["i"] % 1) == 0:
+            T_delta, grad = args["T_delta"], args["grad"]
+            grad_norm = torch.norm(grad.detach(), dim=-1)
+            small_grad = grad_norm < self.conf.grad_stop_criteria
+            dR, dt = T_delta.magnitude()
+            small_step = (dt < self.conf.dt_stop_criteria) & (dR < self.conf.dR_stop_criteria)
+            if torch.all(small_step | small_grad):
+                stop = True
+        return stop
+
+    def log(self, **args):
+        if self.logging_fn is not None:
+            self.logging_fn(**args)
+
+    # ---- native call ------------------------------------------------------
+    def _workspace(self, device):
+        if self._ws is None or self._ws_dev != device:
+            n = int(_lib.lib().pxt_lm_workspace_bytes())
+            self._ws = torch.zeros(n, dtype=torch.uint8, device=device)
+            self._ws_dev = device
+        return self._ws
+
+    def native_conf(self) -> _lib.LmConf:
+        kind, alpha, scale = parse_loss_fn(self.conf.loss_fn)
+        c = _lib.LmConf()
+        c.num_iters = int(self.conf.num_iters)
+        c.pad = int(self.interpolator.pad)
+        c.loss, c.loss_alpha, c.loss_scale = kind, alpha, scale
+        c.grad_stop = float(self.conf.grad_stop_criteria)
+        c.dt_stop = float(self.conf.dt_stop_criteria)
+        c.dR_stop = float(self.conf.dR_stop_criteria)
+        c.min_valid = int(self.conf.min_valid)
+        c.n_workgroups = int(self.conf.n_workgroups)
+        return c
+
+    @staticmethod
+    def refine_levels(
+        p3d: torch.Tensor,
+        levels: Sequence[LevelPack],
+        T_init: Pose,
+        conf: _lib.LmConf,
+        workspace: torch.Tensor,
+        mask: Optional[torch.Tensor] = None,
+        want_log: bool = True,
+    ) -> "PendingLM":
+        """Enqueue the fused multi-level refinement (levels in EXECUTION order,
+        coarse -> fine).  Returns a handle; ``.result()`` synchronises."""
+        L = _lib.lib()
+        _lib.require_gpu(p3d, "p3d")
+        dev = p3d.device
+        n_levels = len(levels)
+        assert 1 <= n_levels <= _lib.PXT_MAX_LEVELS
+        arr = (_lib.LmLevel * n_levels)()
+        keep = []
+        for i, lp in enumerate(levels):
+            assert lp.fmap.is_contiguous() and lp.fref.is_contiguous()
+            assert lp.fmap.dtype == torch.float32 and lp.fref.dtype == torch.float32
+            h, w, cs = lp.fmap.shape
+            assert lp.fref.shape == (p3d.shape[0], cs)
+            arr[i].fmap, arr[i].fref = lp.fmap.data_ptr(), lp.fref.data_ptr()
+            arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, lp.C, cs
+            cam10 = lp.camera.as10()
+            arr[i].cam[:] = cam10.tolist()
+            arr[i].ndist = int(lp.camera._data.shape[-1] - 6)
+            arr[i].lambda_[:] = lp.lambda_.float().tolist()
+            keep.append(lp)
+        T0 = T_init.as12().detach().to(dev, torch.float32).contiguous()
+        out = torch.zeros(16 + _lib.PXT_MAX_LEVELS, device=dev, dtype=torch.float32)
+        log = (
+            torch.zeros(n_levels, conf.num_iters, _lib.PXT_LM_LOG_STRIDE, device=dev, dtype=torch.float32)
+            if want_log
+            else None
+        )
+        p3d = p3d.to(torch.float32).contiguous()
+        if mask is not None:
+            mask = mask.to(dev, torch.uint8).contiguous()
+        _lib.check(
+            L.pxt_lm_refine(
+                p3d.data_ptr(), _lib.dptr(mask), p3d.shape[0], arr, n_levels, T0.data_ptr(),
+                C.byref(conf), out.data_ptr(), _lib.dptr(log), workspace.data_ptr(),
+                _lib.stream_ptr(dev),
+            ),
+            "pxt_lm_refine",
+        )
+        return PendingLM(out, log, n_levels, conf.num_iters, (p3d, mask, T0, keep, workspace))
+
+    def run(self, p3D, F_ref, F_query, T_init: Pose, camera: Camera, mask=None, W_ref_query=None):
+        """One pyramid level, pixloc calling convention:
+        p3D [N,3] (numpy or tensor), F_ref [N,C], F_query [C,h,w], W_ref_query =
+        (W_ref [N,1], W_q [1,h,w]).  Returns (T: Pose on F_query's device/dtype, failed)."""
+        _lib.require_gpu(F_query, "F_query")
+        dev = F_query.device
+        if isinstance(p3D, np.ndarray):
+            p3D = torch.from_numpy(p3D)
+        p3D = p3D.to(dev, torch.float32)
+        Cc, h, w = F_query.shape
+        N = p3D.shape[0]
+        cs = cstride_for(Cc)
+        fmap = torch.zeros(h, w, cs, device=dev, dtype=torch.float32)
+        fmap[..., :Cc] = F_query.permute(1, 2, 0)
+        fref = torch.zeros(N, cs, device=dev, dtype=torch.float32)
+        fref[:, :Cc] = F_ref
+        if W_ref_query is not None:
+            W_ref, W_q = W_ref_query
+            fmap[..., Cc] = W_q[0]
+            fref[:, Cc] = W_ref[:, 0]
+        else:
+            fmap[..., Cc] = 1.0
+            fref[:, Cc] = 1.0
+        lp = LevelPack(fmap, fref, Cc, camera, self.dampingnet())
+        res = self.refine_levels(p3D, [lp], T_init, self.native_conf(), self._workspace(dev), mask).result()
+        self.replay_log(res, 0, T_init)
+        T = Pose(res.T.as12().to(dev, F_query.dtype))
+        return T, torch.tensor(res.failed, device=dev)
+
+    _run = run
+
+    def replay_log(self, res: LMResult, level: int, T_init: Pose):
+        """Feed the recorded iterations of one level to ``logging_fn`` with the kwargs
+        DebugTracker.log_optim_iter reads (tracker.py:32-46)."""
+        if self.logging_fn is None:
+            return
+        lg = res.log[level]
+        T_prev = Pose(T_init.as12().detach().cpu().float())
+        for i in range(res.iters[level]):
+            T = Pose(lg[i, 8:20].clone())
+            T_delta = T @ T_prev.inv()
+            self.logging_fn(
+                i=i, T_init=T_init, T=T, T_delta=T_delta,
+                cost=lg[i, 0:1].clone(), valid=torch.ones(1), n_valid=int(lg[i, 1]),
+            )
+            T_prev = T
+
+
+class PendingLM:
+    """Result handle of an enqueued refinement (one device->host copy on .result())."""
+
+    def __init__(self, out, log, n_levels, num_iters, keepalive):
+        self.out, self.log_dev = out, log
+        self.n_levels, self.num_iters = n_levels, num_iters
+        self._keep = keepalive
+
+    def result(self) -> LMResult:
+        out = self.out.cpu()
+        status = int(out[13])
+        if status != 0:
+            raise _lib.PxtError(f"pxt_lm_refine: in-kernel status {status} (spin bound exceeded)")
+        iters = [int(out[16 + l]) for l in range(self.n_levels)]
+        log = self.log_dev.cpu() if self.log_dev is not None else torch.zeros(self.n_levels, 0, 20)
+        costs = [[float(c) for c in log[l, : iters[l], 0]] for l in range(self.n_levels)] if self.log_dev is not None else []
+        self._keep = None
+        return LMResult(Pose(out[:12].clone()), bool(out[12] != 0), iters, costs, log, int(out[14]))

@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/pixtrack_hip.h declares (no compute without a GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "pixtrack_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pxt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    for s in ["pxt_lm_refine", "pxt_sample_sparse", "pxt_unet_forward", "pxt_ngp_render", "pxt_depth_mask"]:
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from pixtrack_amd import _build, _lib
+
+    _build.build(verbose=False)
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_binding_covers_every_declared_symbol():
+    from pixtrack_amd import _lib
+
+    assert sorted(_lib.PROTOTYPES) == declared_symbols()
+    L = _lib.lib()
+    assert L.pxt_version() == _lib.ABI_VERSION
+    assert int(L.pxt_lm_workspace_bytes()) > 0
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes mirrors must have the sizes the C compiler gives the header structs."""
+    import subprocess, tempfile, textwrap
+    from pixtrack_amd import _lib
+
+    src = textwrap.dedent(
+        """
+        #include <stdio.h>
+        #include "pixtrack_hip.h"
+        int main(void) {
+          printf("%zu %zu %zu %zu %zu\\n", sizeof(pxt_lm_level), sizeof(pxt_lm_conf),
+                 sizeof(pxt_sample_level), sizeof(pxt_ngp_model), sizeof(pxt_ngp_view));
+          return 0;
+        }
+        """
+    )
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "s.c").write_text(src)
+        subprocess.check_call(["gcc", "-I", str(ROOT / "include"), str(Path(d) / "s.c"), "-o", str(Path(d) / "s")])
+        out = subprocess.check_output([str(Path(d) / "s")]).decode().split()
+    sizes = [int(x) for x in out]
+    got = [ctypes.sizeof(c) for c in (_lib.LmLevel, _lib.LmConf, _lib.SampleLevel, _lib.NgpModel, _lib.NgpView)]
+    assert got == sizes
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from pixtrack_amd import _lib
+    from pixtrack_amd.optimizer import PixTrackOptimizer
+    from pixtrack_amd.geometry import Camera, Pose
+
+    opt = PixTrackOptimizer(dict(num_iters=3))
+    with pytest.raises(_lib.PxtError):
+        opt.run(torch.zeros(20, 3), torch.zeros(20, 32), torch.zeros(32, 8, 8),
+                Pose(torch.zeros(12)), Camera(torch.zeros(8)))
