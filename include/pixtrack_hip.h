@@ -154,6 +154,13 @@ int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8, cons
                      int32_t H, int32_t W, float* const out_maps[3], const int32_t out_cstride[3],
                      int32_t normalize, void* workspace, void* stream);
 
+/* One 3x3 convolution (pad 1) of the pyramid as a stand-alone call, for layer-by-layer
+ * parity tests against torch.nn.functional.conv2d (SURVEY KAT-6) and for profiling:
+ * in  [H][W][Cin]  fp16 NHWC (Cin % 32 == 0), weights [Cout][3][3][Cin] fp16
+ * (Cout % 32 == 0), bias [Cout] float32, out [H][W][Cout] fp16; fused bias (+ReLU). */
+int pxt_conv3x3_nhwc_f16(const void* in, int32_t H, int32_t W, int32_t Cin, const void* weights,
+                         const float* bias, int32_t Cout, int32_t relu, void* out, void* stream);
+
 /* -------------------------------------------------------------------------
  * instant-ngp style NeRF inference renderer.
  *

@@ -119,6 +119,7 @@ PROTOTYPES = {
         C.c_int,
         [_VP, _VP, _I32, _VP, _I32, _I32, C.POINTER(_VP), C.POINTER(_I32), _I32, _VP, _VP],
     ),
+    "pxt_conv3x3_nhwc_f16": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _I32, _I32, _VP, _VP]),
     "pxt_ngp_create": (C.c_int, [C.POINTER(NgpModel), _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
     "pxt_ngp_destroy": (C.c_int, [_VP]),
     "pxt_ngp_render": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP]),

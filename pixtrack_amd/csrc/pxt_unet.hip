@@ -1,0 +1,588 @@
+// VGG16-UNet feature pyramid (pixloc `UNet`) for gfx950.
+//
+// Replaces `pred = self.model({"image": image_tensor})`
+// (pixtrack/localization/feature_extractor.py:48, prepare_input :31-32).
+//
+// Data layout: activations are NHWC fp16 in HBM (one pixel's channels contiguous), so
+//  * an MFMA operand fragment (8 consecutive input channels of one pixel / of one
+//    filter tap) is ONE 16-byte LDS read,
+//  * the 1x1 heads and the LM kernel read whole pixels as contiguous records.
+// The 3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation: rows = output channels (A operand = filter taps), columns = pixels
+// (B operand = the shifted input window), K = 9 * Cin walked as (Cin chunk of 32) x
+// (9 taps) x (2 k-steps of 16).  A workgroup owns a 16x16 pixel tile and 32*NT output
+// channels; the 18x18 halo of the current Cin chunk and the 9 filter taps of that
+// chunk are staged in LDS once and reused by all taps / all four waves.  Bias (or the
+// folded BatchNorm affine) and ReLU are fused into the epilogue.
+#include "pxt_common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace pxt {
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kNumConv = 17;
+constexpr int kNumHeads = 3;
+
+// ---------------------------------------------------------------------------
+// First layer: image (HWC, 0..255, float or u8) [* mask] -> /255 -> ImageNet
+// normalisation -> conv3x3 (3 -> Cout) + bias + ReLU -> fp16 NHWC.  HBM-bound.
+// ---------------------------------------------------------------------------
+template <bool U8>
+__global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict__ image,
+                                                         const uint8_t* __restrict__ mask, int H,
+                                                         int W, const float* __restrict__ wts,
+                                                         const float* __restrict__ bias, int Cout,
+                                                         half_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [27][Cout] + bias[Cout]
+  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
+    int co = i / 27, k = i % 27;
+    s_w[k * Cout + co] = wts[i];
+  }
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) s_w[27 * Cout + i] = bias[i];
+  __syncthreads();
+  const int groups = Cout / 16;  // threads per pixel, 16 output channels each
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long pix = gid / groups;
+  const int cg = (int)(gid % groups);
+  if (pix >= (long long)H * W) return;
+  const int y = (int)(pix / W), x = (int)(pix % W);
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+  float in[27];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = y + ky - 1, xx = x + kx - 1;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = 0.f;
+        if (ok) {
+          const size_t idx = ((size_t)yy * W + xx) * 3 + c;
+          float raw = U8 ? (float)((const uint8_t*)image)[idx] : ((const float*)image)[idx];
+          if (mask) raw *= (float)mask[(size_t)yy * W + xx];
+          v = (raw / 255.0f - mean[c]) * istd[c];
+        }
+        in[(ky * 3 + kx) * 3 + c] = v;
+      }
+    }
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = s_w[27 * Cout + cg * 16 + j];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float4* wr = (const float4*)(s_w + k * Cout + cg * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 w4 = wr[q];
+      acc[4 * q + 0] += in[k] * w4.x;
+      acc[4 * q + 1] += in[k] * w4.y;
+      acc[4 * q + 2] += in[k] * w4.z;
+      acc[4 * q + 3] += in[k] * w4.w;
+    }
+  }
+  half8 o0, o1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    o0[j] = (half_t)fmaxf(acc[j], 0.f);
+    o1[j] = (half_t)fmaxf(acc[8 + j], 0.f);
+  }
+  half_t* dst = out + (size_t)pix * Cout + cg * 16;
+  *(half8*)dst = o0;
+  *(half8*)(dst + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 convolution, pad 1, NHWC fp16 -> NHWC fp16, MFMA implicit GEMM.
+// ---------------------------------------------------------------------------
+constexpr int kTH = 16, kTW = 16;        // output pixels per workgroup
+constexpr int kCK = 32;                  // input channels per staged chunk
+constexpr int kPix = 40;                 // padded halves per LDS pixel/filter row (80 B)
+constexpr int kHalo = (kTH + 2) * (kTW + 2);
+
+template <int NT>  // output channels per workgroup = 32 * NT
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restrict__ in, int H,
+                                                           int W, int Cin,
+                                                           const half_t* __restrict__ wts,
+                                                           const float* __restrict__ bias,
+                                                           int Cout, int relu,
+                                                           half_t* __restrict__ out) {
+  constexpr int BNC = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) half_t smem[];
+  half_t* s_in = smem;                  // [kHalo][kPix]
+  half_t* s_w = smem + kHalo * kPix;    // [9][BNC][kPix]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (W + kTW - 1) / kTW;
+  const int ty0 = (blockIdx.x / tiles_x) * kTH, tx0 = (blockIdx.x % tiles_x) * kTW;
+  const int co0 = blockIdx.y * BNC;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][c][r] = 0.f;
+
+  // this lane's two pixels (one per 32-wide MFMA column block) inside the tile
+  const int r31 = lane & 31, khalf = lane >> 5;
+  int p_off[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int ty = 4 * wave + 2 * p + (r31 >> 4), tx = r31 & 15;
+    p_off[p] = (ty * (kTW + 2) + tx) * kPix + 8 * khalf;
+  }
+  const int w_off = r31 * kPix + 8 * khalf;
+
+  for (int c0 = 0; c0 < Cin; c0 += kCK) {
+    __syncthreads();
+    // stage the 18x18 halo of this channel chunk (zero outside the image)
+    for (int i = tid; i < kHalo * 4; i += 256) {
+      const int pix = i >> 2, seg = i & 3;
+      const int hy = pix / (kTW + 2), hx = pix % (kTW + 2);
+      const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *(const half8*)(in + ((size_t)gy * W + gx) * Cin + c0 + seg * 8);
+      *(half8*)(s_in + pix * kPix + seg * 8) = v;
+    }
+    // stage the 9 taps of this chunk for the workgroup's output channels
+    for (int i = tid; i < 9 * BNC * 4; i += 256) {
+      const int row = i >> 2, seg = i & 3;
+      const int t = row / BNC, n = row % BNC;
+      const half8 v = *(const half8*)(wts + ((size_t)(co0 + n) * 9 + t) * Cin + c0 + seg * 8);
+      *(half8*)(s_w + row * kPix + seg * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int tap_in = ((t / 3) * (kTW + 2) + (t % 3)) * kPix;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8 b[2], a[NT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) b[p] = *(const half8*)(s_in + p_off[p] + tap_in + 16 * s);
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+          a[c] = *(const half8*)(s_w + (t * BNC + 32 * c) * kPix + w_off + 16 * s);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int c = 0; c < NT; ++c)
+            acc[p][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], b[p], acc[p][c], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: D[row = cout][col = pixel]; lane holds col = lane&31,
+  // rows (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int ty = 4 * wave + 2 * p + (r31 >> 4), tx = r31 & 15;
+    const int gy = ty0 + ty, gx = tx0 + tx;
+    if (gy >= H || gx >= W) continue;
+    half_t* dst = out + ((size_t)gy * W + gx) * Cout + co0;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = 32 * c + 8 * g + 4 * khalf;
+        const float4 bv = *(const float4*)(bias + co0 + co);
+        float v0 = acc[p][c][4 * g + 0] + bv.x, v1 = acc[p][c][4 * g + 1] + bv.y,
+              v2 = acc[p][c][4 * g + 2] + bv.z, v3 = acc[p][c][4 * g + 3] + bv.w;
+        if (relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        half4 o;
+        o[0] = (half_t)v0; o[1] = (half_t)v1; o[2] = (half_t)v2; o[3] = (half_t)v3;
+        *(half4*)(dst + co) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 2x2 max-pool stride 2 (floor), NHWC fp16, 8 channels per thread.
+// ---------------------------------------------------------------------------
+__global__ void maxpool2_kernel(const half_t* __restrict__ in, int H, int W, int C,
+                                half_t* __restrict__ out, int Ho, int Wo) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8;
+  if (i >= (long long)Ho * Wo * c8) return;
+  const int c = (int)(i % c8) * 8;
+  const long long p = i / c8;
+  const int x = (int)(p % Wo), y = (int)(p / Wo);
+  const half_t* s = in + ((size_t)(2 * y) * W + 2 * x) * C + c;
+  half8 a = *(const half8*)s, b = *(const half8*)(s + C), d = *(const half8*)(s + (size_t)W * C),
+        e = *(const half8*)(s + (size_t)W * C + C);
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    half_t m0 = a[j] > b[j] ? a[j] : b[j];
+    half_t m1 = d[j] > e[j] ? d[j] : e[j];
+    o[j] = m0 > m1 ? m0 : m1;
+  }
+  *(half8*)(out + ((size_t)y * Wo + x) * C + c) = o;
+}
+
+// ---------------------------------------------------------------------------
+// Decoder input: cat([bilinear x2 upsample(prev) (align_corners=False), skip[:hu,:wu]]).
+// ---------------------------------------------------------------------------
+__global__ void upcat_kernel(const half_t* __restrict__ prev, int Hp, int Wp, int Cp,
+                             const half_t* __restrict__ skip, int Ws, int Cs,
+                             half_t* __restrict__ out) {
+  const int Ho = 2 * Hp, Wo = 2 * Wp, Ct = Cp + Cs;
+  const int c8 = Ct / 8;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Ho * Wo * c8) return;
+  const int c = (int)(i % c8) * 8;
+  const long long p = i / c8;
+  const int x = (int)(p % Wo), y = (int)(p / Wo);
+  half8 o;
+  if (c < Cp) {
+    float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.f);
+    float sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, Hp - 1), x1 = min(x0 + 1, Wp - 1);
+    const float ay = sy - (float)y0, ax = sx - (float)x0;
+    const half8 a = *(const half8*)(prev + ((size_t)y0 * Wp + x0) * Cp + c);
+    const half8 b = *(const half8*)(prev + ((size_t)y0 * Wp + x1) * Cp + c);
+    const half8 d = *(const half8*)(prev + ((size_t)y1 * Wp + x0) * Cp + c);
+    const half8 e = *(const half8*)(prev + ((size_t)y1 * Wp + x1) * Cp + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float top = (float)a[j] * (1.f - ax) + (float)b[j] * ax;
+      const float bot = (float)d[j] * (1.f - ax) + (float)e[j] * ax;
+      o[j] = (half_t)(top * (1.f - ay) + bot * ay);
+    }
+  } else {
+    o = *(const half8*)(skip + ((size_t)y * Ws + x) * Cs + (c - Cp));
+  }
+  *(half8*)(out + ((size_t)y * Wo + x) * Ct + c) = o;
+}
+
+// ---------------------------------------------------------------------------
+// 1x1 heads: descriptor (Cout) + uncertainty (1) from a fp16 NHWC map; writes the
+// float32 HWC record [Cout descriptor | confidence = sigmoid(-unc) | zero pad].
+// One wave handles PIX pixels; lane = output channel (strided by 64).
+// ---------------------------------------------------------------------------
+template <int PIX>
+__global__ __launch_bounds__(256) void head_kernel(const half_t* __restrict__ in, long long npix,
+                                                   int Cin, const float* __restrict__ wts,
+                                                   const float* __restrict__ bias, int Cout,
+                                                   int normalize, float* __restrict__ out,
+                                                   int cstride) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long p0 = wave * PIX;
+  if (p0 >= npix) return;
+  const int Co1 = Cout + 1;
+  constexpr int MAXR = 3;  // up to 192 outputs (129 used)
+  float acc[MAXR][PIX];
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int co = lane + 64 * r;
+    const float b = (co < Co1) ? bias[co] : 0.f;
+#pragma unroll
+    for (int p = 0; p < PIX; ++p) acc[r][p] = b;
+  }
+  for (int k = 0; k < Cin; k += 8) {
+    half8 xv[PIX];
+#pragma unroll
+    for (int p = 0; p < PIX; ++p) {
+      const long long pp = min(p0 + p, npix - 1);
+      xv[p] = *(const half8*)(in + (size_t)pp * Cin + k);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int r = 0; r < MAXR; ++r) {
+        const int co = lane + 64 * r;
+        if (64 * r < Co1) {
+          const float w = (co < Co1) ? wts[(size_t)(k + j) * Co1 + co] : 0.f;
+#pragma unroll
+          for (int p = 0; p < PIX; ++p) acc[r][p] += (float)xv[p][j] * w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PIX; ++p) {
+    if (p0 + p >= npix) break;
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int co = lane + 64 * r;
+      if (co < Cout) ss += acc[r][p] * acc[r][p];
+    }
+    ss = group_allreduce_sum<64>(ss);
+    const float inv = normalize ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+    float* o = out + (size_t)(p0 + p) * cstride;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+      const int co = lane + 64 * r;
+      if (co < Cout)
+        o[co] = acc[r][p] * inv;
+      else if (co == Cout)
+        o[co] = 1.f / (1.f + expf(acc[r][p]));  // sigmoid(-x)
+      else if (co < cstride)
+        o[co] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------
+struct UnetLayer {
+  int cin, cout;
+  const void* w;
+  const float* b;
+};
+
+}  // namespace pxt
+
+struct pxt_unet {
+  void* dev_blob = nullptr;
+  int64_t n_bytes = 0;
+  pxt::UnetLayer conv[pxt::kNumConv];
+  pxt::UnetLayer head[pxt::kNumHeads];
+};
+
+using namespace pxt;
+
+namespace {
+
+struct Plan {
+  int h[5], w[5];          // encoder block resolutions
+  int dh[4], dw[4];        // decoder block output resolutions
+  // byte offsets into the workspace
+  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_cat[4], dec_out[4], total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+bool make_plan(const pxt_unet* ctx, int H, int W, Plan& P) {
+  P.h[0] = H; P.w[0] = W;
+  for (int b = 1; b < 5; ++b) { P.h[b] = P.h[b - 1] / 2; P.w[b] = P.w[b - 1] / 2; }
+  if (P.h[4] < 1 || P.w[4] < 1) return false;
+  int ph = P.h[4], pw = P.w[4];
+  for (int d = 0; d < 4; ++d) { ph *= 2; pw *= 2; P.dh[d] = ph; P.dw[d] = pw; }
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+  static const int enc_c[5] = {64, 128, 256, 512, 512};
+  static const int enc_in[5] = {3, 64, 128, 256, 512};
+  for (int b = 0; b < 5; ++b) {
+    const size_t px = (size_t)P.h[b] * P.w[b];
+    P.enc_pool[b] = (b > 0) ? take(px * enc_in[b] * 2) : 0;
+    P.enc_tmp[b][0] = take(px * enc_c[b] * 2);
+    P.enc_tmp[b][1] = take(px * enc_c[b] * 2);
+    P.enc_out[b] = take(px * enc_c[b] * 2);
+  }
+  for (int d = 0; d < 4; ++d) {
+    const size_t px = (size_t)P.dh[d] * P.dw[d];
+    P.dec_cat[d] = take(px * ctx->conv[13 + d].cin * 2);
+    P.dec_out[d] = take(px * ctx->conv[13 + d].cout * 2);
+  }
+  P.total = off;
+  return true;
+}
+
+void set_conv_lds_attr() {
+  // the conv kernels stage > 64 KiB of LDS (gfx950 has 160 KiB per CU)
+  static bool done = false;
+  if (done) return;
+  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)((kHalo * kPix + 9 * 64 * kPix) * sizeof(half_t)));
+  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)((kHalo * kPix + 9 * 32 * kPix) * sizeof(half_t)));
+  done = true;
+}
+
+int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out, hipStream_t s,
+                int relu = 1) {
+  if (L.cin % kCK != 0 || L.cout % 32 != 0) return PXT_E_ARG;
+  set_conv_lds_attr();
+  const int tiles = ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  if (L.cout % 64 == 0) {
+    const size_t lds = (size_t)(kHalo * kPix + 9 * 64 * kPix) * sizeof(half_t);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, dim3(tiles, L.cout / 64), dim3(256), lds, s, in, H, W,
+                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out);
+  } else {
+    const size_t lds = (size_t)(kHalo * kPix + 9 * 32 * kPix) * sizeof(half_t);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(tiles, L.cout / 32), dim3(256), lds, s, in, H, W,
+                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out);
+  }
+  return PXT_OK;
+}
+
+}  // namespace
+
+extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_unet** out_ctx) {
+  if (!weights_host || !out_ctx || n_bytes < 64) return PXT_E_ARG;
+  const char* p = (const char*)weights_host;
+  if (std::memcmp(p, "PXTUNET1", 8) != 0) return PXT_E_ARG;
+  int32_t n_conv, n_heads;
+  std::memcpy(&n_conv, p + 8, 4);
+  std::memcpy(&n_heads, p + 12, 4);
+  if (n_conv != kNumConv || n_heads != kNumHeads) return PXT_E_ARG;
+  const int32_t* dims = (const int32_t*)(p + 16);
+  const int64_t* table = (const int64_t*)(p + 16 + 8 * (n_conv + n_heads));
+  const int n_arrays = 2 * (n_conv + n_heads);
+  for (int i = 0; i < n_arrays; ++i)
+    if (table[2 * i] < 0 || table[2 * i] + table[2 * i + 1] > n_bytes || (table[2 * i] % 16) != 0)
+      return PXT_E_ARG;
+  pxt_unet* ctx = new pxt_unet();
+  ctx->n_bytes = n_bytes;
+  hipError_t e = hipMalloc(&ctx->dev_blob, (size_t)n_bytes);
+  if (e != hipSuccess) { set_last_error("hipMalloc(unet weights)", e); delete ctx; return PXT_E_HIP; }
+  e = hipMemcpy(ctx->dev_blob, weights_host, (size_t)n_bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_last_error("hipMemcpy(unet weights)", e); hipFree(ctx->dev_blob); delete ctx; return PXT_E_HIP; }
+  const char* d = (const char*)ctx->dev_blob;
+  for (int i = 0; i < n_conv + n_heads; ++i) {
+    UnetLayer& L = (i < n_conv) ? ctx->conv[i] : ctx->head[i - n_conv];
+    L.cin = dims[2 * i];
+    L.cout = dims[2 * i + 1];
+    L.w = d + table[4 * i];
+    L.b = (const float*)(d + table[4 * i + 2]);
+    const int64_t wbytes = table[4 * i + 1], bbytes = table[4 * i + 3];
+    int64_t want_w, want_b;
+    if (i == 0) { want_w = (int64_t)L.cout * 27 * 4; want_b = L.cout * 4; }
+    else if (i < n_conv) { want_w = (int64_t)L.cout * 9 * L.cin * 2; want_b = L.cout * 4; }
+    else { want_w = (int64_t)L.cin * (L.cout + 1) * 4; want_b = (L.cout + 1) * 4; }
+    if (wbytes != want_w || bbytes != want_b) { hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
+  }
+  // architecture checks (VGG16-UNet wiring the forward pass assumes)
+  bool ok = ctx->conv[0].cin == 3 && (ctx->conv[0].cout % 16) == 0;
+  for (int i = 1; i < n_conv; ++i) ok = ok && (ctx->conv[i].cin % kCK) == 0 && (ctx->conv[i].cout % 32) == 0;
+  for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 8) == 0 && ctx->head[i].cout + 1 <= 192;
+  if (!ok) { hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
+  *out_ctx = ctx;
+  return PXT_OK;
+}
+
+extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
+  if (!ctx) return PXT_E_ARG;
+  if (ctx->dev_blob) hipFree(ctx->dev_blob);
+  delete ctx;
+  return PXT_OK;
+}
+
+extern "C" int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W) {
+  if (!ctx) return PXT_E_ARG;
+  Plan P;
+  if (!make_plan(ctx, H, W, P)) return 0;
+  return (int64_t)P.total;
+}
+
+extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8,
+                                const uint8_t* mask, int32_t H, int32_t W, float* const out_maps[3],
+                                const int32_t out_cstride[3], int32_t normalize, void* workspace,
+                                void* stream) {
+  if (!ctx || !image || !out_maps || !out_cstride || !workspace) return PXT_E_ARG;
+  Plan P;
+  if (!make_plan(ctx, H, W, P)) return PXT_E_ARG;
+  for (int k = 0; k < 3; ++k)
+    if (!out_maps[k] || out_cstride[k] < ctx->head[k].cout + 1 || (out_cstride[k] % 4) != 0)
+      return PXT_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto buf = [&](size_t off) { return (half_t*)(ws + off); };
+  static const int block_first[5] = {0, 2, 4, 7, 10};
+  static const int block_n[5] = {2, 2, 3, 3, 3};
+
+  const half_t* skip[5];
+  const half_t* cur = nullptr;
+  for (int b = 0; b < 5; ++b) {
+    const int h = P.h[b], w = P.w[b];
+    const half_t* x;
+    if (b == 0) {
+      const UnetLayer& L0 = ctx->conv[0];
+      const long long threads = (long long)h * w * (L0.cout / 16);
+      const size_t lds = (size_t)(28 * L0.cout) * sizeof(float);
+      half_t* o = buf(P.enc_tmp[0][0]);
+      if (image_is_u8)
+        hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
+                           image, mask, h, w, (const float*)L0.w, L0.b, L0.cout, o);
+      else
+        hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
+                           image, mask, h, w, (const float*)L0.w, L0.b, L0.cout, o);
+      x = o;
+    } else {
+      const int cin = ctx->conv[block_first[b]].cin;
+      half_t* o = buf(P.enc_pool[b]);
+      const long long n = (long long)h * w * (cin / 8);
+      hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cur, P.h[b - 1],
+                         P.w[b - 1], cin, o, h, w);
+      x = o;
+    }
+    for (int i = (b == 0 ? 1 : 0); i < block_n[b]; ++i) {
+      const bool last = i == block_n[b] - 1;
+      half_t* o = last ? buf(P.enc_out[b]) : buf(P.enc_tmp[b][i & 1]);
+      int rc = launch_conv(ctx->conv[block_first[b] + i], x, h, w, o, s);
+      if (rc != PXT_OK) return rc;
+      x = o;
+    }
+    skip[b] = x;
+    cur = x;
+  }
+  // decoder
+  const half_t* pre[5];  // fine -> coarse: dec3, dec2, dec1, dec0, enc4
+  pre[4] = skip[4];
+  const half_t* prev = skip[4];
+  int ph = P.h[4], pw = P.w[4], pc = ctx->conv[12].cout;
+  for (int d = 0; d < 4; ++d) {
+    const UnetLayer& L = ctx->conv[13 + d];
+    const int sb = 3 - d;
+    const int cs = L.cin - pc;
+    half_t* cat = buf(P.dec_cat[d]);
+    const long long n = (long long)P.dh[d] * P.dw[d] * (L.cin / 8);
+    hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prev, ph, pw, pc,
+                       skip[sb], P.w[sb], cs, cat);
+    half_t* o = buf(P.dec_out[d]);
+    int rc = launch_conv(L, cat, P.dh[d], P.dw[d], o, s);
+    if (rc != PXT_OK) return rc;
+    prev = o;
+    ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
+    pre[3 - d] = o;
+  }
+  // heads at output scales 0, 2, 4
+  static const int head_src[3] = {0, 2, 4};
+  for (int k = 0; k < 3; ++k) {
+    const UnetLayer& Lh = ctx->head[k];
+    const int i = head_src[k];
+    const int hh = (i == 4) ? P.h[4] : P.dh[3 - i], ww = (i == 4) ? P.w[4] : P.dw[3 - i];
+    const long long npix = (long long)hh * ww;
+    constexpr int PIX = 4;
+    const long long waves = (npix + PIX - 1) / PIX;
+    hipLaunchKernelGGL(head_kernel<PIX>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pre[i], npix,
+                       Lh.cin, (const float*)Lh.w, Lh.b, Lh.cout, normalize, out_maps[k], out_cstride[k]);
+  }
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_conv3x3_nhwc_f16(const void* in, int32_t H, int32_t W, int32_t Cin,
+                                    const void* weights, const float* bias, int32_t Cout,
+                                    int32_t relu, void* out, void* stream) {
+  if (!in || !weights || !bias || !out || H < 1 || W < 1) return PXT_E_ARG;
+  UnetLayer L;
+  L.cin = Cin;
+  L.cout = Cout;
+  L.w = weights;
+  L.b = bias;
+  int rc = launch_conv(L, (const half_t*)in, H, W, (half_t*)out, (hipStream_t)stream, relu);
+  if (rc != PXT_OK) return rc;
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}

@@ -1,0 +1,252 @@
+"""Host side of the UNet feature pyramid (pixloc ``UNet``, experiment pixloc_megadepth).
+
+Reference interface: ``pred = self.model({"image": image_tensor})`` ->
+``{"feature_maps": [...], "confidences": [...]}`` with ``model.scales``
+(pixtrack/localization/feature_extractor.py:26,48-57).  Architecture: SURVEY.md A.5.
+
+The forward pass is a chain of hand-written HIP kernels behind ``pxt_unet_forward``
+(csrc/pxt_unet.hip): fp16 NHWC activations, MFMA implicit-GEMM 3x3 convolutions with
+fp32 accumulation, BatchNorm folded into the decoder convolutions, and 1x1 heads that
+write the HWC float32 maps (descriptor + confidence channel) the LM kernel reads.
+This module only packs weights and marshals pointers; there is no PyTorch conv path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .optimizer import cstride_for
+
+ENC_BLOCKS = [[(3, 64), (64, 64)], [(64, 128), (128, 128)], [(128, 256), (256, 256), (256, 256)],
+              [(256, 512), (512, 512), (512, 512)], [(512, 512), (512, 512), (512, 512)]]
+SKIP_DIMS = [64, 128, 256, 512, 512]
+DECODER = [64, 64, 64, 32]
+OUTPUT_SCALES = [0, 2, 4]
+OUTPUT_DIMS = [32, 128, 128]
+HEAD_INPUTS = [32, 64, 512]
+BN_EPS = 1e-5
+MAGIC = b"PXTUNET1"
+
+
+def conv_layer_names() -> List[str]:
+    names = [f"enc{b}_{i}" for b, convs in enumerate(ENC_BLOCKS) for i in range(len(convs))]
+    return names + [f"dec{d}" for d in range(len(DECODER))]
+
+
+def conv_layer_dims() -> List[Tuple[int, int]]:
+    dims = [c for convs in ENC_BLOCKS for c in convs]
+    prev = SKIP_DIMS[-1]
+    for out, skip in zip(DECODER, SKIP_DIMS[:-1][::-1]):
+        dims.append((prev + skip, out))
+        prev = out
+    return dims
+
+
+def make_synthetic_unet_weights(seed: int = 7, bn_trivial: bool = True) -> Dict[str, torch.Tensor]:
+    """Seeded stand-in for the absent pixloc_megadepth checkpoint: He-normal
+    convolutions, zero biases for the encoder... BN gamma=1, beta=0, running stats 0/1
+    (``bn_trivial=False`` randomises the BN statistics to exercise the folding)."""
+    g = torch.Generator().manual_seed(seed)
+    w: Dict[str, torch.Tensor] = {}
+
+    def he(cout, cin, k):
+        return torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+
+    for b, convs in enumerate(ENC_BLOCKS):
+        for i, (cin, cout) in enumerate(convs):
+            w[f"enc{b}_{i}.weight"] = he(cout, cin, 3)
+            w[f"enc{b}_{i}.bias"] = 0.05 * torch.randn(cout, generator=g)
+    prev = SKIP_DIMS[-1]
+    for d, (out, skip) in enumerate(zip(DECODER, SKIP_DIMS[:-1][::-1])):
+        w[f"dec{d}.weight"] = he(out, prev + skip, 3)
+        if bn_trivial:
+            w[f"dec{d}.bn_weight"] = torch.ones(out)
+            w[f"dec{d}.bn_bias"] = torch.zeros(out)
+            w[f"dec{d}.bn_mean"] = torch.zeros(out)
+            w[f"dec{d}.bn_var"] = torch.ones(out)
+        else:
+            w[f"dec{d}.bn_weight"] = 1.0 + 0.2 * torch.randn(out, generator=g)
+            w[f"dec{d}.bn_bias"] = 0.1 * torch.randn(out, generator=g)
+            w[f"dec{d}.bn_mean"] = 0.1 * torch.randn(out, generator=g)
+            w[f"dec{d}.bn_var"] = 0.5 + torch.rand(out, generator=g)
+        prev = out
+    for k, (cin, dim) in enumerate(zip(HEAD_INPUTS, OUTPUT_DIMS)):
+        w[f"adapt{k}.weight"] = torch.randn(dim, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+        w[f"adapt{k}.bias"] = 0.05 * torch.randn(dim, generator=g)
+        w[f"unc{k}.weight"] = torch.randn(1, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+        w[f"unc{k}.bias"] = 0.05 * torch.randn(1, generator=g)
+    return w
+
+
+def from_pixloc_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Maps a pixloc checkpoint's ``extractor.*`` keys (torchvision VGG16 indices inside
+    checkpointed Sequential blocks) to the canonical names used here."""
+    sd = {k[len("extractor."):] if k.startswith("extractor.") else k: v for k, v in sd.items()}
+    out: Dict[str, torch.Tensor] = {}
+    for b, convs in enumerate(ENC_BLOCKS):
+        # block 0: conv,relu,conv,relu -> conv indices 0,2 ; later blocks open with the pool:
+        # pool,conv,relu,... -> conv indices 1,3,5
+        first = 0 if b == 0 else 1
+        for i in range(len(convs)):
+            idx = first + 2 * i
+            out[f"enc{b}_{i}.weight"] = sd[f"encoder.{b}.{idx}.weight"]
+            out[f"enc{b}_{i}.bias"] = sd[f"encoder.{b}.{idx}.bias"]
+    for d in range(len(DECODER)):
+        out[f"dec{d}.weight"] = sd[f"decoder.{d}.layers.0.weight"]
+        out[f"dec{d}.bn_weight"] = sd[f"decoder.{d}.layers.1.weight"]
+        out[f"dec{d}.bn_bias"] = sd[f"decoder.{d}.layers.1.bias"]
+        out[f"dec{d}.bn_mean"] = sd[f"decoder.{d}.layers.1.running_mean"]
+        out[f"dec{d}.bn_var"] = sd[f"decoder.{d}.layers.1.running_var"]
+    for k in range(len(OUTPUT_SCALES)):
+        out[f"adapt{k}.weight"] = sd[f"adaptation.{k}.0.weight"]
+        out[f"adapt{k}.bias"] = sd[f"adaptation.{k}.0.bias"]
+        out[f"unc{k}.weight"] = sd[f"uncertainty.{k}.0.weight"]
+        out[f"unc{k}.bias"] = sd[f"uncertainty.{k}.0.bias"]
+    return out
+
+
+def _align16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def pack_unet_weights(w: Dict[str, torch.Tensor]) -> bytes:
+    """Flat blob consumed by ``pxt_unet_create``.
+
+    Layout: MAGIC(8) | int32 n_conv(17) | int32 n_heads(3) | n_conv x (int32 cin, cout) |
+    n_heads x (int32 cin, cout) | n_arrays x (int64 offset, int64 bytes) | data.
+    Arrays, in order: for every conv layer [weights, bias]; for every head [weights, bias].
+      * layer 0 weights: float32 [cout][ky][kx][cin]
+      * other conv weights: float16 [cout][ky][kx][cin]  (BatchNorm folded for decoders)
+      * conv bias: float32 [cout]
+      * head weights: float32 [cin][cout+1] (column `cout` = uncertainty row); bias [cout+1]
+    """
+    names, dims = conv_layer_names(), conv_layer_dims()
+    arrays: List[bytes] = []
+    for li, (name, (cin, cout)) in enumerate(zip(names, dims)):
+        W = w[f"{name}.weight"].detach().float()
+        assert tuple(W.shape) == (cout, cin, 3, 3), (name, W.shape)
+        if name.startswith("dec"):
+            s = w[f"{name}.bn_weight"].float() / torch.sqrt(w[f"{name}.bn_var"].float() + BN_EPS)
+            b = w[f"{name}.bn_bias"].float() - w[f"{name}.bn_mean"].float() * s
+            W = W * s[:, None, None, None]
+        else:
+            b = w[f"{name}.bias"].detach().float()
+        Wk = W.permute(0, 2, 3, 1).contiguous()  # [cout][ky][kx][cin]
+        arrays.append(Wk.numpy().astype(np.float32 if li == 0 else np.float16).tobytes())
+        arrays.append(b.numpy().astype(np.float32).tobytes())
+    for k, (cin, dim) in enumerate(zip(HEAD_INPUTS, OUTPUT_DIMS)):
+        Wa = w[f"adapt{k}.weight"].detach().float().reshape(dim, cin)
+        Wu = w[f"unc{k}.weight"].detach().float().reshape(1, cin)
+        Wt = torch.cat([Wa, Wu], 0).t().contiguous()  # [cin][dim+1]
+        bt = torch.cat([w[f"adapt{k}.bias"].float(), w[f"unc{k}.bias"].float()])
+        arrays.append(Wt.numpy().astype(np.float32).tobytes())
+        arrays.append(bt.numpy().astype(np.float32).tobytes())
+    head = bytearray()
+    head += MAGIC
+    head += struct.pack("<ii", len(names), len(OUTPUT_DIMS))
+    for cin, cout in dims:
+        head += struct.pack("<ii", cin, cout)
+    for cin, dim in zip(HEAD_INPUTS, OUTPUT_DIMS):
+        head += struct.pack("<ii", cin, dim)
+    table_off = len(head)
+    data_off = _align16(table_off + 16 * len(arrays))
+    offs, cur = [], data_off
+    for a in arrays:
+        offs.append((cur, len(a)))
+        cur = _align16(cur + len(a))
+    for o, n in offs:
+        head += struct.pack("<qq", o, n)
+    blob = bytearray(cur)
+    blob[: len(head)] = head
+    for (o, n), a in zip(offs, arrays):
+        blob[o : o + n] = a
+    return bytes(blob)
+
+
+class UNet:
+    """``model({"image": 1x3xHxW in [0,1]})`` compatible wrapper + the packed fast path."""
+
+    scales = [1, 4, 16]
+    output_dims = OUTPUT_DIMS
+
+    def __init__(self, weights: Dict[str, torch.Tensor], device: torch.device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PxtError("UNet needs a ROCm device; no CPU path exists")
+        blob = pack_unet_weights(weights)
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().pxt_unet_create(blob, len(blob), C.byref(self._ctx)), "pxt_unet_create")
+        self._ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                _lib.lib().pxt_unet_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # pixloc module-ish surface
+    def eval(self):
+        return self
+
+    def to(self, device):
+        assert torch.device(device) == self.device
+        return self
+
+    @staticmethod
+    def level_shapes(H: int, W: int) -> List[Tuple[int, int]]:
+        hs, ws = [H], [W]
+        for _ in range(4):
+            hs.append(hs[-1] // 2)
+            ws.append(ws[-1] // 2)
+        # decoder output sizes (upsample x2 of the coarser map, skip cropped to it)
+        dh, dw = hs[4], ws[4]
+        dec = []
+        for _ in range(4):
+            dh, dw = dh * 2, dw * 2
+            dec.append((dh, dw))
+        return [dec[3], dec[1], (hs[4], ws[4])]  # strides 1, 4, 16
+
+    def forward_packed(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                       normalize: bool = False) -> List[torch.Tensor]:
+        """image: HWC, 3 channels, 0..255, float32 or uint8, on the device.  Returns the
+        three HWC float32 maps [h,w,cstride] (descriptor channels then confidence)."""
+        L = _lib.lib()
+        _lib.require_gpu(image, "image")
+        assert image.dim() == 3 and image.shape[2] == 3 and image.is_contiguous()
+        assert image.dtype in (torch.float32, torch.uint8)
+        H, W = int(image.shape[0]), int(image.shape[1])
+        need = int(L.pxt_unet_workspace_bytes(self._ctx, H, W))
+        if need <= 0:
+            raise _lib.PxtError(f"image {H}x{W} too small for the 4-level encoder")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        shapes = self.level_shapes(H, W)
+        outs = [torch.empty(h, w, cstride_for(c), device=self.device, dtype=torch.float32)
+                for (h, w), c in zip(shapes, OUTPUT_DIMS)]
+        ptrs = (C.c_void_p * 3)(*[o.data_ptr() for o in outs])
+        cs = (C.c_int32 * 3)(*[o.shape[2] for o in outs])
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.shape == (H, W) and mask.is_contiguous()
+        _lib.check(
+            L.pxt_unet_forward(self._ctx, image.data_ptr(), int(image.dtype == torch.uint8), _lib.dptr(mask),
+                               H, W, ptrs, cs, int(normalize), self._ws.data_ptr(), _lib.stream_ptr(self.device)),
+            "pxt_unet_forward",
+        )
+        return outs
+
+    def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, List[torch.Tensor]]:
+        image = data["image"]  # 1 x 3 x H x W in [0, 1]
+        assert image.dim() == 4 and image.shape[0] == 1 and image.shape[1] == 3
+        hwc = (image[0].permute(1, 2, 0) * 255.0).to(self.device, torch.float32).contiguous()
+        outs = self.forward_packed(hwc, None, normalize=False)
+        feats = [o[..., :c].permute(2, 0, 1)[None] for o, c in zip(outs, OUTPUT_DIMS)]
+        confs = [o[..., c : c + 1].permute(2, 0, 1)[None] for o, c in zip(outs, OUTPUT_DIMS)]
+        return {"feature_maps": feats, "confidences": confs}

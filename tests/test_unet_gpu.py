@@ -1,0 +1,102 @@
+"""Parity of the HIP UNet (MFMA implicit-GEMM convs, fp16 activations, fp32 accumulate)
+against the fp32 PyTorch-CPU oracle.  Tolerances are those of fp16 storage (11-bit
+mantissa, the same mantissa as the TF32 convs the reference runs on Ampere)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_oracle as UO
+from pixtrack_amd import _lib
+from pixtrack_amd.unet import OUTPUT_DIMS, UNet, make_synthetic_unet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,relu", [(16, 16, 32, 32, 1), (37, 50, 64, 64, 1), (20, 33, 128, 96, 0),
+                                               (30, 40, 512, 128, 1), (48, 64, 1024, 64, 1)])
+def test_conv3x3_layer_matches_conv2d(device, H, W, Cin, Cout, relu):
+    """KAT-6: one layer vs torch.nn.functional.conv2d on the same fp16-rounded operands;
+    asymmetric random weights catch operand/row-column transposes."""
+    g = torch.Generator().manual_seed(H * 1000 + W + Cin)
+    x = torch.randn(Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.float()[None], w.float(), b, padding=1)[0]
+    if relu:
+        ref = F.relu(ref)
+    xd = x.permute(1, 2, 0).contiguous().to(device)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device)
+    bd = b.to(device)
+    out = torch.full((H, W, Cout), float("nan"), dtype=torch.float16, device=device)
+    _lib.check(_lib.lib().pxt_conv3x3_nhwc_f16(xd.data_ptr(), H, W, Cin, wd.data_ptr(), bd.data_ptr(), Cout, relu,
+                                               out.data_ptr(), _lib.stream_ptr(device)), "conv")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(2, 0, 1)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def _compare_pyramid(device, H, W, normalize, seed=3, bn_trivial=False, mask=None, u8=False):
+    w = make_synthetic_unet_weights(seed=seed, bn_trivial=bn_trivial)
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(0, 255, size=(H, W, 3)).astype(np.float32)
+    # smooth it a little so it resembles an image rather than white noise
+    img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(img, 2, 0)) / 4
+    if u8:
+        img = np.floor(img).astype(np.float32)
+    img_ref = img * mask[..., None] if mask is not None else img
+    feats, confs = UO.unet_forward(w, torch.from_numpy(img_ref).permute(2, 0, 1) / 255.0)
+    net = UNet(w, device)
+    src = torch.from_numpy(img.astype(np.uint8) if u8 else img).to(device)
+    md = torch.from_numpy(mask.astype(np.uint8)).to(device) if mask is not None else None
+    outs = net.forward_packed(src, md, normalize=normalize)
+    torch.cuda.synchronize()
+    for k, (o, c) in enumerate(zip(outs, OUTPUT_DIMS)):
+        o = o.cpu()
+        f_ref = feats[k].permute(1, 2, 0)
+        assert o.shape[:2] == f_ref.shape[:2], (o.shape, f_ref.shape)
+        f = o[..., :c]
+        if normalize:
+            f_ref = f_ref / f_ref.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        cos = F.cosine_similarity(f, f_ref, dim=-1)
+        assert cos.min().item() > 0.9995, (k, cos.min().item())
+        scale = f_ref.abs().max().item()
+        assert (f - f_ref).abs().max().item() < 2e-2 * scale, (k, (f - f_ref).abs().max().item(), scale)
+        assert (o[..., c] - confs[k][0]).abs().max().item() < 5e-3
+        assert (o[..., c + 1:] == 0).all()
+    return outs
+
+
+@pytest.mark.parametrize("H,W", [(64, 48), (96, 128)])
+def test_unet_matches_oracle(device, H, W):
+    _compare_pyramid(device, H, W, normalize=False)
+
+
+def test_unet_odd_size_crops_like_pixloc(device):
+    """Sizes not divisible by 16: pool floors, decoder crops the skip (A.5)."""
+    _compare_pyramid(device, 75, 100, normalize=True)
+
+
+def test_unet_mask_and_u8_and_normalize(device):
+    rng = np.random.default_rng(0)
+    mask = (rng.uniform(size=(64, 80)) > 0.3).astype(np.float32)
+    _compare_pyramid(device, 64, 80, normalize=True, mask=mask, u8=True)
+
+
+def test_unet_module_call_convention(device):
+    """model({"image": 1x3xHxW in [0,1]}) -> feature_maps / confidences, model.scales."""
+    w = make_synthetic_unet_weights(seed=5)
+    net = UNet(w, device)
+    x = torch.rand(1, 3, 48, 64)
+    pred = net({"image": x.to(device)})
+    feats, confs = UO.unet_forward(w, x[0])
+    assert net.scales == [1, 4, 16]
+    for k in range(3):
+        assert pred["feature_maps"][k].shape == (1,) + tuple(feats[k].shape)
+        assert pred["confidences"][k].shape == (1,) + tuple(confs[k].shape)
+        cos = F.cosine_similarity(pred["feature_maps"][k][0].cpu(), feats[k], dim=0)
+        assert cos.min().item() > 0.9995
