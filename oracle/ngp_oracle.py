@@ -1,0 +1,359 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the instant-ngp style NeRF
+inference renderer on the pixtrack hot path.
+
+PARITY UNPINNED: the renderer is NVlabs/instant-ngp (`.gitmodules:7-11`, branch master,
+`checkout = b551bf1`) + tiny-cuda-nn, reached through `pyngp`; none of that source is
+under /root/reference.  The only reference-side facts are the call
+sites -- pixtrack/visualization/run_vis_on_poses.py:28-57 (fov from fx, camera matrix,
+render(w,h,spp=8,linear=True), Depth/Shade), pixtrack/utils/ingp_utils.py:22-44 (render
+settings) -- and the model shape printed in `notebooks/Render YCB GT Poses .ipynb:147-150`
+(hash grid L=16,F=2,T=2^19,N_min=16,b=1.51572 -> 13,074,912 params, which
+`grid_level_layout` below reproduces exactly; MLPs 32->64->16 and 32->64->64->16).
+Everything else restates the published instant-ngp inference algorithm (SURVEY.md
+Appendix B); where recollection was uncertain the choice made here IS the
+specification the HIP kernel is tested against:
+
+* rays through pixel centres, principal point at the image centre, fov from fx on x;
+* radial k1 lens handled by 8 fixed-point un-distortion iterations;
+* per-(pixel, spp) start jitter u in [0,1) from an integer hash (`start_jitter`);
+* dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 2^(cascades-1) * 8);
+* occupancy bitfield: one bit per 128^3 cell, x fastest, cascades concatenated;
+* empty cells are skipped by stepping t in dt increments to the next voxel border;
+* hash grid: tcnn layout (dense below 2^19 entries, else the 3-prime xor hash),
+  trilinear, fp16 table, fp16 output; SH degree 4 of the view direction (fp16);
+* MLPs: fp16 weights and activations, fp32 accumulation, ReLU hidden, density =
+  exp(out[0]), rgb = sigmoid(out[0..2]);
+* compositing front to back, stop when transmittance < min_transmittance with the
+  accumulated colour renormalised by 1/alpha (instant-ngp's early-out);
+* output = premultiplied linear RGBA averaged over spp, composited over
+  background.rgb * background.a (transparent for pixtrack's [255,255,255,0]).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+F32 = np.float32
+GRID = 128
+MIN_STEP = F32(math.sqrt(3.0) / 1024.0)
+
+
+@dataclass
+class NgpModel:
+    n_levels: int = 16
+    n_features: int = 2
+    log2_hashmap: int = 19
+    base_res: int = 16
+    per_level_scale: float = 1.51572
+    cascades: int = 3
+    aabb_scale: float = 4.0
+    cone_angle: float = 1.0 / 256.0
+    depth_scale: float = 1.0
+    grid: np.ndarray = None  # float16 [n_entries_total, n_features]
+    mlp: Dict[str, np.ndarray] = None  # float16: d1 [64,32], d2 [16,64], c1 [64,32], c2 [64,64], c3 [16,64]
+    occupancy: np.ndarray = None  # uint8 bitfield [cascades * 128^3 / 8]
+
+
+def grid_level_layout(m: NgpModel) -> List[Tuple[float, int, int, int, bool]]:
+    """Per level: (scale, resolution, offset, size, hashed) -- tiny-cuda-nn GridEncoding."""
+    out, off = [], 0
+    T = 1 << m.log2_hashmap
+    for l in range(m.n_levels):
+        scale = 2.0 ** (l * math.log2(m.per_level_scale)) * m.base_res - 1.0
+        res = int(math.ceil(scale)) + 1
+        n = res**3
+        n = T if n > T else n
+        n = (n + 7) // 8 * 8
+        n = min(n, T)
+        out.append((scale, res, off, n, res**3 > n))
+        off += n
+    return out
+
+
+def max_step(m: NgpModel) -> np.float32:
+    return F32(MIN_STEP * F32(2 ** (m.cascades - 1)) * F32(1024 // GRID))
+
+
+def start_jitter(pixel_index: np.ndarray, spp_index: int) -> np.ndarray:
+    """u in [0,1): 24-bit integer hash of (pixel, sample), exact in float32."""
+    h = (pixel_index.astype(np.uint64) * 747796405 + np.uint64(spp_index) * 2891336453 + 1) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & 0xFFFFFFFF
+    h ^= h >> 16
+    return ((h >> 8).astype(np.float32) * F32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def nerf_matrix_to_ngp(nerf_c2w: np.ndarray, scale: float = 0.33, offset: float = 0.5) -> np.ndarray:
+    """instant-ngp nerf_matrix_to_ngp: flip y,z columns, scale+offset the origin, cycle
+    the world axes (x,y,z) <- (y,z,x).  Input/outputs 3x4."""
+    m = np.array(nerf_c2w[:3, :4], dtype=np.float64).copy()
+    m[:, 1] *= -1
+    m[:, 2] *= -1
+    m[:, 3] = m[:, 3] * scale + offset
+    return m[[1, 2, 0], :]
+
+
+def calc_dt(t, cone_angle, lo, hi):
+    return np.minimum(np.maximum(t * F32(cone_angle), lo), hi).astype(np.float32)
+
+
+def mip_from_pos(pos: np.ndarray, cascades: int) -> np.ndarray:
+    maxval = np.max(np.abs(pos - F32(0.5)), axis=-1)
+    _, e = np.frexp(maxval)
+    return np.clip(e + 1, 0, cascades - 1).astype(np.int32)
+
+
+def mip_from_dt(dt: np.ndarray, pos: np.ndarray, cascades: int) -> np.ndarray:
+    _, e = np.frexp(dt * F32(GRID))
+    return np.minimum(cascades - 1, np.maximum(e, mip_from_pos(pos, cascades))).astype(np.int32)
+
+
+def occupied(m: NgpModel, pos: np.ndarray, mip: np.ndarray) -> np.ndarray:
+    """Bit test of the cascade-`mip` cell containing pos (float32 [n,3])."""
+    scale = np.ldexp(F32(1.0), -mip).astype(np.float32)[:, None]  # 2^-mip
+    p = (pos - F32(0.5)) * scale + F32(0.5)
+    idx = np.floor(p * F32(GRID)).astype(np.int64)
+    inside = np.all((idx >= 0) & (idx < GRID), axis=-1)
+    idx = np.clip(idx, 0, GRID - 1)
+    lin = (idx[:, 2] * GRID + idx[:, 1]) * GRID + idx[:, 0] + mip.astype(np.int64) * GRID**3
+    bits = (m.occupancy[lin >> 3] >> (lin & 7).astype(np.uint8)) & 1
+    return inside & (bits != 0)
+
+
+def advance_to_next_voxel(t, pos, d, idir, mip, cone_angle, lo, hi):
+    """Step t in dt increments until it passes the border of the current cascade cell."""
+    res = np.ldexp(F32(GRID), -mip).astype(np.float32)[:, None]  # cells per unit at this mip
+    p = (res * (pos - F32(0.5))).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        tx = (np.floor(p + F32(0.5) + F32(0.5) * np.sign(d).astype(np.float32)) - p) * idir
+    tx = np.where(d != 0, tx, np.float32(np.inf))  # axes the ray does not move along
+    tmin = np.min(tx, axis=-1)
+    t_target = (t + np.maximum(tmin / res[:, 0], F32(0.0))).astype(np.float32)
+    t = t.copy()
+    todo = np.ones_like(t, dtype=bool)
+    while todo.any():
+        t[todo] = (t[todo] + calc_dt(t[todo], cone_angle, lo, hi)).astype(np.float32)
+        todo &= t < t_target
+    return t
+
+
+# ---- encodings -------------------------------------------------------------
+
+PRIMES = (np.uint32(1), np.uint32(2654435761), np.uint32(805459861))
+
+
+def hash_grid_encode(m: NgpModel, x: np.ndarray) -> np.ndarray:
+    """x float32 [n,3] in [0,1]; returns float16 [n, n_levels*n_features]."""
+    n = x.shape[0]
+    out = np.zeros((n, m.n_levels * m.n_features), np.float16)
+    for l, (scale, res, off, size, hashed) in enumerate(grid_level_layout(m)):
+        pos = (x * F32(scale)).astype(np.float32) + F32(0.5)
+        pg = np.floor(pos)
+        frac = (pos - pg).astype(np.float32)
+        pg = pg.astype(np.int64).astype(np.uint32)
+        acc = np.zeros((n, m.n_features), np.float32)
+        for corner in range(8):
+            w = np.ones(n, np.float32)
+            cg = np.zeros((n, 3), np.uint32)
+            for dim in range(3):
+                if corner & (1 << dim):
+                    w = w * frac[:, dim]
+                    cg[:, dim] = pg[:, dim] + np.uint32(1)
+                else:
+                    w = w * (F32(1.0) - frac[:, dim])
+                    cg[:, dim] = pg[:, dim]
+            if hashed:
+                idx = (cg[:, 0] * PRIMES[0]) ^ (cg[:, 1] * PRIMES[1]) ^ (cg[:, 2] * PRIMES[2])
+            else:
+                idx = cg[:, 0] + cg[:, 1] * np.uint32(res) + cg[:, 2] * np.uint32(res * res)
+            idx = (idx % np.uint32(size)).astype(np.int64) + off
+            acc += w[:, None] * m.grid[idx].astype(np.float32)
+        out[:, l * m.n_features:(l + 1) * m.n_features] = acc.astype(np.float16)
+    return out
+
+
+def sh4(d: np.ndarray) -> np.ndarray:
+    """Real spherical harmonics up to degree 4 (16 coefficients), tiny-cuda-nn ordering."""
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    o = np.empty((d.shape[0], 16), np.float32)
+    o[:, 0] = 0.28209479177387814
+    o[:, 1] = -0.48860251190291987 * y
+    o[:, 2] = 0.48860251190291987 * z
+    o[:, 3] = -0.48860251190291987 * x
+    o[:, 4] = 1.0925484305920792 * xy
+    o[:, 5] = -1.0925484305920792 * yz
+    o[:, 6] = 0.94617469575755997 * z2 - 0.31539156525251999
+    o[:, 7] = -1.0925484305920792 * xz
+    o[:, 8] = 0.54627421529603959 * x2 - 0.54627421529603959 * y2
+    o[:, 9] = 0.59004358992664352 * y * (-3.0 * x2 + y2)
+    o[:, 10] = 2.8906114426405538 * xy * z
+    o[:, 11] = 0.45704579946446572 * y * (1.0 - 5.0 * z2)
+    o[:, 12] = 0.3731763325901154 * z * (5.0 * z2 - 3.0)
+    o[:, 13] = 0.45704579946446572 * x * (1.0 - 5.0 * z2)
+    o[:, 14] = 1.4453057213202769 * z * (x2 - y2)
+    o[:, 15] = 0.59004358992664352 * x * (-x2 + 3.0 * y2)
+    return o.astype(np.float16)
+
+
+def _layer(w16: np.ndarray, x16: np.ndarray, relu: bool) -> np.ndarray:
+    y = x16.astype(np.float32) @ w16.astype(np.float32).T
+    if relu:
+        y = np.maximum(y, 0)
+    return y
+
+
+def network(m: NgpModel, pos_unit: np.ndarray, dirs: np.ndarray):
+    """pos_unit: warped position in [0,1]^3; dirs: unit view directions.
+    Returns (density [n], rgb [n,3]) float32."""
+    feat = hash_grid_encode(m, pos_unit)
+    h = _layer(m.mlp["d1"], feat, True).astype(np.float16)
+    dout = _layer(m.mlp["d2"], h, False)
+    density = np.exp(dout[:, 0]).astype(np.float32)
+    cin = np.concatenate([dout.astype(np.float16), sh4(dirs)], 1)
+    h = _layer(m.mlp["c1"], cin, True).astype(np.float16)
+    h = _layer(m.mlp["c2"], h, True).astype(np.float16)
+    cout = _layer(m.mlp["c3"], h, False)
+    rgb = (1.0 / (1.0 + np.exp(-cout[:, :3]))).astype(np.float32)
+    return density, rgb
+
+
+# ---- renderer --------------------------------------------------------------
+
+
+@dataclass
+class View:
+    cam: np.ndarray  # 3x4 camera-to-world in ngp coordinates
+    focal: float
+    width: int
+    height: int
+    spp: int = 8
+    k1: float = 0.0
+    aabb_min: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    aabb_max: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    background: Tuple[float, float, float, float] = (255.0, 255.0, 255.0, 0.0)
+    min_transmittance: float = 1e-7
+    mode: int = 0  # 0 Shade, 1 Depth
+
+
+def generate_rays(v: View):
+    W, H = v.width, v.height
+    px, py = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    u = ((px + F32(0.5)) / F32(W)).astype(np.float32)
+    w_ = ((py + F32(0.5)) / F32(H)).astype(np.float32)
+    dx = ((u - F32(0.5)) * F32(W) / F32(v.focal)).astype(np.float32).ravel()
+    dy = ((w_ - F32(0.5)) * F32(H) / F32(v.focal)).astype(np.float32).ravel()
+    if v.k1 != 0.0:
+        xu, yu = dx.copy(), dy.copy()
+        for _ in range(8):
+            r2 = (xu * xu + yu * yu).astype(np.float32)
+            s = (F32(1.0) + F32(v.k1) * r2).astype(np.float32)
+            xu, yu = (dx / s).astype(np.float32), (dy / s).astype(np.float32)
+        dx, dy = xu, yu
+    cam = np.asarray(v.cam, dtype=np.float32)
+    d = (dx[:, None] * cam[None, :, 0] + dy[:, None] * cam[None, :, 1]).astype(np.float32) + cam[None, :, 2]
+    d = d.astype(np.float32)
+    nrm = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+    d = (d / nrm[:, None]).astype(np.float32)
+    o = np.broadcast_to(cam[:, 3], d.shape).astype(np.float32)
+    c2 = cam[:, 2]
+    fn = np.sqrt((c2[0] * c2[0] + c2[1] * c2[1]).astype(np.float32) + c2[2] * c2[2]).astype(np.float32)
+    fwd = (c2 / fn).astype(np.float32)
+    return o, d, fwd
+
+
+def ray_aabb(o, d, lo, hi):
+    idir = (F32(1.0) / d).astype(np.float32)
+    t0 = ((lo - o) * idir).astype(np.float32)
+    t1 = ((hi - o) * idir).astype(np.float32)
+    tmin = np.max(np.minimum(t0, t1), axis=-1)
+    tmax = np.min(np.maximum(t0, t1), axis=-1)
+    return tmin, tmax, idir
+
+
+def render(m: NgpModel, v: View, return_stats: bool = False):
+    """Returns float32 [H, W, 4] linear premultiplied RGBA."""
+    o, d, fwd = generate_rays(v)
+    n = o.shape[0]
+    half = F32(m.aabb_scale / 2.0)
+    scene_lo, scene_hi = F32(0.5) - half, F32(0.5) + half
+    lo = np.maximum(np.asarray(v.aabb_min, np.float32), scene_lo)
+    hi = np.minimum(np.asarray(v.aabb_max, np.float32), scene_hi)
+    tmin, tmax, idir = ray_aabb(o, d, lo, hi)
+    hit = tmax > np.maximum(tmin, F32(0.0))
+    dt_lo, dt_hi = MIN_STEP, max_step(m)
+    out = np.zeros((n, 4), np.float32)
+    pix = np.arange(n, dtype=np.int64)
+    n_samples = 0
+    zdot = ((d[:, 0] * fwd[0] + d[:, 1] * fwd[1]).astype(np.float32) + d[:, 2] * fwd[2]).astype(np.float32)
+    inv_s = F32(1.0 / m.aabb_scale)
+    for s in range(v.spp):
+        t = (np.maximum(tmin, F32(0.0)) + F32(1e-6)).astype(np.float32)
+        t = (t + start_jitter(pix, s) * calc_dt(t, m.cone_angle, dt_lo, dt_hi)).astype(np.float32)
+        alive = hit.copy()
+        T = np.ones(n, np.float32)
+        rgba = np.zeros((n, 4), np.float32)
+        while alive.any():
+            idx = np.nonzero(alive)[0]
+            # -- find the next occupied sample of every live ray
+            ti = t[idx]
+            searching = np.ones(idx.shape[0], bool)
+            found = np.zeros(idx.shape[0], bool)
+            while searching.any():
+                k = np.nonzero(searching)[0]
+                tk = ti[k]
+                pos = (o[idx[k]] + tk[:, None] * d[idx[k]]).astype(np.float32)
+                out_of_box = tk >= tmax[idx[k]]
+                dtk = calc_dt(tk, m.cone_angle, dt_lo, dt_hi)
+                mip = mip_from_dt(dtk, pos, m.cascades)
+                occ = occupied(m, pos, mip) & ~out_of_box
+                found[k[occ]] = True
+                searching[k[occ | out_of_box]] = False
+                adv = ~(occ | out_of_box)
+                if adv.any():
+                    ka = k[adv]
+                    ti[ka] = advance_to_next_voxel(tk[adv], pos[adv], d[idx[ka]], idir[idx[ka]], mip[adv],
+                                                   m.cone_angle, dt_lo, dt_hi)
+            t[idx] = ti
+            alive[idx[~found]] = False
+            idx = idx[found]
+            if idx.size == 0:
+                break
+            # -- evaluate + composite one sample per live ray
+            ti = t[idx]
+            pos = (o[idx] + ti[:, None] * d[idx]).astype(np.float32)
+            dti = calc_dt(ti, m.cone_angle, dt_lo, dt_hi)
+            unit = ((pos - scene_lo) * inv_s).astype(np.float32)
+            density, rgb = network(m, unit, d[idx])
+            n_samples += idx.size
+            if v.mode == 1:
+                depth = (ti * zdot[idx] * F32(m.depth_scale)).astype(np.float32)
+                rgb = np.repeat(depth[:, None], 3, 1)
+            alpha = (F32(1.0) - np.exp(-density * dti)).astype(np.float32)
+            wgt = (alpha * T[idx]).astype(np.float32)
+            rgba[idx, :3] += wgt[:, None] * rgb
+            rgba[idx, 3] += wgt
+            T[idx] = (T[idx] * (F32(1.0) - alpha)).astype(np.float32)
+            done = T[idx] < F32(v.min_transmittance)
+            if done.any():
+                di = idx[done]
+                rgba[di] = rgba[di] / rgba[di, 3:4]
+                alive[di] = False
+            t[idx] = (ti + dti).astype(np.float32)
+        out += rgba
+    out /= F32(v.spp)
+    bg = np.asarray(v.background, np.float32)
+    a = out[:, 3:4]
+    out[:, :3] += bg[:3] * bg[3] * (1 - a)
+    out[:, 3:4] = a + bg[3] * (1 - a)
+    img = out.reshape(v.height, v.width, 4)
+    if return_stats:
+        return img, {"samples": int(n_samples), "rays_hit": int(hit.sum()) * v.spp}
+    return img

@@ -30,6 +30,10 @@ FLAGS = [
 ]
 
 
+# per-file extra flags: the NeRF march must round exactly like the numpy oracle
+EXTRA = {"pxt_ngp": ["-ffp-contract=off"]}
+
+
 def sources():
     return sorted(CSRC.glob("*.hip"))
 
@@ -49,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         obj = OBJ / (src.stem + ".o")
         objs.append(obj)
         if force or _stale(obj, [src, *headers]):
-            cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+            cmd = [HIPCC, *FLAGS, *EXTRA.get(src.stem, []), "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -179,3 +179,110 @@ def make_lm_scene(
         scales.append(sc)
     return LMScene(width, height, p3d, camera, R_gt, t_gt, R_init, t_init, scales, feats_query,
                    feats_ref, tuple(dims), tuple(strides), center)
+
+
+# ---------------------------------------------------------------------------
+# Synthetic NeRF ("seeded synthetic hash-grid NeRF + a procedural density
+# prior so the object is opaque inside the AABB").  Pure data generation.
+# ---------------------------------------------------------------------------
+
+
+def ngp_grid_layout(n_levels=16, log2_hashmap=19, base_res=16, per_level_scale=1.51572):
+    """(scale, res, offset, size, hashed) per level -- tiny-cuda-nn GridEncoding sizes
+    (reproduces the 13,074,912 parameters of `notebooks/Render YCB GT Poses .ipynb:147`)."""
+    out, off, T = [], 0, 1 << log2_hashmap
+    for l in range(n_levels):
+        scale = 2.0 ** (l * math.log2(per_level_scale)) * base_res - 1.0
+        res = int(math.ceil(scale)) + 1
+        n = res**3
+        n = T if n > T else n
+        n = min((n + 7) // 8 * 8, T)
+        out.append((scale, res, off, n, res**3 > n))
+        off += n
+    return out, off
+
+
+def shape_value(x_ngp: np.ndarray, aabb) -> np.ndarray:
+    """Procedural object: a super-ellipsoid filling ~90 % of the render box; > 0 inside."""
+    lo, hi = np.asarray(aabb[0], np.float64), np.asarray(aabb[1], np.float64)
+    c, r = 0.5 * (lo + hi), 0.45 * (hi - lo)
+    q = np.abs((x_ngp - c) / r)
+    return 1.0 - np.sum(q**4, axis=-1) ** 0.25
+
+
+SHAPE_LEVEL = 3  # finest dense level (56^3 vertices): carries the shape indicator
+SHAPE_SHARPNESS = 3.0
+DENSITY_LOGIT = 10.0  # density = exp(+-10) inside / outside
+C3_GAIN = 1.0
+
+
+def make_synthetic_nerf(seed: int = 11, aabb=PREMIER_PROTEIN_AABB, aabb_scale: float = 4.0, cascades: int = 3):
+    from .ngp import NerfSnapshot
+
+    rng = np.random.default_rng(seed)
+    layout, n_entries = ngp_grid_layout()
+    grid = rng.uniform(-0.5, 0.5, size=(n_entries, 2)).astype(np.float32)
+    # shape indicator on the vertices of the dense level SHAPE_LEVEL, feature 0
+    scale, res, off, size, hashed = layout[SHAPE_LEVEL]
+    assert not hashed
+    g = np.arange(res, dtype=np.float64)
+    gx, gy, gz = np.meshgrid(g, g, g, indexing="ij")
+    # vertex g sits at warped x_w = (g - 0.5) / scale; ngp coords = x_w * aabb_scale + scene_lo
+    scene_lo = 0.5 - aabb_scale / 2
+    P = np.stack([gx, gy, gz], -1)
+    xw = (P - 0.5) / scale
+    x_ngp = xw * aabb_scale + scene_lo
+    val = np.clip(SHAPE_SHARPNESS * shape_value(x_ngp, aabb), -1.0, 1.0)
+    idx = (gx + gy * res + gz * res * res).astype(np.int64)
+    grid[off + idx.ravel(), 0] = val.ravel()
+
+    # MLPs (row-major [out][in]); feature index = 2 * level + f
+    def he(o, i, gain=1.0):
+        return rng.normal(size=(o, i)) * math.sqrt(2.0 / i) * gain
+
+    d1 = he(64, 32, 2.0)
+    d1[0, :] = 0.0
+    d1[1, :] = 0.0
+    d1[0, 2 * SHAPE_LEVEL] = 4.0
+    d1[1, 2 * SHAPE_LEVEL] = -4.0
+    d2 = he(16, 64, 2.0)
+    d2[0, :] = 0.0
+    d2[0, 0], d2[0, 1] = DENSITY_LOGIT / 4.0, -DENSITY_LOGIT / 4.0
+    d2[1:, 0:2] = 0.0  # the geometry features do not see the density logit
+    c1 = he(64, 32, 2.0)
+    c1[:, 0] = 0.0  # colour does not see the density logit either
+    c1[:, 16:] *= 0.15  # weak view dependence
+    # last two colour layers in antisymmetric pairs: relu(a) - relu(-a) = a keeps the colour
+    # logits zero-mean (there are no biases in these MLPs), so colours spread around 0.5
+    w = he(32, 64, 1.0)
+    w -= w.mean(axis=1, keepdims=True)
+    c2 = np.concatenate([w, -w], 0)
+    v = rng.normal(size=(3, 32)) * C3_GAIN / math.sqrt(32)
+    c3 = np.zeros((16, 64))
+    c3[:3, :32] = v
+    c3[:3, 32:] = -v
+    mlp = np.concatenate([m.astype(np.float16).ravel() for m in (d1, d2, c1, c2, c3)])
+
+    # occupancy: cascade c covers [0.5 - 2^c/2, 0.5 + 2^c/2]^3 with 128^3 cells
+    G = 128
+    occ_bits = np.zeros(cascades * G**3, np.uint8)
+    for c in range(cascades):
+        span = 2.0**c
+        cc = (np.arange(G) + 0.5) / G
+        cx, cy, cz = np.meshgrid(cc, cc, cc, indexing="ij")  # x fastest is handled below
+        centres = (np.stack([cx, cy, cz], -1) - 0.5) * span + 0.5
+        cell = span / G
+        # occupied if the shape value anywhere in the cell can exceed the -1 clamp:
+        # |grad(shape)| <= 1/min(r) ; be conservative by one cell diagonal + one level-3 cell
+        lo, hi = np.asarray(aabb[0]), np.asarray(aabb[1])
+        rmin = float(np.min(0.45 * (hi - lo)))
+        margin = (cell * math.sqrt(3) + aabb_scale / scale) / rmin
+        v = shape_value(centres, aabb)
+        o = (SHAPE_SHARPNESS * (v + margin) > -0.8)
+        lin = (np.arange(G)[None, None, :, None] * 0)  # placeholder to keep shapes explicit
+        # linear index = (z * G + y) * G + x
+        o_zyx = np.transpose(o, (2, 1, 0))
+        occ_bits[c * G**3:(c + 1) * G**3] = o_zyx.ravel().astype(np.uint8)
+    occupancy = np.packbits(occ_bits, bitorder="little")
+    return NerfSnapshot(grid=grid.astype(np.float16), mlp=mlp, occupancy=occupancy, cascades=cascades,
+                        aabb_scale=aabb_scale)
