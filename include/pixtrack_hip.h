@@ -199,6 +199,11 @@ typedef struct {
 int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
                    uint64_t* stats /* device, 4 counters or NULL */, void* stream);
 
+/* Network query at caller-given points, ngp coordinates + unit view directions (device
+ * float32 [n][3] each): out[n][4] = (density logit, r, g, b).  Same device code as the
+ * renderer's per-sample evaluation; used by the parity tests (SURVEY KAT-7). */
+int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, int32_t n, float* out, void* stream);
+
 /* -------------------------------------------------------------------------
  * Small image ops on the path (host cv2/numpy calls in the reference).
  * ---------------------------------------------------------------------- */

@@ -126,6 +126,134 @@ __device__ inline half8 relu_pack8(const f32x16& a, int base, bool relu) {
   return r;
 }
 
+// Hash-grid encode + both MLPs for the wave's 64 samples (lane = sample).  Must be called
+// by all 64 lanes (MFMA); `alive` only gates the gathers.  ux,uy,uz: position in [0,1]^3.
+__device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, bool alive, float ux,
+                                float uy, float uz, const unsigned* shB0, const unsigned* shB1,
+                                float& logit, float* rgbv) {
+        // ---- hash grid encode (lane = sample) ----
+        unsigned Flo[8], Fhi[8];
+        {
+#pragma unroll
+          for (int l = 0; l < kMaxLevels; ++l) {
+            float f0 = 0.f, f1 = 0.f;
+            if (alive && l < P.n_levels) {
+              const NgpLevel& Lv = P.lv[l];
+              const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
+              const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+              const float ax = qx - fx, ay = qy - fy, az = qz - fz;
+              const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
+              unsigned vals[8];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const unsigned cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
+                unsigned idx;
+                if (Lv.hashed)
+                  idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+                else
+                  idx = cx + cy * Lv.res + cz * Lv.res * Lv.res;
+                idx = idx % Lv.size + Lv.offset;
+                vals[c] = P.grid[idx];
+              }
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                float w = 1.0f;
+                w = w * ((c & 1) ? ax : (1.0f - ax));
+                w = w * ((c & 2) ? ay : (1.0f - ay));
+                w = w * ((c & 4) ? az : (1.0f - az));
+                const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
+                f0 += w * (float)hv[0];
+                f1 += w * (float)hv[1];
+              }
+            }
+            const unsigned pk = pack_h2(f0, f1);
+            if (l < 8) Flo[l] = pk; else Fhi[l - 8] = pk;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) swap32(Flo[i], Fhi[i]);
+        // B fragments of the feature input: [cb][q]
+        half8 xB[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          xB[0][q] = as_half8(Flo[4 * q], Flo[4 * q + 1], Flo[4 * q + 2], Flo[4 * q + 3]);
+          xB[1][q] = as_half8(Fhi[4 * q], Fhi[4 * q + 1], Fhi[4 * q + 2], Fhi[4 * q + 3]);
+        }
+
+        // ---- density MLP: 32 -> 64 (ReLU) -> 16 ----
+        f32x16 h1[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x16 a = {0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD1 + 2 * rb + q) * 64 + lane], xB[cb][q], a, 0, 0, 0);
+            h1[rb][cb] = a;
+          }
+        f32x16 dout[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          f32x16 a = {0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD2 + q) * 64 + lane],
+                                                       relu_pack8(h1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
+          dout[cb] = a;
+        }
+        // ---- colour MLP: [16 density outputs | 16 SH] -> 64 -> 64 -> 16 ----
+        f32x16 c1[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x16 a = {0};
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb) * 64 + lane],
+                                                       relu_pack8(dout[cb], 0, false), a, 0, 0, 0);
+            const half8 shb = cb == 0 ? as_half8(shB0[0], shB0[1], shB0[2], shB0[3])
+                                      : as_half8(shB1[0], shB1[1], shB1[2], shB1[3]);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb + 1) * 64 + lane], shb, a, 0, 0, 0);
+            c1[rb][cb] = a;
+          }
+        f32x16 c2[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            f32x16 a = {0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC2 + 4 * rb + q) * 64 + lane],
+                                                         relu_pack8(c1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
+            c2[rb][cb] = a;
+          }
+        f32x16 cout[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          f32x16 a = {0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC3 + q) * 64 + lane],
+                                                       relu_pack8(c2[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
+          cout[cb] = a;
+        }
+        // rows 0..3 of column block cb sit in the low half; bring block 1 to the high lanes
+        unsigned r0 = __builtin_bit_cast(unsigned, dout[0][0]), r1 = __builtin_bit_cast(unsigned, dout[1][0]);
+        swap32(r0, r1);
+        logit = __builtin_bit_cast(float, r0);
+        // The activation is applied BEFORE the cross-lane move: v_permlane32_swap reading a
+        // register an MFMA is still writing returned stale rows (regs > 0) on gfx950/ROCm 7.2;
+        // a VALU op in between gets the MFMA->VALU wait states the compiler does model.
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          unsigned a0 = __builtin_bit_cast(unsigned, 1.0f / (1.0f + expf(-cout[0][c])));
+          unsigned a1 = __builtin_bit_cast(unsigned, 1.0f / (1.0f + expf(-cout[1][c])));
+          swap32(a0, a1);
+          rgbv[c] = __builtin_bit_cast(float, a0);
+        }
+}
+
 __global__ __launch_bounds__(256) void ngp_render_kernel(const NgpParams P) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
@@ -265,126 +393,9 @@ __global__ __launch_bounds__(256) void ngp_render_kernel(const NgpParams P) {
         n_batches += 1;
         if (alive) n_samples += 1;
 
-        // ---- hash grid encode (lane = sample) ----
-        unsigned Flo[8], Fhi[8];
-        {
-          const float ux = (pos[0] - scene_lo) * inv_s, uy = (pos[1] - scene_lo) * inv_s,
-                      uz = (pos[2] - scene_lo) * inv_s;
-#pragma unroll
-          for (int l = 0; l < kMaxLevels; ++l) {
-            float f0 = 0.f, f1 = 0.f;
-            if (alive && l < P.n_levels) {
-              const NgpLevel& Lv = P.lv[l];
-              const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
-              const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-              const float ax = qx - fx, ay = qy - fy, az = qz - fz;
-              const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
-              unsigned vals[8];
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                const unsigned cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
-                unsigned idx;
-                if (Lv.hashed)
-                  idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
-                else
-                  idx = cx + cy * Lv.res + cz * Lv.res * Lv.res;
-                idx = idx % Lv.size + Lv.offset;
-                vals[c] = P.grid[idx];
-              }
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                float w = 1.0f;
-                w = w * ((c & 1) ? ax : (1.0f - ax));
-                w = w * ((c & 2) ? ay : (1.0f - ay));
-                w = w * ((c & 4) ? az : (1.0f - az));
-                const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
-                f0 += w * (float)hv[0];
-                f1 += w * (float)hv[1];
-              }
-            }
-            const unsigned pk = pack_h2(f0, f1);
-            if (l < 8) Flo[l] = pk; else Fhi[l - 8] = pk;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) swap32(Flo[i], Fhi[i]);
-        // B fragments of the feature input: [cb][q]
-        half8 xB[2][2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          xB[0][q] = as_half8(Flo[4 * q], Flo[4 * q + 1], Flo[4 * q + 2], Flo[4 * q + 3]);
-          xB[1][q] = as_half8(Fhi[4 * q], Fhi[4 * q + 1], Fhi[4 * q + 2], Fhi[4 * q + 3]);
-        }
-
-        // ---- density MLP: 32 -> 64 (ReLU) -> 16 ----
-        f32x16 h1[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            f32x16 a = {0};
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD1 + 2 * rb + q) * 64 + lane], xB[cb][q], a, 0, 0, 0);
-            h1[rb][cb] = a;
-          }
-        f32x16 dout[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          f32x16 a = {0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD2 + q) * 64 + lane],
-                                                       relu_pack8(h1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
-          dout[cb] = a;
-        }
-        // ---- colour MLP: [16 density outputs | 16 SH] -> 64 -> 64 -> 16 ----
-        f32x16 c1[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            f32x16 a = {0};
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb) * 64 + lane],
-                                                       relu_pack8(dout[cb], 0, false), a, 0, 0, 0);
-            const half8 shb = cb == 0 ? as_half8(shB0[0], shB0[1], shB0[2], shB0[3])
-                                      : as_half8(shB1[0], shB1[1], shB1[2], shB1[3]);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb + 1) * 64 + lane], shb, a, 0, 0, 0);
-            c1[rb][cb] = a;
-          }
-        f32x16 c2[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            f32x16 a = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC2 + 4 * rb + q) * 64 + lane],
-                                                         relu_pack8(c1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
-            c2[rb][cb] = a;
-          }
-        f32x16 cout[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          f32x16 a = {0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC3 + q) * 64 + lane],
-                                                       relu_pack8(c2[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
-          cout[cb] = a;
-        }
-        // rows 0..3 of column block cb sit in the low half; bring block 1 to the high lanes
-        unsigned r0 = __builtin_bit_cast(unsigned, dout[0][0]), r1 = __builtin_bit_cast(unsigned, dout[1][0]);
-        swap32(r0, r1);
-        const float logit = __builtin_bit_cast(float, r0);
-        float rgbv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          unsigned a0 = __builtin_bit_cast(unsigned, cout[0][c]), a1 = __builtin_bit_cast(unsigned, cout[1][c]);
-          swap32(a0, a1);
-          rgbv[c] = 1.0f / (1.0f + expf(-__builtin_bit_cast(float, a0)));
-        }
+        float logit, rgbv[3];
+        ngp_eval(P, s_w, lane, alive, (pos[0] - scene_lo) * inv_s, (pos[1] - scene_lo) * inv_s,
+                 (pos[2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
         // ---- composite ----
         if (alive) {
           const float density = expf(logit);
@@ -430,6 +441,39 @@ __global__ __launch_bounds__(256) void ngp_render_kernel(const NgpParams P) {
       atomicAdd(P.stats + 1, n_hit);
       atomicAdd(P.stats + 2, n_batches);
     }
+  }
+}
+
+// Network query at caller-given points (unit tests / debugging): out[n] = (logit, r, g, b).
+__global__ __launch_bounds__(256) void ngp_query_kernel(const NgpParams P, const float* __restrict__ pos,
+                                                        const float* __restrict__ dir, int n,
+                                                        float* __restrict__ out) {
+  __shared__ half8 s_w[kNumFrags * 64];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < n;
+  const int ii = ok ? i : 0;
+  const float half_s = P.aabb_scale * 0.5f;
+  const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
+  float sh[16];
+  sh4_eval(dir[3 * ii], dir[3 * ii + 1], dir[3 * ii + 2], sh);
+  unsigned shB0[4], shB1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    shB0[k] = pack_h2(sh[2 * k], sh[2 * k + 1]);
+    shB1[k] = pack_h2(sh[8 + 2 * k], sh[8 + 2 * k + 1]);
+    swap32(shB0[k], shB1[k]);
+  }
+  float logit, rgbv[3];
+  ngp_eval(P, s_w, lane, ok, (pos[3 * ii] - scene_lo) * inv_s, (pos[3 * ii + 1] - scene_lo) * inv_s,
+           (pos[3 * ii + 2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
+  if (ok) {
+    out[4 * i] = logit;
+    out[4 * i + 1] = rgbv[0];
+    out[4 * i + 2] = rgbv[1];
+    out[4 * i + 3] = rgbv[2];
   }
 }
 
@@ -533,11 +577,38 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   return PXT_OK;
 }
 
+static void fill_model(const pxt_ngp* ctx, NgpParams& P) {
+  std::memset(&P, 0, sizeof(P));
+  P.grid = ctx->grid;
+  P.wfrag = ctx->wfrag;
+  P.occ = ctx->occ;
+  for (int l = 0; l < kMaxLevels; ++l) P.lv[l] = ctx->lv[l < ctx->model.n_levels ? l : 0];
+  P.n_levels = ctx->model.n_levels;
+  P.cascades = ctx->model.grid_cascades;
+  P.aabb_scale = ctx->model.aabb_scale;
+  P.cone_angle = ctx->model.cone_angle;
+  P.depth_scale = ctx->model.depth_scale;
+  P.dt_lo = (float)(std::sqrt(3.0) / 1024.0);
+  P.dt_hi = P.dt_lo * (float)(1 << (P.cascades - 1)) * (float)(1024 / kGrid);
+}
+
+extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, int32_t n, float* out,
+                             void* stream) {
+  if (!ctx || !pos || !dir || !out || n < 1) return PXT_E_ARG;
+  NgpParams P;
+  fill_model(ctx, P);
+  hipLaunchKernelGGL(ngp_query_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, pos, dir, n,
+                     out);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
 extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, uint64_t* stats,
                               void* stream) {
   if (!ctx || !v || !out_rgba) return PXT_E_ARG;
   if (v->width < 1 || v->height < 1 || v->spp < 1 || !(v->focal > 0.f)) return PXT_E_ARG;
   NgpParams P;
+  fill_model(ctx, P);
   P.grid = ctx->grid;
   P.wfrag = ctx->wfrag;
   P.occ = ctx->occ;

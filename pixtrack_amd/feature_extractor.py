@@ -1,0 +1,78 @@
+"""PixTrackFeatureExtractor (reference pixtrack/localization/feature_extractor.py:9-59).
+
+Same name, constructor and ``__call__(image, scale_image) -> (features, scales, confidences)``
+contract.  ``extract_packed`` is the device-resident path the refiner uses: the image stays on
+the GPU (float32 / uint8 HWC 0..255), the optional query mask is multiplied inside the first
+convolution, and the pyramid comes back as the HWC records the LM kernel reads.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .unet import OUTPUT_DIMS
+from .utils.conf import merge
+
+
+class PixTrackFeatureExtractor:
+    default_conf: Dict = dict(resize=1024, resize_by="max")
+
+    def __init__(self, model, device: torch.device, conf: Optional[Dict] = None):
+        self.conf = merge(self.default_conf, conf or {})
+        self.device = torch.device(device)
+        self.model = model
+        assert hasattr(self.model, "scales")
+        assert self.conf.resize_by in ["max", "max_force"], self.conf.resize_by
+
+    def eval(self):
+        return self
+
+    # ---- sizing rule of pixloc `resize(image, size, max, "linear")` -----------
+    def target_size(self, h: int, w: int, scale_image: int) -> Tuple[int, int, Tuple[float, float]]:
+        scale_resize = (1.0, 1.0)
+        if self.conf.resize is not None:
+            target = self.conf.resize // scale_image
+            if max(h, w) > target or self.conf.resize_by == "max_force":
+                s = target / max(h, w)
+                h_new, w_new = int(round(h * s)), int(round(w * s))
+                scale_resize = (w_new / w, h_new / h)
+                return h_new, w_new, scale_resize
+        return h, w, scale_resize
+
+    def _to_device_hwc(self, image) -> torch.Tensor:
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image))
+        if image.dtype not in (torch.float32, torch.uint8):
+            image = image.float()
+        return image.to(self.device).contiguous()
+
+    def extract_packed(self, image, scale_image: int = 1, mask: Optional[torch.Tensor] = None,
+                       normalize: bool = False):
+        """-> (maps [h,w,cstride] x3 on device, scales [(sx,sy)] x3)."""
+        img = self._to_device_hwc(image)
+        H, W = int(img.shape[0]), int(img.shape[1])
+        h_new, w_new, scale_resize = self.target_size(H, W, scale_image)
+        if (h_new, w_new) != (H, W):
+            if mask is not None:  # the reference multiplies the mask into the image first
+                img = img.float() * mask.to(self.device)[..., None].float()
+                mask = None
+            src = img.float().contiguous()
+            dst = torch.empty(h_new, w_new, 3, device=self.device, dtype=torch.float32)
+            _lib.check(_lib.lib().pxt_resize_linear(src.data_ptr(), H, W, 3, dst.data_ptr(), h_new, w_new,
+                                                    _lib.stream_ptr(self.device)), "pxt_resize_linear")
+            img = dst
+        maps = self.model.forward_packed(img, mask, normalize=normalize)
+        scales = [(scale_resize[0] / s, scale_resize[1] / s) for s in self.model.scales]
+        return maps, scales
+
+    @torch.no_grad()
+    def __call__(self, image: np.ndarray, scale_image: int = 1):
+        """Reference contract: features [C,h,w] x3, scales, confidences [1,h,w] x3 (device)."""
+        maps, scales = self.extract_packed(image, scale_image, None, normalize=False)
+        features = [m[..., :c].permute(2, 0, 1) for m, c in zip(maps, OUTPUT_DIMS)]
+        confidences = [m[..., c : c + 1].permute(2, 0, 1) for m, c in zip(maps, OUTPUT_DIMS)]
+        assert len(self.model.scales) == len(features)
+        return features, scales, confidences

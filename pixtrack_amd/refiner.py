@@ -1,0 +1,306 @@
+"""PoseTrackerLocalizer / PoseTrackerRefiner -- the owners of the drop-in boundary
+(reference pixtrack/localization/pixloc_pose_refiners.py:28-396; pixloc BaseRefiner,
+SURVEY.md Appendix A.4).
+
+Same class names, method names, argument meaning and return dictionaries as the
+reference; inside, the three device stages are the HIP kernels of this package:
+
+* ``dense_feature_extraction``  -> pxt_unet_forward (feature_extractor.extract_packed)
+* ``interp_sparse_observations`` -> pxt_sample_sparse (all levels, one launch)
+* ``refine_pose_using_features`` -> pxt_lm_refine     (all levels, one persistent launch)
+
+Per-point Python lists of the reference (``p3did_to_feat`` built by slicing N tensors per
+level per frame, :359-366) are replaced by packed [N, cstride] tensors plus a validity
+mask; the list views the reference exposes are materialised lazily on access only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .feature_extractor import PixTrackFeatureExtractor
+from .geometry import Camera, Pose
+from .model3d import Model3D
+from .optimizer import LevelPack, PixTrackOptimizer, cstride_for
+from .unet import OUTPUT_DIMS, UNet
+from .utils.conf import Conf, merge
+
+logger = logging.getLogger(__name__)
+
+
+class SparseReferenceFeatures(dict):
+    """features_dicts[...]["features"][str(scale)] entry.
+
+    Dict keys kept from the reference: "p3dids" (ids valid on all levels) and
+    "p3did_to_feat" (per point tuple of per-level [C+1] tensors).  Both are derived lazily
+    from the packed device buffers the kernels use: ``packed[l]`` [N, cstride] (descriptor
+    L2-normalised, confidence at channel C), ``valid`` uint8 [N], ``p3dids_all``, ``p3d``."""
+
+    def __init__(self, packed, valid, p3dids_all, p3d, dims):
+        super().__init__()
+        self.packed, self.valid, self.p3dids_all, self.p3d, self.dims = packed, valid, p3dids_all, p3d, dims
+
+    def __missing__(self, key):
+        if key == "p3dids":
+            keep = self.valid.cpu().bool().tolist()
+            self[key] = [p for p, k in zip(self.p3dids_all, keep) if k]
+        elif key == "p3did_to_feat":
+            keep = self.valid.cpu().bool()
+            idx = torch.nonzero(keep)[:, 0].tolist()
+            self[key] = [tuple(self.packed[l][i, : c + 1] for l, c in enumerate(self.dims)) for i in idx]
+        else:
+            raise KeyError(key)
+        return self[key]
+
+
+class PoseTrackerRefiner:
+    base_default_config = dict(
+        layer_indices=None,
+        min_matches_db=10,
+        num_dbs=1,
+        min_track_length=3,
+        min_points_opt=10,
+        point_selection="all",
+        average_observations=False,
+        normalize_descriptors=True,
+        compute_uncertainty=True,
+    )
+    default_config = dict(
+        multiscale=None,
+        filter_covisibility=False,
+        do_pose_approximation=False,
+        do_inlier_ranking=False,
+    )
+    tracker = None
+
+    def __init__(self, device, optimizer: List[PixTrackOptimizer], model3d: Model3D,
+                 feature_extractor: PixTrackFeatureExtractor, paths, conf, global_descriptors=None):
+        self.global_descriptors = global_descriptors
+        self.reference_scale = 1.0
+        self.choices = {}
+        self.features_dicts: Dict = {}
+        self.device = torch.device(device)
+        self.optimizer = optimizer
+        self.model3d = model3d
+        self.feature_extractor = feature_extractor
+        self.paths = paths
+        self.conf = merge(self.base_default_config, self.default_config, conf or {})
+        assert self.conf.normalize_descriptors and self.conf.compute_uncertainty
+        self.query_mask: Optional[torch.Tensor] = None  # device uint8 [H,W], set by the tracker
+        self._p3d_cache: Dict[int, Tuple[List[int], torch.Tensor]] = {}
+        self._ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=self.device)
+        self.last_lm = []  # LMResult per image scale of the last refine (costs for the tracker gate)
+
+    # ---- logging hooks (pixloc BaseRefiner) -----------------------------------
+    def log_dense(self, **kwargs):
+        if self.tracker is not None:
+            self.tracker.log_dense(**kwargs)
+
+    def log_optim(self, **kwargs):
+        if self.tracker is not None:
+            self.tracker.log_optim_done(**kwargs)
+
+    # ---- reference-image points ------------------------------------------------
+    def _points_of(self, dbids: Sequence[int]) -> Tuple[List[int], torch.Tensor]:
+        """3-D points observed by dbids[0] with a long enough track (static per ref id)."""
+        key = int(dbids[0])
+        if key not in self._p3d_cache:
+            p3did_to_dbids = self.model3d.get_p3did_to_dbids(
+                list(dbids), None, None, self.conf.point_selection, self.conf.min_track_length)
+            dbid_to_p3dids = self.model3d.get_dbid_to_p3dids(p3did_to_dbids)
+            p3dids = dbid_to_p3dids.get(dbids[0], [])
+            xyz = np.array([self.model3d.points3D[p].xyz for p in p3dids], dtype=np.float32).reshape(-1, 3)
+            self._p3d_cache[key] = (p3dids, torch.from_numpy(xyz).to(self.device))
+        return self._p3d_cache[key]
+
+    # ---- dense features ----------------------------------------------------------
+    def dense_feature_extraction(self, image, name: str, image_scale: int = 1, mask=None, normalize=False):
+        """-> (HWC maps [h,w,cstride] x3 with the confidence as channel C, scales)."""
+        maps, scales = self.feature_extractor.extract_packed(image, image_scale, mask, normalize)
+        if self.tracker is not None and getattr(self.tracker, "debug", 0) >= 2:
+            feats = [m[..., :c].permute(2, 0, 1) for m, c in zip(maps, OUTPUT_DIMS)]
+            weight = [m[..., c : c + 1].permute(2, 0, 1) for m, c in zip(maps, OUTPUT_DIMS)]
+            self.log_dense(name=name, image=image, image_scale=image_scale, features=feats, scales=scales,
+                           weight=weight)
+        return maps, scales
+
+    # ---- sparse reference observations --------------------------------------------
+    def interp_sparse_observations(self, feature_maps: List[torch.Tensor], feature_scales, image_id: int,
+                                   p3dids: List[int], pose: Optional[Pose] = None,
+                                   p3d: Optional[torch.Tensor] = None) -> SparseReferenceFeatures:
+        image = self.model3d.dbs[image_id]
+        camera = Camera.from_colmap(self.model3d.cameras[image.camera_id]).scale(self.reference_scale)
+        T_w2cam = Pose.from_colmap(image) if pose is None else pose
+        if p3d is None:
+            p3d = torch.from_numpy(np.array([self.model3d.points3D[p].xyz for p in p3dids], np.float32)).to(self.device)
+        n = int(p3d.shape[0])
+        L = _lib.lib()
+        arr = (_lib.SampleLevel * len(feature_maps))()
+        outs = []
+        for i, (fm, sc) in enumerate(zip(feature_maps, feature_scales)):
+            h, w, cs = fm.shape
+            out = torch.empty(n, cs, device=self.device, dtype=torch.float32)
+            outs.append(out)
+            cam_l = camera.scale(sc)
+            arr[i].fmap, arr[i].out = fm.data_ptr(), out.data_ptr()
+            arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, OUTPUT_DIMS[i], cs
+            arr[i].cam[:] = cam_l.as10().tolist()
+            arr[i].ndist = int(cam_l._data.shape[-1] - 6)
+        T12 = T_w2cam.as12().detach().to(self.device, torch.float32).contiguous()
+        valid = torch.empty(n, dtype=torch.uint8, device=self.device)
+        pad = self.optimizer[0].interpolator.pad
+        _lib.check(L.pxt_sample_sparse(p3d.data_ptr(), n, T12.data_ptr(), arr, len(feature_maps), int(pad), 1,
+                                       valid.data_ptr(), _lib.stream_ptr(self.device)), "pxt_sample_sparse")
+        return SparseReferenceFeatures(outs, valid, list(p3dids), p3d, OUTPUT_DIMS)
+
+    def extract_reference_features(self, dbids, pose: Optional[Pose] = None, reference_image=None):
+        multiscales = self.conf.multiscale or [1]
+        if reference_image is None:
+            raise NotImplementedError("static reference images on disk (r5/r7 mode) are out of scope: "
+                                      "r9 always passes the NeRF render (pixloc_tracker_r9.py:157-159)")
+        p3dids, p3d = self._points_of(dbids)
+        ref_img = self.model3d.dbs[dbids[0]]
+        if pose is None:
+            pose = Pose.from_Rt(ref_img.qvec2rotmat(), ref_img.tvec)
+        features = {}
+        for image_scale in multiscales:
+            maps, scales = self.dense_feature_extraction(reference_image, ref_img.name, image_scale)
+            features[str(image_scale)] = self.interp_sparse_observations(maps, scales, dbids[0], p3dids, pose, p3d)
+        return features
+
+    # ---- refinement ------------------------------------------------------------------
+    def refine(self, qname: str, qcamera: Camera, pose_init: Pose, dbids: List[int], loc=None,
+               image_query=None, pose: Optional[Pose] = None, reference_images=None, dynamic_id=None) -> Dict:
+        fail = {"success": False, "T_init": pose_init, "dbids": dbids}
+        p3dids, _ = self._points_of(dbids)
+        if len(p3dids) < self.conf.min_points_opt:
+            logger.debug("Not enough valid 3D points to optimize")
+            return fail
+        ret = self.refine_query_pose(qname, qcamera, pose_init, dbids, self.conf.multiscale, image_query, pose,
+                                     reference_images, dynamic_id)
+        return {**ret, "dbids": dbids}
+
+    def refine_query_pose(self, qname, qcamera: Camera, T_init: Pose, dbids, multiscales=None, image_query=None,
+                          pose=None, reference_images=None, dynamic_id=None) -> Dict:
+        if multiscales is None:
+            multiscales = [1]
+        if reference_images is not None:
+            raise NotImplementedError("raw reference images per query (r6/r8 mode) are out of scope")
+        if dynamic_id is None:
+            raise NotImplementedError("reference_features.h5 (static references) is a 'next' row (SURVEY 8f)")
+        features_dict = self.features_dicts[dynamic_id]["features"]
+        self.last_lm = []
+        ret = {"success": False, "T_init": T_init}
+        for image_scale in multiscales:
+            ref = features_dict[str(image_scale)]
+            maps_q, scales_q = self.dense_feature_extraction(image_query, qname, image_scale, mask=self.query_mask,
+                                                             normalize=True)
+            # Infrastructure errors (HIP, spin bound) raise PxtError out of here; only the
+            # algorithmic failure becomes success=False (SURVEY 8b error convention; the
+            # reference's bare `except:` at :259-265 would have hidden both).
+            ret = self.refine_pose_using_features(maps_q, scales_q, qcamera, T_init, ref)
+            if not ret["success"]:
+                logger.info(f"Optimization failed for query {qname}")
+                break
+            T_init = ret["T_refined"]
+        return ret
+
+    def refine_pose_using_features(self, features_query: List[torch.Tensor], scales_query, qcamera: Camera,
+                                   T_init: Pose, ref: SparseReferenceFeatures) -> Dict:
+        """pixloc BaseRefiner.refine_pose_using_features on packed buffers: coarse -> fine,
+        optimizer[level] per level, all levels in one kernel launch."""
+        n_levels = len(features_query)
+        order = list(reversed(range(n_levels)))
+        packs = []
+        for level in order:
+            opt = self.optimizer[level] if isinstance(self.optimizer, (list, tuple)) else self.optimizer
+            packs.append(LevelPack(features_query[level], ref.packed[level], OUTPUT_DIMS[level],
+                                   qcamera.scale(scales_query[level]), opt.dampingnet()))
+        opt0 = self.optimizer[order[0]] if isinstance(self.optimizer, (list, tuple)) else self.optimizer
+        res = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws,
+                                              mask=ref.valid).result()
+        self.last_lm.append(res)
+        # replay the iteration log into the tracker hooks, level by level
+        T_level = T_init
+        for k, level in enumerate(order):
+            if res.iters[k] == 0:
+                break
+            opt = self.optimizer[level] if isinstance(self.optimizer, (list, tuple)) else self.optimizer
+            opt.replay_log(res, k, T_level)
+            T_level = Pose(res.log[k, res.iters[k] - 1, 8:20].clone())
+            self.log_optim(i=k, T_opt=T_level, fail=res.failed, level=level, p3d=None, p3d_ids=ref.p3dids_all,
+                           T_init=T_init, camera=packs[k].camera)
+        ret = {"T_init": T_init}
+        if res.failed:
+            return {**ret, "success": False}
+        T_opt = Pose(res.T.as12().cpu().double())
+        dR, dt = (Pose(T_init.as12().cpu().double()).inv() @ T_opt).magnitude()
+        return {**ret, "success": True, "T_refined": T_opt, "diff_R": dR.item(), "diff_t": dt.item()}
+
+
+class Paths(dict):
+    """pixloc.utils.data.Paths stand-in: attribute dict + add_prefixes."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def add_prefixes(self, dataset, dumps, results):
+        from pathlib import Path
+
+        out = Paths(self)
+        for k in ("query_images", "reference_images", "reference_sfm", "query_list"):
+            if out.get(k) is not None:
+                out[k] = Path(dataset) / out[k] if k in ("query_images",) else Path(dumps) / out[k]
+        out["dumps"] = Path(dumps)
+        out["results_dir"] = Path(results)
+        return out
+
+
+class PoseTrackerLocalizer:
+    """Builds model3d + extractor + the three per-level optimizers + refiner
+    (reference pixloc_pose_refiners.py:28-118).  ``experiment`` weights come either from a
+    dict of tensors (``conf["weights"]``: UNet names of pixtrack_amd.unet + "optimizer.{i}.
+    dampingnet.const") or from ``conf["weights_path"]`` (a torch file of that dict)."""
+
+    def __init__(self, paths, conf, device: Optional[torch.device] = None, model3d: Optional[Model3D] = None):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.PxtError("no ROCm device: the tracking path has no CPU implementation")
+            device = torch.device("cuda:0")
+        self.device = torch.device(device)
+        self.model3d = model3d if model3d is not None else Model3D(paths.reference_sfm)
+        self.queries = {}
+        conf = Conf(conf)
+        weights = conf.get("weights")
+        if weights is None:
+            weights = torch.load(conf["weights_path"], map_location="cpu")
+        conf_optim = merge({"num_iters": 100}, conf.get("optimizer", {}))
+        extractor = UNet(weights, self.device)
+        optimizer = []
+        for i in range(3):
+            opt = PixTrackOptimizer(conf_optim, device=self.device)
+            key = f"optimizer.{i}.dampingnet.const"
+            if key in weights:
+                opt.dampingnet.const = torch.as_tensor(weights[key]).float().cpu()
+            optimizer.append(opt)
+        self.paths = paths
+        self.conf = conf
+        self.optimizer = optimizer
+        self.extractor = PixTrackFeatureExtractor(extractor, self.device, conf.get("features", {}).get("preprocessing", {}))
+        self.refiner = PoseTrackerRefiner(self.device, self.optimizer, self.model3d, self.extractor, paths,
+                                          conf.get("refinement", {}))
+        self.logs = None
+
+    def run_query(self, name: str, camera: Camera, pose_init: Pose, reference_images, image_query=None,
+                  pose: Optional[Pose] = None, reference_images_raw=None, dynamic_id=None):
+        loc = None if self.logs is None else self.logs[name]
+        return self.refiner.refine(name, camera, pose_init, reference_images, loc=loc, image_query=image_query,
+                                   pose=pose, reference_images=reference_images_raw, dynamic_id=dynamic_id)

@@ -263,26 +263,172 @@ def make_synthetic_nerf(seed: int = 11, aabb=PREMIER_PROTEIN_AABB, aabb_scale: f
     c3[:3, 32:] = -v
     mlp = np.concatenate([m.astype(np.float16).ravel() for m in (d1, d2, c1, c2, c3)])
 
-    # occupancy: cascade c covers [0.5 - 2^c/2, 0.5 + 2^c/2]^3 with 128^3 cells
+    # occupancy: cascade c covers [0.5 - 2^c/2, 0.5 + 2^c/2]^3 with 128^3 cells.  instant-ngp
+    # marks a cell occupied when density * MIN_STEP > 0.01 (its minimum optical thickness);
+    # density = exp(DENSITY_LOGIT * interp(level-3 indicator)), evaluated here at the 8 corners
+    # of every cell from the same vertex values the renderer interpolates.
+    vol = val.astype(np.float32)  # [res, res, res] indexed [gx, gy, gz]
+
+    def indicator(x_ngp_pts):
+        q = ((x_ngp_pts - scene_lo) / aabb_scale) * scale + 0.5
+        q = np.clip(q, 0.0, res - 1.000001)
+        i0 = np.floor(q).astype(np.int64)
+        f = (q - i0).astype(np.float32)
+        out = np.zeros(q.shape[:-1], np.float32)
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    w = ((f[..., 0] if dx else 1 - f[..., 0]) * (f[..., 1] if dy else 1 - f[..., 1])
+                         * (f[..., 2] if dz else 1 - f[..., 2]))
+                    out += w * vol[i0[..., 0] + dx, i0[..., 1] + dy, i0[..., 2] + dz]
+        return out
+
+    thresh = math.log(0.01 / (math.sqrt(3) / 1024)) / DENSITY_LOGIT - 0.02
     G = 128
     occ_bits = np.zeros(cascades * G**3, np.uint8)
     for c in range(cascades):
         span = 2.0**c
-        cc = (np.arange(G) + 0.5) / G
-        cx, cy, cz = np.meshgrid(cc, cc, cc, indexing="ij")  # x fastest is handled below
-        centres = (np.stack([cx, cy, cz], -1) - 0.5) * span + 0.5
-        cell = span / G
-        # occupied if the shape value anywhere in the cell can exceed the -1 clamp:
-        # |grad(shape)| <= 1/min(r) ; be conservative by one cell diagonal + one level-3 cell
-        lo, hi = np.asarray(aabb[0]), np.asarray(aabb[1])
-        rmin = float(np.min(0.45 * (hi - lo)))
-        margin = (cell * math.sqrt(3) + aabb_scale / scale) / rmin
-        v = shape_value(centres, aabb)
-        o = (SHAPE_SHARPNESS * (v + margin) > -0.8)
-        lin = (np.arange(G)[None, None, :, None] * 0)  # placeholder to keep shapes explicit
+        e = np.arange(G + 1) / G
+        ez, ey, ex = np.meshgrid(e, e, e, indexing="ij")  # corner grid indexed [z, y, x]
+        corners = (np.stack([ex, ey, ez], -1) - 0.5) * span + 0.5
+        ind = indicator(corners.reshape(-1, 3)).reshape(G + 1, G + 1, G + 1)
+        m = ind[:-1, :-1, :-1]
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    m = np.maximum(m, ind[dz:G + dz, dy:G + dy, dx:G + dx])
         # linear index = (z * G + y) * G + x
-        o_zyx = np.transpose(o, (2, 1, 0))
-        occ_bits[c * G**3:(c + 1) * G**3] = o_zyx.ravel().astype(np.uint8)
+        occ_bits[c * G**3:(c + 1) * G**3] = (m > thresh).ravel().astype(np.uint8)
     occupancy = np.packbits(occ_bits, bitorder="little")
     return NerfSnapshot(grid=grid.astype(np.float16), mlp=mlp, occupancy=occupancy, cascades=cascades,
                         aabb_scale=aabb_scale)
+
+
+# ---------------------------------------------------------------------------
+# Full-pipeline synthetic object (BASELINE configs 2-4): NeRF snapshot + SfM model
+# (reference cameras, surface points with tracks) + nerf2sfm + network weights + a
+# ground-truth camera trajectory.  The query frames themselves are NeRF renders at the GT
+# poses; they are produced on the device by `render_query_frames` (setup, not timed).
+# ---------------------------------------------------------------------------
+
+# p_ngp = A p_sfm * 0.33 + 0.5 for the identity-like nerf2sfm below (see sfm_to_nerf_pose
+# followed by instant-ngp's nerf_matrix_to_ngp)
+_A_SFM_TO_NGP = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
+
+
+def ngp_to_sfm_points(p_ngp: np.ndarray) -> np.ndarray:
+    return ((p_ngp - NGP_OFFSET) / NGP_SCALE) @ _A_SFM_TO_NGP  # A^T applied to row vectors
+
+
+def sfm_to_ngp_points(p_sfm: np.ndarray) -> np.ndarray:
+    return (p_sfm @ _A_SFM_TO_NGP.T) * NGP_SCALE + NGP_OFFSET
+
+
+def surface_points(rng, n: int, aabb, level: float = 0.12):
+    """Points (and outward normals) on the iso-surface shape_value == level, ngp coordinates."""
+    lo, hi = np.asarray(aabb[0], float), np.asarray(aabb[1], float)
+    c, r = 0.5 * (lo + hi), 0.45 * (hi - lo)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    q = u / r  # direction in normalised coordinates
+    s = (1.0 - level) / (np.sum(np.abs(q) ** 4, axis=1) ** 0.25)
+    p = c + u * s[:, None]
+    qn = (p - c) / r
+    nrm = np.sign(qn) * np.abs(qn) ** 3 / r
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return p, nrm
+
+
+def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, n_frames: int = 200,
+                         aabb=PREMIER_PROTEIN_AABB, n_points: int = 5600, n_refs: int = 16,
+                         step_deg: float = 0.5, jitter_deg: float = 0.3, jitter_trans: float = 0.003,
+                         unet_seed: int = 7):
+    """Returns the dict PixLocPoseTrackerR9(assets=...) consumes plus 'gt_poses' [(R, t)] and
+    'query_camera' (COLMAP dict).  All seeded."""
+    from .model3d import Model3D
+    from .unet import make_synthetic_unet_weights
+    from .utils.colmap import ColmapCamera, ColmapImage, ColmapPoint3D, rotmat2qvec
+
+    rng = np.random.default_rng(seed)
+    snapshot = make_synthetic_nerf(seed + 10, aabb)
+    nerf2sfm = {"up": np.array([0.0, 0.0, 1.0]), "centroid": np.zeros(3), "avglen": 3.0, "totp": np.zeros(3),
+                "R": np.eye(4)}
+    p_ngp, n_ngp = surface_points(rng, n_points, aabb)
+    p_sfm = ngp_to_sfm_points(p_ngp)
+    n_sfm = n_ngp @ _A_SFM_TO_NGP  # rotation only
+    lo, hi = np.asarray(aabb[0], float), np.asarray(aabb[1], float)
+    center = ngp_to_sfm_points((0.5 * (lo + hi))[None])[0]
+    extent = float(np.max(hi - lo)) / NGP_SCALE
+    f_q = 1.2 * max(width, height)
+    dist = f_q * extent / (0.5 * min(width, height))
+
+    # reference (mapping) cameras: one COLMAP camera of twice the query resolution
+    Wr, Hr = 2 * width, 2 * height
+    cameras = {1: ColmapCamera(1, "SIMPLE_RADIAL", Wr, Hr, np.array([1.2 * max(Wr, Hr), Wr / 2.0, Hr / 2.0, 0.0]))}
+    up_axis = np.array([0.0, 0.0, 1.0])  # sfm z is the object's long axis (ngp -y ... +y)
+    images, obs = {}, {i: [] for i in range(n_points)}
+    fr = 1.2 * max(Wr, Hr)
+    for k in range(n_refs):
+        az = 2 * math.pi * k / n_refs
+        el = math.radians(15.0 * math.sin(3 * az))
+        d = np.array([math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)])
+        eye = center + d * dist
+        Rk, tk = look_at_pose(eye, center, up=up_axis)
+        pc = p_sfm @ Rk.T + tk
+        facing = np.einsum("ij,ij->i", n_sfm, eye[None] - p_sfm) > 0.15 * np.linalg.norm(eye[None] - p_sfm, axis=1)
+        uv = pc[:, :2] / pc[:, 2:3] * fr + np.array([Wr / 2.0, Hr / 2.0])
+        vis = facing & (pc[:, 2] > 0) & (uv[:, 0] > 2) & (uv[:, 0] < Wr - 2) & (uv[:, 1] > 2) & (uv[:, 1] < Hr - 2)
+        ids = np.nonzero(vis)[0]
+        for j, pid in enumerate(ids):
+            obs[int(pid)].append((k + 1, j))
+        images[k + 1] = ColmapImage(k + 1, rotmat2qvec(Rk), tk, 1, f"mapping/{k + 1:04d}.png", uv[ids], ids.astype(np.int64))
+    points3D = {}
+    for pid in range(n_points):
+        tr = obs[pid]
+        points3D[pid] = ColmapPoint3D(pid, p_sfm[pid], np.array([128, 128, 128]), 0.5,
+                                      np.array([a for a, _ in tr], np.int64), np.array([b for _, b in tr], np.int64))
+    model3d = Model3D(model=(cameras, images, points3D))
+
+    weights = make_synthetic_unet_weights(unet_seed)
+    wrng = np.random.default_rng(seed + 20)
+    for i in range(3):  # damping constants of the three per-level optimizers (absent checkpoint)
+        weights[f"optimizer.{i}.dampingnet.const"] = torch.from_numpy(wrng.uniform(-2.5, -1.5, size=6)).float()
+
+    # ground-truth trajectory: orbit about the object's long axis from reference image 1,
+    # plus a small per-frame random twist (<= ~1 deg, <= ~5e-3 units: tracking-sized motion)
+    R0, t0 = images[1].qvec2rotmat(), images[1].tvec
+    gt = []
+    Rc, tc = perturb_pose(R0, t0, rng, 0.8, 0.004, center)
+    for i in range(n_frames):
+        gt.append((Rc.copy(), tc.copy()))
+        dR = rodrigues(up_axis * math.radians(step_deg))
+        Rn = Rc @ dR
+        tn = Rc @ (center - dR @ center) + tc
+        Rc, tc = perturb_pose(Rn, tn, rng, jitter_deg * rng.uniform(), jitter_trans * rng.uniform(), center)
+    qcam = dict(model="SIMPLE_RADIAL", width=width, height=height,
+                params=np.array([f_q, width / 2.0, height / 2.0, 0.0]))
+    return dict(model3d=model3d, nerf2sfm=nerf2sfm, snapshot=snapshot, weights=weights, covis=None, aabb=aabb,
+                upright_ref_img="mapping/0001.png", gt_poses=gt, query_camera=qcam, center=center,
+                width=width, height=height)
+
+
+def render_query_frames(assets, testbed, noise_sigma: float = 2.0, seed: int = 5):
+    """Query frames = NeRF renders at the GT poses (+ Gaussian noise, sigma in 8-bit levels),
+    float32 HWC 0..255 device tensors, as ImageIterator would hand them over.  Setup only."""
+    from .utils.ingp_utils import sfm_to_nerf_pose
+    from .visualization.run_vis_on_poses import get_nerf_image_device, rgba_to_u8
+
+    cam = Camera.from_colmap(assets["query_camera"])
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    frames = []
+    for (Rg, tg) in assets["gt_poses"]:
+        wIc = np.eye(4)
+        wIc[:3, :3], wIc[:3, 3] = Rg, tg
+        nerf_pose = sfm_to_nerf_pose(assets["nerf2sfm"], np.linalg.inv(wIc))
+        u8 = rgba_to_u8(get_nerf_image_device(testbed, nerf_pose, cam), 0.0)
+        img = u8.float()
+        if noise_sigma > 0:
+            noise = torch.randn(img.shape, generator=g) * noise_sigma
+            img = (img + noise.to(img.device)).clamp_(0, 255).round_()
+        frames.append(img.contiguous())
+    return frames

@@ -1,0 +1,61 @@
+"""NeRF <-> SfM frame maps and Testbed construction (reference
+pixtrack/utils/ingp_utils.py:16-83).  ``nerf2sfm.pkl`` = {up, centroid, avglen, totp, R}
+written by colmap2ingp (reference pixtrack/utils/colmap2ingp.py:356-362)."""
+from __future__ import annotations
+
+import pickle as pkl
+
+import numpy as np
+
+_FLIP_YZ = np.diag([1.0, -1.0, -1.0, 1.0])
+
+
+def load_nerf2sfm(path):
+    with open(path, "rb") as f:
+        return pkl.load(f)
+
+
+def initialize_ingp(snapshot_path, aabb, background=None, device=None):
+    """Same render settings as reference ingp_utils.py:22-44, on the HIP Testbed."""
+    from ..ngp import Testbed, TestbedMode
+
+    if background is None:
+        background = [255, 255, 255, 0.0]
+    testbed = Testbed(TestbedMode.Nerf, device=device)
+    testbed.nerf.sharpen = 0.0
+    testbed.load_snapshot(snapshot_path)
+    testbed.nerf.render_with_camera_distortion = True
+    testbed.background_color = background
+    testbed.snap_to_pixel_centers = True
+    testbed.nerf.rendering_min_transmittance = 1e-7
+    testbed.fov_axis = 0
+    testbed.shall_train = False
+    testbed.render_aabb.min = aabb[0]
+    testbed.render_aabb.max = aabb[1]
+    testbed.exposure = 0.0
+    return testbed
+
+
+def sfm_to_nerf_pose(nerf2sfm, sfm_pose: np.ndarray) -> np.ndarray:
+    """camera-in-world (SfM) 4x4 -> NeRF transform_matrix convention: camera y/z flip,
+    world x<->y swap and z flip, recentre, scale to 'nerf size', align up, recentre on the
+    cameras' centre of attention."""
+    p = np.asarray(sfm_pose, dtype=np.float64) @ _FLIP_YZ
+    p = p[[1, 0, 2, 3], :]
+    p[2, :] *= -1
+    p[0:3, 3] -= nerf2sfm["centroid"]
+    p[0:3, 3] *= 3.0 / nerf2sfm["avglen"]
+    p = nerf2sfm["R"] @ p
+    p[0:3, 3] -= nerf2sfm["totp"]
+    return p
+
+
+def nerf_to_sfm_pose(nerf2sfm, nerf_pose: np.ndarray) -> np.ndarray:
+    p = np.array(nerf_pose, dtype=np.float64)
+    p[0:3, 3] += nerf2sfm["totp"]
+    p = np.linalg.inv(nerf2sfm["R"]) @ p
+    p[0:3, 3] /= 3.0 / nerf2sfm["avglen"]
+    p[0:3, 3] += nerf2sfm["centroid"]
+    p[2, :] *= -1
+    p = p[[1, 0, 2, 3], :]
+    return p @ _FLIP_YZ

@@ -111,3 +111,36 @@ def test_background_and_miss(device, snap):
     tb.background_color = [0.5, 0.25, 1.0, 1.0]
     out = tb.render_device(24, 16, 2, True).cpu().numpy()
     assert np.allclose(out, np.array([0.5, 0.25, 1.0, 1.0], np.float32))
+
+
+def test_network_query_matches_oracle(device, snap):
+    """KAT-7: hash-grid encode + both MLPs at given points (dense random weights so every
+    row/column of every layer matters; an A=I style structured test would hide transposes)."""
+    import ctypes as C
+
+    from pixtrack_amd import _lib
+    from pixtrack_amd.ngp import NerfSnapshot
+
+    rg = np.random.default_rng(5)
+    shapes = dict(d1=(64, 32), d2=(16, 64), c1=(64, 32), c2=(64, 64), c3=(16, 64))
+    rnd = {k: (rg.normal(size=v) * (2.0 / v[1]) ** 0.5).astype(np.float16) for k, v in shapes.items()}
+    s2 = NerfSnapshot(grid=snap.grid, mlp=np.concatenate([rnd[k].ravel() for k in ("d1", "d2", "c1", "c2", "c3")]),
+                      occupancy=snap.occupancy)
+    n = 1000  # not a multiple of 64: the tail wave is partially filled
+    lo, hi = np.array(PREMIER_PROTEIN_AABB)
+    x = rg.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rg.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tb = Testbed(device=device)
+    tb.load_snapshot(s2)
+    out = torch.zeros(n, 4, device=device)
+    xd, dd = torch.from_numpy(x).to(device), torch.from_numpy(d).to(device)
+    _lib.check(_lib.lib().pxt_ngp_query(tb._ctx, xd.data_ptr(), dd.data_ptr(), n, out.data_ptr(),
+                                        _lib.stream_ptr(device)), "pxt_ngp_query")
+    torch.cuda.synchronize()
+    m = NO.NgpModel(grid=s2.grid, mlp=s2.mlp_dict(), occupancy=s2.occupancy, cascades=3, aabb_scale=4.0)
+    unit = ((x - np.float32(0.5 - 2.0)) * np.float32(0.25)).astype(np.float32)
+    den, rgb = NO.network(m, unit, d)
+    got = out.cpu().numpy()
+    assert np.abs(got[:, 0] - np.log(den)).max() < 5e-3
+    assert np.abs(got[:, 1:] - rgb).max() < 5e-3
