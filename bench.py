@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Headline benchmark: tracked frames/s at 640x480, full per-frame hot path
+(NeRF template render + depth mask -> UNet pyramids (reference + query) -> sparse sampling ->
+fused LM refinement) on the synthetic premier_protein-style object of BASELINE.json configs[1].
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 : one sequence on cuda:0.  N > 1 (launched by torch.distributed.run, one rank per GPU):
+every rank tracks its OWN independently seeded sequence (frames of one video are sequentially
+dependent), no communication in the loop, one RCCL all_gather of the pose
+records at the end -> "weak" scaling.  A step = one tracked frame; query frames are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
+
+
+class StageTimer:
+    """HIP-event timing of a wrapped callable on torch's current stream (the stream every
+    pxt_* launch of this process uses)."""
+
+    def __init__(self):
+        self.events = {}
+        self.enabled = False
+
+    def wrap(self, obj, attr, name):
+        fn = getattr(obj, attr)
+
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.events.setdefault(name, []).append((e0, e1))
+            return out
+
+        setattr(obj, attr, timed)
+
+    def totals_ms(self):
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.events.items()}
+
+
+def cpu_baseline(assets, frames, start_pose, ref_id):
+    """The CPU oracle ("port" of the reference PyTorch-CPU path) on a bounded sample of the
+    same workload: LM + both UNets at full 640x480; the two NeRF renders at 1/8 resolution
+    per axis with the same field of view (1/64 of the rays, same samples per ray), scaled by 64."""
+    from oracle import frame_oracle as FO
+    from oracle import lm_oracle as LO
+    from oracle import ngp_oracle as NO
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    R, t = start_pose
+    img = frames[1].cpu().numpy()
+    tm = {}
+    # full-size stages except the NeRF: hand the oracle a pre-made mask / reference render path
+    small = dict(assets)
+    qc = dict(assets["query_camera"])
+    s = 8
+    qc_small = dict(model=qc["model"], width=qc["width"] // s, height=qc["height"] // s,
+                    params=np.array([qc["params"][0] / s, qc["params"][1] / s, qc["params"][2] / s, qc["params"][3]]))
+    ngp = FO.ngp_model(assets["snapshot"])
+    cam_small = FO.colmap_camera_to_pix(qc_small)
+    t0 = time.perf_counter()
+    NO.render(ngp, FO.nerf_view(assets["snapshot"], assets["nerf2sfm"], assets["aabb"], R, t, cam_small, 1))
+    NO.render(ngp, FO.nerf_view(assets["snapshot"], assets["nerf2sfm"], assets["aabb"], R, t, cam_small, 0))
+    t_nerf = (time.perf_counter() - t0) * s * s
+    # UNets + sampling + LM at full resolution, reference image = the query itself (same cost)
+    model3d = assets["model3d"]
+    im = model3d.dbs[ref_id]
+    ids = [int(p) for p in im.point3D_ids if p != -1 and len(model3d.points3D[int(p)].image_ids) >= 3]
+    p3d = torch.from_numpy(np.array([model3d.points3D[p].xyz for p in ids], np.float32))
+    from oracle import unet_oracle as UO
+
+    w = assets["weights"]
+    t0 = time.perf_counter()
+    f_ref, sc_ref, c_ref = UO.extractor_call(w, img, 1)
+    f_q, sc_q, c_q = UO.extractor_call(w, img, 1)
+    t_unet = time.perf_counter() - t0
+    maps_ref = [torch.cat([f, c], 0) for f, c in zip(f_ref, c_ref)]
+    maps_q = [torch.cat([f, c], 0) for f, c in zip(f_q, c_q)]
+    c1 = model3d.cameras[1]
+    ref_cam_full = FO.colmap_camera_to_pix(dict(width=c1.width, height=c1.height, params=c1.params))
+    Rt, tt = torch.from_numpy(np.asarray(R, np.float64)), torch.from_numpy(np.asarray(t, np.float64))
+    lambdas = [LO.damping_lambda(w[f"optimizer.{i}.dampingnet.const"].float()) for i in range(3)]
+    t0 = time.perf_counter()
+    obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, 0.5, Rt.float(), tt.float(), p3d, 1)
+    LO.refine_pose_using_features(maps_q, sc_q, FO.colmap_camera_to_pix(qc), Rt, tt, obs, p3d, lambdas, LO.LMConf(),
+                                  mask=valid)
+    t_lm = time.perf_counter() - t0
+    total = t_nerf + t_unet + t_lm
+    return {
+        "value": round(1.0 / total, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"1 frame: UNet x2 + sparse sampling + LM at full 640x480 ({t_unet:.2f}s + {t_lm:.2f}s); NeRF depth+RGB "
+                   f"renders at 80x60 (1/64 of the rays, same fov/spp) x64 = {t_nerf:.1f}s; numpy/torch-CPU oracle"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pixtrack_amd import parallel
+    from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+    from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
+
+    rank, ws, local_rank = parallel.init_from_env("nccl")
+    assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n_frames = args.warmup + args.steps
+    unit = parallel.shard_units(ws, rank, ws)[0]  # one sequence per rank, seeds 1002, 1003, ...
+    assets = make_tracking_assets(seed=1002 + unit, width=args.width, height=args.height, n_frames=n_frames)
+    tracker = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets)
+    frames = render_query_frames(assets, tracker.testbed)
+    names = [f"{i:06d}.png" for i in range(n_frames)]
+    torch.cuda.synchronize()
+
+    timer = StageTimer()
+    timer.wrap(tracker.testbed, "render_device", "nerf_render")
+    timer.wrap(tracker.localizer.extractor.model, "forward_packed", "unet")
+    timer.wrap(tracker.localizer.refiner, "refine_pose_using_features", "lm")
+    timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")
+    tracker.testbed.stats_accum = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    for i in range(args.warmup):
+        tracker.run_single_frame((names[i], frames[i]))
+    torch.cuda.synchronize()
+    start_pose = tracker.pose.numpy()
+    tracker.testbed.stats_accum.zero_()
+    n_renders0 = tracker.testbed.n_renders
+    timer.enabled = True
+
+    if ws > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_frames):
+        tracker.run_single_frame((names[i], frames[i]))
+    torch.cuda.synchronize()
+    if ws > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+
+    records = parallel.pack_pose_records(tracker.pose_history, names[args.warmup:])
+    gathered = parallel.gather_pose_records(records.to(dev), dev)  # the one collective (RCCL)
+    n_ok = int(sum(float(g[:, 12].sum()) for g in gathered))
+    total_frames = sum(g.shape[0] for g in gathered)
+
+    if rank != 0:
+        return
+    stage = timer.totals_ms()
+    stats = tracker.testbed.stats_accum.cpu().tolist()
+    n_renders = tracker.testbed.n_renders - n_renders0
+    nerf_ms, nerf_calls = stage.get("nerf_render", (0.0, 1))
+    avg_launch_ms = nerf_ms / max(nerf_calls, 1)
+    samples_per_launch = stats[0] / max(n_renders, 1)
+    achieved = samples_per_launch * NERF_BYTES_PER_SAMPLE / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # accuracy vs the synthetic ground truth over the timed frames (reported, not the metric)
+    rot_err, tr_err = [], []
+    for i in range(args.warmup, n_frames):
+        ret = tracker.pose_history[names[i]]
+        if ret.get("success"):
+            Rr, tt = ret["T_refined"].numpy()
+            Rg, tg = assets["gt_poses"][i]
+            c = np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1)
+            rot_err.append(float(np.arccos(c)))
+            tr_err.append(float(np.linalg.norm(tt - tg)))
+    unet_ms, unet_calls = stage.get("unet", (0.0, 1))
+    if unet_ms > nerf_ms:
+        # the UNet chain dominates: report its MFMA roofline instead (conv3x3_mfma_kernel)
+        from pixtrack_amd.unet import conv_layer_dims
+
+        hs = [(args.height >> i, args.width >> i) for i in range(5)]
+        res = [0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 3, 2, 1, 0]
+        flop = sum(2 * 9 * cin * cout * hs[r][0] * hs[r][1] for (cin, cout), r in zip(conv_layer_dims(), res))
+        avg_ms = unet_ms / max(unet_calls, 1)
+        ach = flop / (avg_ms * 1e-3) / 1e12
+        roofline = {"kernel": "conv3x3_mfma_kernel (UNet chain, 17 convs)", "bound": "mfma", "achieved": round(ach, 2),
+                    "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": flop}
+    else:
+        roofline = {"kernel": "ngp_render_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_launch_ms, 4), "samples_per_launch": round(samples_per_launch, 1),
+                    "bytes_per_sample": NERF_BYTES_PER_SAMPLE}
+    out = {
+        "metric": "tracked frames/sec at 640x480 (full NeRF render + UNet + LM loop)",
+        "value": round(total_frames / elapsed, 3),
+        "unit": "frames/s",
+        "n_gpus": ws,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "fp16 storage / fp32 accumulate (UNet, NeRF MLPs); fp32 (LM)",
+        "data": "synthetic (seeded hash-grid NeRF, He-init UNet, NeRF-rendered query frames + noise)",
+        "config": {"workload": "configs[1]: premier_protein-style object, 640x480, full NeRF render + UNet + LM loop, "
+                               "1 sequence per GPU", "width": args.width, "height": args.height, "spp": 8,
+                   "n_points_per_reference": int(tracker.localizer.refiner._points_of(tracker.reference_ids)[1].shape[0]),
+                   "parallelism": f"{ws} independent sequence(s), 1 process/GPU, final RCCL all_gather of poses"},
+        "tracked_ok": n_ok,
+        "frames_total": total_frames,
+        "mean_rot_err_vs_gt_rad": round(float(np.mean(rot_err)), 6) if rot_err else None,
+        "mean_trans_err_vs_gt": round(float(np.mean(tr_err)), 6) if tr_err else None,
+        "stage_ms_per_frame": {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and ws == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(assets, frames, start_pose, tracker.reference_ids[0])
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {e!r}"}
+    else:
+        out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "timed on rank 0 at N=1 only"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for ONE tracked frame: the policy of
+PixLocPoseTrackerR9.refine (reference pixtrack/pose_trackers/pixloc_tracker_r9.py:216-275)
+composed from the three stage oracles -- NeRF reference/depth renders (ngp_oracle), UNet
+pyramids (unet_oracle), sparse sampling + LM (lm_oracle).
+
+PARITY UNPINNED (see the stage oracles' headers).  This is "the reference PyTorch-CPU
+path" that BASELINE.json asks to be timed next to the GPU path; bench.py times it on a
+bounded sample, the `-m gpu` frame test runs it at a small resolution.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lm_oracle as LO
+from . import ngp_oracle as NO
+from . import unet_oracle as UO
+
+FLIP_YZ = np.diag([1.0, -1.0, -1.0, 1.0])
+
+
+def sfm_to_nerf_pose(nerf2sfm, cIw):
+    """reference pixtrack/utils/ingp_utils.py:47-63."""
+    p = np.asarray(cIw, np.float64) @ FLIP_YZ
+    p = p[[1, 0, 2, 3], :]
+    p[2, :] *= -1
+    p[0:3, 3] -= nerf2sfm["centroid"]
+    p[0:3, 3] *= 3.0 / nerf2sfm["avglen"]
+    p = nerf2sfm["R"] @ p
+    p[0:3, 3] -= nerf2sfm["totp"]
+    return p
+
+
+def colmap_camera_to_pix(cam) -> torch.Tensor:
+    """pixloc Camera.from_colmap for SIMPLE_RADIAL: (w,h,f,f,cx-.5,cy-.5,k1,0)."""
+    f, cx, cy, k1 = [float(x) for x in cam["params"]]
+    return torch.tensor([cam["width"], cam["height"], f, f, cx - 0.5, cy - 0.5, k1, 0.0], dtype=torch.float32)
+
+
+def ngp_model(snapshot) -> NO.NgpModel:
+    return NO.NgpModel(grid=snapshot.grid, mlp=snapshot.mlp_dict(), occupancy=snapshot.occupancy,
+                       cascades=snapshot.cascades, aabb_scale=snapshot.aabb_scale, cone_angle=snapshot.cone_angle,
+                       depth_scale=1.0 / snapshot.scale)
+
+
+def nerf_view(snapshot, nerf2sfm, aabb, R, t, cam: torch.Tensor, mode: int, spp: int = 8) -> NO.View:
+    """get_nerf_image's camera set-up (run_vis_on_poses.py:28-47): fov from fx on x."""
+    wIc = np.eye(4)
+    wIc[:3, :3], wIc[:3, 3] = R, t
+    nerf_pose = sfm_to_nerf_pose(nerf2sfm, np.linalg.inv(wIc))
+    W, H = int(cam[0]), int(cam[1])
+    fov = math.degrees(math.atan(W / (float(cam[2]) * 2)) * 2)
+    focal = float(np.float32(0.5 * W / math.tan(0.5 * math.radians(fov))))
+    return NO.View(cam=NO.nerf_matrix_to_ngp(nerf_pose, snapshot.scale, snapshot.offset), focal=focal, width=W,
+                   height=H, spp=spp, k1=snapshot.k1, aabb_min=tuple(aabb[0]), aabb_max=tuple(aabb[1]), mode=mode)
+
+
+def to_u8(rgba: np.ndarray) -> np.ndarray:
+    """run_vis_on_poses.py:52-54 with alpha_thresh 0: (rgb * 255).astype(uint8) (wraps)."""
+    return ((rgba[..., :3] * np.float32(255.0)).astype(np.int64) & 255).astype(np.uint8)
+
+
+def morph5(img: np.ndarray, erode: bool) -> np.ndarray:
+    H, W = img.shape
+    pad = np.full((H + 4, W + 4), 255 if erode else 0, dtype=np.uint8)
+    pad[2:-2, 2:-2] = img
+    stack = [pad[dy:dy + H, dx:dx + W] for dy in range(5) for dx in range(5)]
+    return (np.min if erode else np.max)(np.stack(stack, 0), axis=0)
+
+
+def depth_mask(depth_rgba: np.ndarray) -> np.ndarray:
+    """get_mask (pixloc_tracker_r9.py:207-214): != 0, erode 5x5 x1, dilate 5x5 x5."""
+    m = (to_u8(depth_rgba)[..., 0] != 0).astype(np.uint8)
+    m = morph5(m, True)
+    for _ in range(5):
+        m = morph5(m, False)
+    return m
+
+
+def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndarray, ref_id: int,
+                multiscale=(1,), use_mask: bool = True, lm_conf: Optional[LO.LMConf] = None,
+                timings: Optional[Dict[str, float]] = None, spp: int = 8):
+    """One frame from pose (R, t): returns dict(success, R, t, cost, mask).  ``query_image``
+    float32 HWC 0..255.  Follows refine(): mask -> dynamic reference -> per scale
+    {UNet(ref) -> sparse sample, UNet(query) -> LM over 3 levels coarse->fine}."""
+    tm = timings if timings is not None else {}
+
+    def tick(name, t0):
+        tm[name] = tm.get(name, 0.0) + (time.perf_counter() - t0)
+
+    lm_conf = lm_conf or LO.LMConf()
+    model3d, snapshot, nerf2sfm, aabb, weights = (assets["model3d"], assets["snapshot"], assets["nerf2sfm"],
+                                                  assets["aabb"], assets["weights"])
+    ngp = ngp_model(snapshot)
+    qcam = colmap_camera_to_pix(assets["query_camera"])
+    mask = None
+    img = np.asarray(query_image, np.float32)
+    if use_mask:
+        t0 = time.perf_counter()
+        depth = NO.render(ngp, nerf_view(snapshot, nerf2sfm, aabb, R, t, qcam, 1, spp))
+        mask = depth_mask(depth)
+        img = img * mask[..., None].astype(np.float32)
+        tick("nerf_depth", t0)
+    # dynamic reference render with SfM camera 1 scaled by reference_scale 0.5
+    c1 = model3d.cameras[1]
+    ref_cam_full = colmap_camera_to_pix(dict(width=c1.width, height=c1.height, params=c1.params))
+    ref_cam = LO.camera_scale(ref_cam_full, 0.5)
+    t0 = time.perf_counter()
+    ref_rgba = NO.render(ngp, nerf_view(snapshot, nerf2sfm, aabb, R, t, ref_cam, 0, spp))
+    ref_img = to_u8(ref_rgba).astype(np.float32)
+    tick("nerf_ref", t0)
+    # points observed by the reference image with track length >= 3
+    im = model3d.dbs[ref_id]
+    ids = [int(p) for p in im.point3D_ids if p != -1 and len(model3d.points3D[int(p)].image_ids) >= 3]
+    p3d = torch.from_numpy(np.array([model3d.points3D[p].xyz for p in ids], np.float32))
+    lambdas = [LO.damping_lambda(weights[f"optimizer.{i}.dampingnet.const"].float()) for i in range(3)]
+    Rt, tt = torch.from_numpy(np.asarray(R, np.float64)), torch.from_numpy(np.asarray(t, np.float64))
+    log = LO.LMLog()
+    ret = {"success": False}
+    for scale in multiscale:
+        t0 = time.perf_counter()
+        f_ref, sc_ref, c_ref = UO.extractor_call(weights, ref_img, scale)
+        maps_ref = [torch.cat([f, c], 0) for f, c in zip(f_ref, c_ref)]
+        tick("unet_ref", t0)
+        t0 = time.perf_counter()
+        obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, 0.5, Rt.float(), tt.float(), p3d,
+                                                   lm_conf.pad)
+        tick("sample", t0)
+        t0 = time.perf_counter()
+        f_q, sc_q, c_q = UO.extractor_call(weights, img, scale)
+        maps_q = [torch.cat([f, c], 0) for f, c in zip(f_q, c_q)]
+        tick("unet_query", t0)
+        t0 = time.perf_counter()
+        ret = LO.refine_pose_using_features(maps_q, sc_q, qcam, Rt, tt, obs, p3d, lambdas, lm_conf, mask=valid, log=log)
+        tick("lm", t0)
+        if not ret["success"]:
+            break
+        Rt, tt = ret["R"], ret["t"]
+    cost = float(np.mean([c[-1] for c in log.costs if len(c)])) if log.costs else float("nan")
+    return dict(success=ret["success"], R=ret.get("R"), t=ret.get("t"), cost=cost, mask=mask, iters=log.num_iters,
+                n_points=len(ids))

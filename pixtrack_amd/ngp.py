@@ -150,7 +150,8 @@ class Testbed:
         self._ctx = None
         self._snap: Optional[NerfSnapshot] = None
         self._stats = None
-        self.last_stats = None
+        self.stats_accum = None
+        self.n_renders = 0
 
     # class-attribute style access used by pixtrack: testbed.render_mode.Depth
     RenderMode = RenderMode
@@ -209,7 +210,7 @@ class Testbed:
         if not self.snap_to_pixel_centers:
             raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
         out = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
-        stats = None
+        stats = self.stats_accum  # running totals across launches when set (bench)
         if collect_stats:
             stats = torch.zeros(4, dtype=torch.int64, device=self.device)
         v = self._view(width, height, spp)
@@ -218,6 +219,7 @@ class Testbed:
                                       _lib.stream_ptr(self.device)), "pxt_ngp_render")
         if collect_stats:
             self._stats = stats
+        self.n_renders += 1
         return out
 
     def render(self, width: int, height: int, spp: int = 8, linear: bool = True) -> np.ndarray:

@@ -1,0 +1,77 @@
+"""Multi-GPU sharding of the tracking workload.
+
+The reference is single-process, single-GPU (pixloc_pose_refiners.py:35-39).  Frames of one
+video are sequentially dependent (frame t starts from frame t-1's pose, mask, reference
+render and cost threshold: pixloc_tracker_r9.py:224-229,258-265), so the unit of parallel
+work is a SEQUENCE (one object / one video / one independently seeded segment).  Units are
+dealt round-robin to ranks, one process per GPU; there is no communication inside the
+tracking loop.  The only collective is the final gather of the per-frame pose records
+(12 pose floats + success + cost = 14 float64 per frame), done with torch.distributed
+(backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+RECORD = 14  # R (9) | t (3) | success | cost
+
+
+def world() -> tuple:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_units(n_units: int, rank: int, world_size: int) -> List[int]:
+    """Static round-robin assignment of sequence indices to ranks."""
+    return list(range(rank, n_units, world_size))
+
+
+def pack_pose_records(history: dict, names: Sequence[str]) -> torch.Tensor:
+    """[n_frames, 14] float64 from a tracker's pose_history."""
+    out = torch.zeros(len(names), RECORD, dtype=torch.float64)
+    for i, n in enumerate(names):
+        ret = history[n]
+        T = ret.get("T_refined", ret["T_init"]) if ret.get("success") else ret["T_init"]
+        out[i, :12] = T.as12().detach().cpu().double()
+        out[i, 12] = 1.0 if ret.get("success") else 0.0
+        out[i, 13] = float(ret.get("cost", float("nan")))
+    return out
+
+
+def gather_pose_records(records: torch.Tensor, device=None) -> List[torch.Tensor]:
+    """All ranks receive every rank's [n_i, 14] records (ragged n_i handled by padding)."""
+    rank, ws = world()
+    if ws == 1:
+        return [records]
+    dev = device if device is not None else records.device
+    n = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(ns, n)
+    nmax = int(max(int(x) for x in ns))
+    pad = torch.zeros(nmax, RECORD, dtype=torch.float64, device=dev)
+    pad[: records.shape[0]] = records.to(dev)
+    outs = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(outs, pad)
+    return [o[: int(k)].cpu() for o, k in zip(outs, ns)]
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    rank, ws = world()
+    if ws == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def init_from_env(backend: str = "nccl"):
+    """torchrun contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1 and not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
+    return int(os.environ.get("RANK", "0")), ws, int(os.environ.get("LOCAL_RANK", "0"))

@@ -110,6 +110,7 @@ class PixLocPoseTrackerR9(PoseTracker):
         self.relocalization_count = 0
         self.success = True
         self.camera = None
+        self.spp = 8  # run_vis_on_poses.py:29
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
 
     # ------------------------------------------------------------------ relocalisation
@@ -153,7 +154,7 @@ class PixLocPoseTrackerR9(PoseTracker):
     def get_reference_image(self, pose) -> torch.Tensor:
         """uint8 [H,W,3] NeRF render at ``pose`` with SfM camera 1 scaled by reference_scale."""
         ref_camera = PixCamera.from_colmap(self.localizer.model3d.cameras[1]).scale(self.reference_scale)
-        rgba = get_nerf_image_device(self.testbed, self._nerf_pose(pose), ref_camera)
+        rgba = get_nerf_image_device(self.testbed, self._nerf_pose(pose), ref_camera, spp=self.spp)
         return rgba_to_u8(rgba, 0.0)
 
     def create_dynamic_reference_image(self, pose):
@@ -184,7 +185,7 @@ class PixLocPoseTrackerR9(PoseTracker):
 
     def get_mask(self, pose) -> torch.Tensor:
         """uint8 [H,W] on the device: depth render != 0, erode 5x5 x1, dilate 5x5 x5."""
-        depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True)
+        depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp)
         H, W = int(depth.shape[0]), int(depth.shape[1])
         mask = torch.empty(H, W, dtype=torch.uint8, device=self.device)
         tmp = torch.empty(2 * H * W, dtype=torch.uint8, device=self.device)
