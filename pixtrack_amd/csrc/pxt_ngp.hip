@@ -25,6 +25,7 @@
 #include "pxt_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -62,6 +63,7 @@ struct NgpParams {
   int W, H, spp, mode;
   float* out;
   unsigned long long* stats;
+  int ablate;  // debug only (PXT_NGP_ABLATE): 1 skip gathers, 2 skip MLPs
 };
 
 __device__ inline float calc_dt(float t, float cone, float lo, float hi) {
@@ -137,7 +139,7 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 #pragma unroll
           for (int l = 0; l < kMaxLevels; ++l) {
             float f0 = 0.f, f1 = 0.f;
-            if (alive && l < P.n_levels) {
+            if (alive && l < P.n_levels && !(P.ablate & 1)) {
               const NgpLevel& Lv = P.lv[l];
               const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
               const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
@@ -180,6 +182,11 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
           xB[1][q] = as_half8(Fhi[4 * q], Fhi[4 * q + 1], Fhi[4 * q + 2], Fhi[4 * q + 3]);
         }
 
+        if (P.ablate & 2) {
+          logit = 10.f + __builtin_bit_cast(float, xB[0][0][0] == (half_t)3.f ? 1u : 0u);
+          rgbv[0] = rgbv[1] = rgbv[2] = 0.5f;
+          return;
+        }
         // ---- density MLP: 32 -> 64 (ReLU) -> 16 ----
         f32x16 h1[2][2];
 #pragma unroll
@@ -629,6 +636,7 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
   P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = v->mode;
   P.out = out_rgba;
   P.stats = (unsigned long long*)stats;
+  { const char* e = getenv("PXT_NGP_ABLATE"); P.ablate = e ? atoi(e) : 0; }
   const int n_tiles = ((v->width + 7) / 8) * ((v->height + 7) / 8);
   int grid = (n_tiles + 3) / 4;
   if (grid > 2048) grid = 2048;

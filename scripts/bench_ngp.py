@@ -14,7 +14,8 @@ def main():
     tb.nerf.rendering_min_transmittance = 1e-7
     tb.render_aabb.min, tb.render_aabb.max = PREMIER_PROTEIN_AABB
     lo, hi = np.array(PREMIER_PROTEIN_AABB); c = 0.5 * (lo + hi)
-    for dist in (1.2, 0.8):
+    import os
+    for dist in (1.69,):
         eye = c + np.array([0.9, 0.5, 0.3]) / np.linalg.norm([0.9, 0.5, 0.3]) * dist
         R, _ = look_at_pose(eye, c, up=np.array([0, 1.0, 0]))
         tb._cam_ngp = np.concatenate([R.T, eye[:, None]], 1)

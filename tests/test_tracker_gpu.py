@@ -1,0 +1,100 @@
+"""One tracked frame end to end (NeRF renders -> mask -> UNets -> sparse sampling -> LM) on
+the HIP path vs the CPU frame oracle on identical inputs, plus the tracker's policy surface.
+Tolerance (BASELINE.json): final pose within 1e-3 rad / 1e-3 units of the CPU path."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frame_oracle as FO
+from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
+from pixtrack_amd.utils.pose_utils import geodesic_distance_for_rotations
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tracked(device):
+    assets = make_tracking_assets(seed=1011, width=128, height=96, n_frames=4, n_points=3000)
+    tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=1, device=device, assets=assets)
+    tr.spp = 2
+    frames = render_query_frames(assets, tr.testbed)
+    states = []
+    for i, f in enumerate(frames):
+        before = None if tr.pose is None else tr.pose.numpy()
+        ref_before = list(tr.reference_ids)
+        tr.run_single_frame((f"{i:06d}.png", f))
+        states.append((before, ref_before, tr.pose.numpy(), tr.success))
+    return assets, tr, frames, states
+
+
+def test_cold_start_frame_matches_oracle(tracked):
+    assets, tr, frames, states = tracked
+    ref = assets["model3d"].dbs[1]
+    want = FO.track_frame(assets, ref.qvec2rotmat(), ref.tvec, frames[0].cpu().numpy(), 1, multiscale=(4, 1),
+                          use_mask=False, spp=2)
+    ret = tr.pose_history["000000.png"]
+    assert ret["success"] and want["success"]
+    R, t = ret["T_refined"].numpy()
+    assert geodesic_distance_for_rotations(R, want["R"].numpy()) < 1e-3
+    assert np.linalg.norm(t - want["t"].numpy()) < 1e-3
+    assert ret["cost"] == pytest.approx(want["cost"], rel=0.03)
+    assert tr.cost_threshold == pytest.approx(1.1 * ret["cost"])
+
+
+def test_masked_frame_matches_oracle(tracked):
+    assets, tr, frames, states = tracked
+    (R0, t0), ref_ids, _, ok = states[1]
+    assert ok
+    want = FO.track_frame(assets, R0, t0, frames[1].cpu().numpy(), ref_ids[0], multiscale=(1,), use_mask=True, spp=2)
+    ret = tr.pose_history["000001.png"]
+    R, t = ret["T_refined"].numpy()
+    assert geodesic_distance_for_rotations(R, want["R"].numpy()) < 1e-3
+    assert np.linalg.norm(t - want["t"].numpy()) < 1e-3
+    assert ret["cost"] == pytest.approx(want["cost"], rel=0.03)
+    # the device mask equals the cv2-semantics mask of the oracle (a few edge pixels may flip
+    # where the composited depth sits within float noise of 1/255)
+    tr.localizer.refiner.query_mask = None
+    saved = tr.pose
+    from pixtrack_amd.geometry import Pose
+    tr.pose = Pose.from_Rt(R0, t0)
+    mask = tr.get_mask(tr.pose).cpu().numpy()
+    tr.pose = saved
+    assert (mask != want["mask"]).mean() < 2e-3 and 0.02 < mask.mean() < 0.9
+
+
+def test_tracking_follows_ground_truth_and_history(tracked):
+    assets, tr, frames, states = tracked
+    for i, (_, _, (R, t), ok) in enumerate(states):
+        assert ok
+        Rg, tg = assets["gt_poses"][i]
+        assert geodesic_distance_for_rotations(R, Rg) < 2e-2 and np.linalg.norm(t - tg) < 2e-2
+    assert tr.misses == len(frames) - 1 and tr.hits == 0  # THRESH = 0: never a cache hit
+    assert set(tr.pose_history) == {f"{i:06d}.png" for i in range(len(frames))}
+    ret = tr.pose_history["000002.png"]
+    for k in ("success", "T_init", "T_refined", "diff_R", "diff_t", "dbids", "camera", "reference_ids", "query_path"):
+        assert k in ret
+    # poses.pkl / trackers.pkl payloads pickle
+    blob = pickle.dumps(tr.pose_history)
+    back = pickle.loads(blob)
+    assert np.allclose(back["000002.png"]["T_refined"].numpy()[0], ret["T_refined"].numpy()[0])
+    dbg = pickle.loads(pickle.dumps(tr.pose_tracker_history))
+    costs = dbg["000001.png"].costs
+    assert len(costs) == 3 and all(len(c) >= 1 for c in costs)  # one list per level, scale [1]
+    assert len(dbg["000000.png"].costs) == 6  # cold start: scales [4, 1] x 3 levels
+
+
+def test_failed_frame_keeps_pose_and_drops_mask(tracked):
+    assets, tr, frames, states = tracked
+    pose_before = tr.pose.numpy()
+    old_thr = tr.cost_threshold
+    tr.cost_threshold = 0.0  # force the gate to reject
+    ok = tr.refine(("forced_fail.png", frames[-1]))
+    assert not ok and not tr.success
+    assert np.array_equal(tr.pose.numpy()[0], pose_before[0])
+    tr.cost_threshold = old_thr
+    ok = tr.refine(("after_fail.png", frames[-1]))  # Appendix D.3: no mask after a failed frame
+    assert tr.localizer.refiner.query_mask is None
+    assert ok
