@@ -121,6 +121,7 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
     p3d = torch.from_numpy(np.array([model3d.points3D[p].xyz for p in ids], np.float32))
     lambdas = [LO.damping_lambda(weights[f"optimizer.{i}.dampingnet.const"].float()) for i in range(3)]
     Rt, tt = torch.from_numpy(np.asarray(R, np.float64)), torch.from_numpy(np.asarray(t, np.float64))
+    R_ref, t_ref = Rt.float(), tt.float()  # the reference is rendered AND sampled at the frame's start pose
     log = LO.LMLog()
     ret = {"success": False}
     for scale in multiscale:
@@ -129,8 +130,7 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
         maps_ref = [torch.cat([f, c], 0) for f, c in zip(f_ref, c_ref)]
         tick("unet_ref", t0)
         t0 = time.perf_counter()
-        obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, 0.5, Rt.float(), tt.float(), p3d,
-                                                   lm_conf.pad)
+        obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, 0.5, R_ref, t_ref, p3d, lm_conf.pad)
         tick("sample", t0)
         t0 = time.perf_counter()
         f_q, sc_q, c_q = UO.extractor_call(weights, img, scale)
@@ -144,4 +144,4 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
         Rt, tt = ret["R"], ret["t"]
     cost = float(np.mean([c[-1] for c in log.costs if len(c)])) if log.costs else float("nan")
     return dict(success=ret["success"], R=ret.get("R"), t=ret.get("t"), cost=cost, mask=mask, iters=log.num_iters,
-                n_points=len(ids))
+                n_points=len(ids), log=log)
