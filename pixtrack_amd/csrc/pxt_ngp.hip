@@ -63,7 +63,6 @@ struct NgpParams {
   int W, H, spp, mode;
   float* out;
   unsigned long long* stats;
-  int ablate;  // debug only (PXT_NGP_ABLATE): 1 skip gathers, 2 skip MLPs
 };
 
 __device__ inline float calc_dt(float t, float cone, float lo, float hi) {
@@ -128,50 +127,44 @@ __device__ inline half8 relu_pack8(const f32x16& a, int base, bool relu) {
   return r;
 }
 
-// Hash-grid encode + both MLPs for the wave's 64 samples (lane = sample).  Must be called
-// by all 64 lanes (MFMA); `alive` only gates the gathers.  ux,uy,uz: position in [0,1]^3.
-__device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, bool alive, float ux,
-                                float uy, float uz, const unsigned* shB0, const unsigned* shB1,
-                                float& logit, float* rgbv) {
-        // ---- hash grid encode (lane = sample) ----
-        unsigned Flo[8], Fhi[8];
-        {
+// One hash-grid level at a warped position in [0,1]^3 -> packed (f0, f1) fp16 pair.
+__device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, const NgpLevel& Lv, float ux,
+                                            float uy, float uz) {
+  const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
+  const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+  const float ax = qx - fx, ay = qy - fy, az = qz - fz;
+  const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
+  unsigned vals[8];
 #pragma unroll
-          for (int l = 0; l < kMaxLevels; ++l) {
-            float f0 = 0.f, f1 = 0.f;
-            if (alive && l < P.n_levels && !(P.ablate & 1)) {
-              const NgpLevel& Lv = P.lv[l];
-              const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
-              const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-              const float ax = qx - fx, ay = qy - fy, az = qz - fz;
-              const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
-              unsigned vals[8];
+  for (int c = 0; c < 8; ++c) {
+    const unsigned cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
+    unsigned idx;
+    if (Lv.hashed)
+      idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+    else
+      idx = cx + cy * Lv.res + cz * Lv.res * Lv.res;
+    idx = idx % Lv.size + Lv.offset;
+    vals[c] = grid[idx];
+  }
+  float f0 = 0.f, f1 = 0.f;
 #pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                const unsigned cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
-                unsigned idx;
-                if (Lv.hashed)
-                  idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
-                else
-                  idx = cx + cy * Lv.res + cz * Lv.res * Lv.res;
-                idx = idx % Lv.size + Lv.offset;
-                vals[c] = P.grid[idx];
-              }
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                float w = 1.0f;
-                w = w * ((c & 1) ? ax : (1.0f - ax));
-                w = w * ((c & 2) ? ay : (1.0f - ay));
-                w = w * ((c & 4) ? az : (1.0f - az));
-                const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
-                f0 += w * (float)hv[0];
-                f1 += w * (float)hv[1];
-              }
-            }
-            const unsigned pk = pack_h2(f0, f1);
-            if (l < 8) Flo[l] = pk; else Fhi[l - 8] = pk;
-          }
-        }
+  for (int c = 0; c < 8; ++c) {
+    float w = 1.0f;
+    w = w * ((c & 1) ? ax : (1.0f - ax));
+    w = w * ((c & 2) ? ay : (1.0f - ay));
+    w = w * ((c & 4) ? az : (1.0f - az));
+    const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
+    f0 += w * (float)hv[0];
+    f1 += w * (float)hv[1];
+  }
+  return pack_h2(f0, f1);
+}
+
+// Both MLPs for the wave's 64 samples (lane = sample).  Flo/Fhi: this lane's 32 encoded
+// features as 16 packed dwords (levels 0..7 / 8..15).  All 64 lanes must call (MFMA).
+template <bool DEPTH_ONLY>
+__device__ inline void ngp_mlp(const half8* s_w, int lane, unsigned* Flo, unsigned* Fhi, const unsigned* shB0,
+                               const unsigned* shB1, float& logit, float* rgbv) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) swap32(Flo[i], Fhi[i]);
         // B fragments of the feature input: [cb][q]
@@ -180,12 +173,6 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
         for (int q = 0; q < 2; ++q) {
           xB[0][q] = as_half8(Flo[4 * q], Flo[4 * q + 1], Flo[4 * q + 2], Flo[4 * q + 3]);
           xB[1][q] = as_half8(Fhi[4 * q], Fhi[4 * q + 1], Fhi[4 * q + 2], Fhi[4 * q + 3]);
-        }
-
-        if (P.ablate & 2) {
-          logit = 10.f + __builtin_bit_cast(float, xB[0][0][0] == (half_t)3.f ? 1u : 0u);
-          rgbv[0] = rgbv[1] = rgbv[2] = 0.5f;
-          return;
         }
         // ---- density MLP: 32 -> 64 (ReLU) -> 16 ----
         f32x16 h1[2][2];
@@ -208,6 +195,13 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
             a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD2 + q) * 64 + lane],
                                                        relu_pack8(h1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
           dout[cb] = a;
+        }
+        unsigned r0 = __builtin_bit_cast(unsigned, dout[0][0]), r1 = __builtin_bit_cast(unsigned, dout[1][0]);
+        swap32(r0, r1);
+        logit = __builtin_bit_cast(float, r0);
+        if (DEPTH_ONLY) {
+          rgbv[0] = rgbv[1] = rgbv[2] = 0.f;
+          return;
         }
         // ---- colour MLP: [16 density outputs | 16 SH] -> 64 -> 64 -> 16 ----
         f32x16 c1[2][2];
@@ -245,10 +239,7 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
                                                        relu_pack8(c2[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
           cout[cb] = a;
         }
-        // rows 0..3 of column block cb sit in the low half; bring block 1 to the high lanes
-        unsigned r0 = __builtin_bit_cast(unsigned, dout[0][0]), r1 = __builtin_bit_cast(unsigned, dout[1][0]);
-        swap32(r0, r1);
-        logit = __builtin_bit_cast(float, r0);
+        // rows 0..3 of column block cb sit in the low half; block 1 is brought to the high lanes.
         // The activation is applied BEFORE the cross-lane move: v_permlane32_swap reading a
         // register an MFMA is still writing returned stale rows (regs > 0) on gfx950/ROCm 7.2;
         // a VALU op in between gets the MFMA->VALU wait states the compiler does model.
@@ -261,194 +252,418 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
         }
 }
 
-__global__ __launch_bounds__(256) void ngp_render_kernel(const NgpParams P) {
+
+// Fused encode + MLPs (lane = sample) used by the straggler kernel and the point query.
+template <bool DEPTH_ONLY>
+__device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, bool alive, float ux,
+                                float uy, float uz, const unsigned* shB0, const unsigned* shB1,
+                                float& logit, float* rgbv) {
+  unsigned Flo[8], Fhi[8];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    unsigned pk = 0u;
+    if (alive && l < P.n_levels) pk = ngp_encode_level(P.grid, P.lv[l], ux, uy, uz);
+    if (l < 8) Flo[l] = pk; else Fhi[l - 8] = pk;
+  }
+  ngp_mlp<DEPTH_ONLY>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+}
+
+// ===========================================================================
+// Wavefront renderer.
+//
+// The hash table (26 MB) does not fit one XCD's 4 MB L2, so a kernel in which every wave
+// walks all 16 levels for its own samples re-fetches table lines from the Infinity Cache at
+// ~3 KB of 64/128-B lines per 512 algorithmic bytes (measured: 7 ms per 640x480x8 render, the
+// gathers 6 of them).  Here a render is a short chain of kernels over a COMPACT list of live
+// rays, and the encoder runs LEVEL-MAJOR: blocks are dispatched in level order, so at any
+// moment the whole chip gathers from one ~2 MB level, which every XCD's L2 holds.
+//
+//   init     : ray per (pixel, spp); rays that hit the render box enter the live list
+//   round r  : march   -- each live ray collects its next K occupied lattice samples
+//              encode  -- level-major gathers -> feat[level][sample] (fp16 x2)
+//              shade   -- 8 rays x K=8 samples per wave: MLPs on MFMA, in-order compositing,
+//                         early-out; surviving rays are re-compacted for round r+1
+//   tail     : after kRounds rounds the few remaining rays (grazing the soft shell) finish in
+//              a fused per-ray loop (march + encode + MLP per step)
+//   resolve  : fixed-order mean over spp + background
+//
+// Every ray performs exactly the arithmetic of oracle/ngp_oracle.py on exactly the same
+// samples; samples a round evaluates past a ray's termination point are discarded.
+// ===========================================================================
+constexpr int kK = 8;          // samples per ray per round
+constexpr int kRounds = 3;     // wavefront rounds before the tail kernel
+constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
+
+struct Ray {
+  float o[3], d[3], idir[3];
+  float tmin, tmax, zdot;
+  bool hit;
+};
+
+__device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
+  Ray r;
+  const float u = ((float)px + 0.5f) / (float)P.W, vv = ((float)py + 0.5f) / (float)P.H;
+  float dxn = (u - 0.5f) * (float)P.W / P.focal, dyn = (vv - 0.5f) * (float)P.H / P.focal;
+  if (P.k1 != 0.f) {
+    float xu = dxn, yu = dyn;
+    for (int it = 0; it < 8; ++it) {
+      const float r2 = xu * xu + yu * yu;
+      const float s = 1.0f + P.k1 * r2;
+      xu = dxn / s;
+      yu = dyn / s;
+    }
+    dxn = xu;
+    dyn = yu;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    r.d[a] = (dxn * P.cam[4 * a + 0] + dyn * P.cam[4 * a + 1]) + P.cam[4 * a + 2];
+    r.o[a] = P.cam[4 * a + 3];
+  }
+  const float nrm = sqrtf((r.d[0] * r.d[0] + r.d[1] * r.d[1]) + r.d[2] * r.d[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    r.d[a] = r.d[a] / nrm;
+    r.idir[a] = 1.0f / r.d[a];
+  }
+  const float fn = sqrtf((P.cam[2] * P.cam[2] + P.cam[6] * P.cam[6]) + P.cam[10] * P.cam[10]);
+  r.zdot = (r.d[0] * (P.cam[2] / fn) + r.d[1] * (P.cam[6] / fn)) + r.d[2] * (P.cam[10] / fn);
+  const float half_s = P.aabb_scale * 0.5f;
+  r.tmin = -INFINITY;
+  r.tmax = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = fmaxf(P.lo[a], 0.5f - half_s), hi = fminf(P.hi[a], 0.5f + half_s);
+    const float t0 = (lo - r.o[a]) * r.idir[a], t1 = (hi - r.o[a]) * r.idir[a];
+    r.tmin = fmaxf(r.tmin, fminf(t0, t1));
+    r.tmax = fminf(r.tmax, fmaxf(t0, t1));
+  }
+  r.hit = r.tmax > fmaxf(r.tmin, 0.f);
+  return r;
+}
+
+// Advances t along the dt lattice to the next sample whose occupancy cell is set.
+// Returns false when the ray leaves the render box first.  pos/dt describe the sample.
+__device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, float* pos, float& dt) {
+  for (int guard = 0; guard < 1000000; ++guard) {
+    if (t >= r.tmax) return false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pos[a] = r.o[a] + t * r.d[a];
+    dt = calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+    int e;
+    frexpf(dt * (float)kGrid, &e);
+    const int mip = min(P.cascades - 1, max(e, mip_from_pos(pos[0], pos[1], pos[2], P.cascades)));
+    const float msc = ldexpf(1.0f, -mip);
+    int ci[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float p = (pos[a] - 0.5f) * msc + 0.5f;
+      ci[a] = (int)floorf(p * (float)kGrid);
+      inside = inside && ci[a] >= 0 && ci[a] < kGrid;
+      ci[a] = min(max(ci[a], 0), kGrid - 1);
+    }
+    const unsigned lin = (unsigned)((ci[2] * kGrid + ci[1]) * kGrid + ci[0]) +
+                         (unsigned)mip * (unsigned)(kGrid * kGrid * kGrid);
+    if (inside && ((P.occ[lin >> 3] >> (lin & 7u)) & 1u)) return true;
+    // advance_to_next_voxel: step in dt increments past the cell border
+    const float res = ldexpf((float)kGrid, -mip);
+    float tm = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float p = res * (pos[a] - 0.5f);
+      const float sg = r.d[a] > 0.f ? 1.f : (r.d[a] < 0.f ? -1.f : 0.f);
+      const float tx = (floorf(p + 0.5f + 0.5f * sg) - p) * r.idir[a];
+      if (r.d[a] != 0.f) tm = fminf(tm, tx);
+    }
+    const float t_target = t + fmaxf(tm / res, 0.f);
+    do {
+      t = t + calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+    } while (t < t_target);
+  }
+  return false;
+}
+
+struct RayState {  // SoA, indexed by compact slot; two copies ping-pong between rounds
+  unsigned* rid;   // spp_index * W*H + pixel
+  float* t;        // next lattice position
+  float* T;        // transmittance so far
+  float4* acc;     // premultiplied colour (or depth) + alpha so far
+};
+
+struct NgpWork {
+  RayState st[2];
+  int* counters;       // [(kRounds + 2) * kCtrStride]: live rays entering round r
+  float4* spos;        // [slot * kK + k] = (x, y, z, dt); dt == 0 marks "no sample"
+  float* st_t;         // t of each sample (depth mode)
+  unsigned* feat;      // [level][sample] packed fp16 pair
+  uint8_t* exhausted;  // per slot: the ray left the box during this round's march
+  float4* sppbuf;      // [spp][H][W] finished rays
+  size_t feat_stride;  // samples per level plane
+};
+
+__device__ inline void sh_fragments(const float* d, unsigned* shB0, unsigned* shB1) {
+  float sh[16];
+  sh4_eval(d[0], d[1], d[2], sh);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    shB0[i] = pack_h2(sh[2 * i], sh[2 * i + 1]);
+    shB1[i] = pack_h2(sh[8 + 2 * i], sh[8 + 2 * i + 1]);
+    swap32(shB0[i], shB1[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const NgpWork Wk) {
+  const int wh = P.W * P.H;
+  const long long total = (long long)wh * P.spp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int s = (int)(i / wh), pix = (int)(i % wh);
+    const Ray r = make_ray(P, pix % P.W, pix / P.W);
+    Wk.sppbuf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!r.hit) continue;
+    float t = fmaxf(r.tmin, 0.f) + 1e-6f;
+    unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
+    t = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+    const int slot = atomicAdd(Wk.counters, 1);
+    Wk.st[0].rid[slot] = (unsigned)i;
+    Wk.st[0].t[slot] = t;
+    Wk.st[0].T[slot] = 1.f;
+    Wk.st[0].acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  const int n = Wk.counters[round * kCtrStride];
+  const RayState& S = Wk.st[round & 1];
+  const int wh = P.W * P.H;
+  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
+    const int pix = (int)(S.rid[slot] % (unsigned)wh);
+    const Ray r = make_ray(P, pix % P.W, pix / P.W);
+    float t = S.t[slot];
+    bool out = false;
+    for (int k = 0; k < kK; ++k) {
+      float pos[3], dt = 0.f;
+      const bool found = !out && next_sample(P, r, t, pos, dt);
+      const size_t si = (size_t)slot * kK + k;
+      if (found) {
+        Wk.spos[si] = make_float4(pos[0], pos[1], pos[2], dt);
+        Wk.st_t[si] = t;
+        t = t + dt;
+      } else {
+        out = true;
+        Wk.spos[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    S.t[slot] = t;
+    Wk.exhausted[slot] = out ? 1 : 0;
+  }
+}
+
+// Level-major encode: work item = (level, chunk of 256 samples), items ordered by level.
+__global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  const int n = Wk.counters[round * kCtrStride];
+  const long long ns = (long long)n * kK;
+  const long long chunks = (ns + 255) / 256;
+  const float half_s = P.aabb_scale * 0.5f;
+  const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
+  for (long long item = blockIdx.x; item < chunks * P.n_levels; item += gridDim.x) {
+    const int l = (int)(item / chunks);
+    const long long s = (item % chunks) * 256 + threadIdx.x;
+    if (s >= ns) continue;
+    const float4 sp = Wk.spos[s];
+    unsigned pk = 0u;
+    if (sp.w != 0.f)
+      pk = ngp_encode_level(P.grid, P.lv[l], (sp.x - scene_lo) * inv_s, (sp.y - scene_lo) * inv_s,
+                            (sp.z - scene_lo) * inv_s);
+    Wk.feat[(size_t)l * Wk.feat_stride + s] = pk;
+  }
+}
+
+// Shared by the shade and tail kernels: close a finished ray.
+__device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, bool terminated) {
+  if (terminated) {
+    acc.x /= acc.w; acc.y /= acc.w; acc.z /= acc.w; acc.w = 1.0f;
+  }
+  Wk.sppbuf[rid] = acc;
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
   __syncthreads();
-
+  const int n = Wk.counters[round * kCtrStride];
+  const RayState& S = Wk.st[round & 1];
+  const RayState& Sn = Wk.st[(round + 1) & 1];
+  int* next_count = Wk.counters + (round + 1) * kCtrStride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tiles_x = (P.W + 7) / 8, tiles_y = (P.H + 7) / 8;
-  const int n_tiles = tiles_x * tiles_y;
-  const float half_s = P.aabb_scale * 0.5f;
-  const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
-  unsigned long long n_samples = 0, n_batches = 0, n_hit = 0;
-
-  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-    const int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
-    const bool inb = px < P.W && py < P.H;
-    // ---- ray through the pixel centre (oracle generate_rays) ----
-    const float u = ((float)px + 0.5f) / (float)P.W, vv = ((float)py + 0.5f) / (float)P.H;
-    float dxn = (u - 0.5f) * (float)P.W / P.focal, dyn = (vv - 0.5f) * (float)P.H / P.focal;
-    if (P.k1 != 0.f) {
-      float xu = dxn, yu = dyn;
-      for (int it = 0; it < 8; ++it) {
-        const float r2 = xu * xu + yu * yu;
-        const float s = 1.0f + P.k1 * r2;
-        xu = dxn / s;
-        yu = dyn / s;
-      }
-      dxn = xu;
-      dyn = yu;
-    }
-    float d[3], o[3], idir[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      d[a] = (dxn * P.cam[4 * a + 0] + dyn * P.cam[4 * a + 1]) + P.cam[4 * a + 2];
-      o[a] = P.cam[4 * a + 3];
-    }
-    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      d[a] = d[a] / nrm;
-      idir[a] = 1.0f / d[a];
-    }
-    const float fn = sqrtf((P.cam[2] * P.cam[2] + P.cam[6] * P.cam[6]) + P.cam[10] * P.cam[10]);
-    const float zdot = (d[0] * (P.cam[2] / fn) + d[1] * (P.cam[6] / fn)) + d[2] * (P.cam[10] / fn);
-    float tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float lo = fmaxf(P.lo[a], scene_lo), hi = fminf(P.hi[a], 0.5f + half_s);
-      const float t0 = (lo - o[a]) * idir[a], t1 = (hi - o[a]) * idir[a];
-      tmin = fmaxf(tmin, fminf(t0, t1));
-      tmax = fminf(tmax, fmaxf(t0, t1));
-    }
-    const bool hit = inb && (tmax > fmaxf(tmin, 0.f));
-    if (!__any(hit)) {
-      if (inb) {
-        float4 r;
-        r.x = P.bg[0] * P.bg[3]; r.y = P.bg[1] * P.bg[3]; r.z = P.bg[2] * P.bg[3]; r.w = P.bg[3];
-        *(float4*)(P.out + 4 * ((size_t)py * P.W + px)) = r;
-      }
-      continue;
-    }
-    // ---- SH of the view direction, moved into the two 32-column operand halves ----
+  const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
+  const int wh = P.W * P.H;
+  unsigned long long n_samples = 0;
+  const int n_groups = (n + 7) / 8;
+  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+    const int slot = g * 8 + rlane;
+    const bool ray_ok = slot < n;
+    const int sl = ray_ok ? slot : 0;
+    const size_t si = (size_t)sl * kK + k;
+    const float4 sp = Wk.spos[si];
+    const float dt = ray_ok ? sp.w : 0.f;
+    const bool valid = dt != 0.f;
+    const unsigned rid = S.rid[sl];
+    const int pix = (int)(rid % (unsigned)wh);
+    const Ray r = make_ray(P, pix % P.W, pix / P.W);
     unsigned shB0[4], shB1[4];
-    {
-      float sh[16];
-      sh4_eval(d[0], d[1], d[2], sh);
+    sh_fragments(r.d, shB0, shB1);
+    unsigned Flo[8], Fhi[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        shB0[i] = pack_h2(sh[2 * i], sh[2 * i + 1]);          // coeffs 0..7
-        shB1[i] = pack_h2(sh[8 + 2 * i], sh[8 + 2 * i + 1]);  // coeffs 8..15
-        swap32(shB0[i], shB1[i]);
-      }
+    for (int l = 0; l < 8; ++l) {
+      Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
+      Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
     }
-    const unsigned pix_index = (unsigned)py * (unsigned)P.W + (unsigned)px;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_a = 0.f;
-
-    for (int s = 0; s < P.spp; ++s) {
-      float t = fmaxf(tmin, 0.f) + 1e-6f;
-      {
-        unsigned h = pix_index * 747796405u + (unsigned)s * 2891336453u + 1u;
-        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-        const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
-        t = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-      }
-      bool alive = hit;
-      if (alive) ++n_hit;
-      float T = 1.f, cr = 0.f, cg = 0.f, cb_ = 0.f, ca = 0.f;
-
-      while (__any(alive)) {
-        // ---- per-lane search for the next occupied sample ----
-        float pos[3] = {0.5f, 0.5f, 0.5f};
-        float dt = P.dt_lo;
-        if (alive) {
-          bool found = false;
-          for (int guard = 0; guard < 100000; ++guard) {
-            if (t >= tmax) break;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) pos[a] = o[a] + t * d[a];
-            dt = calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-            int e;
-            frexpf(dt * (float)kGrid, &e);
-            const int mip = min(P.cascades - 1, max(e, mip_from_pos(pos[0], pos[1], pos[2], P.cascades)));
-            const float msc = ldexpf(1.0f, -mip);
-            int ci[3];
-            bool inside = true;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              const float p = (pos[a] - 0.5f) * msc + 0.5f;
-              ci[a] = (int)floorf(p * (float)kGrid);
-              inside = inside && ci[a] >= 0 && ci[a] < kGrid;
-              ci[a] = min(max(ci[a], 0), kGrid - 1);
-            }
-            const unsigned lin = (unsigned)((ci[2] * kGrid + ci[1]) * kGrid + ci[0]) +
-                                 (unsigned)mip * (unsigned)(kGrid * kGrid * kGrid);
-            const bool occ = inside && ((P.occ[lin >> 3] >> (lin & 7u)) & 1u);
-            if (occ) {
-              found = true;
-              break;
-            }
-            // advance_to_next_voxel: step in dt increments past the cell border
-            const float res = ldexpf((float)kGrid, -mip);
-            float tm = INFINITY;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              const float p = res * (pos[a] - 0.5f);
-              const float sg = d[a] > 0.f ? 1.f : (d[a] < 0.f ? -1.f : 0.f);
-              const float tx = (floorf(p + 0.5f + 0.5f * sg) - p) * idir[a];
-              if (d[a] != 0.f) tm = fminf(tm, tx);
-            }
-            const float t_target = t + fmaxf(tm / res, 0.f);
-            do {
-              t = t + calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-            } while (t < t_target);
-          }
-          alive = found;
-        }
-        if (!__any(alive)) break;
-        n_batches += 1;
-        if (alive) n_samples += 1;
-
-        float logit, rgbv[3];
-        ngp_eval(P, s_w, lane, alive, (pos[0] - scene_lo) * inv_s, (pos[1] - scene_lo) * inv_s,
-                 (pos[2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
-        // ---- composite ----
-        if (alive) {
-          const float density = expf(logit);
-          if (P.mode == 1) {
-            const float depth = (t * zdot) * P.depth_scale;
-            rgbv[0] = rgbv[1] = rgbv[2] = depth;
-          }
-          const float alpha = 1.0f - expf(-density * dt);
-          const float wgt = alpha * T;
-          cr += wgt * rgbv[0];
-          cg += wgt * rgbv[1];
-          cb_ += wgt * rgbv[2];
-          ca += wgt;
-          T = T * (1.0f - alpha);
-          if (T < P.min_T) {
-            cr /= ca; cg /= ca; cb_ /= ca; ca = 1.0f;
-            alive = false;
-          }
-          t = t + dt;
-        }
-      }
-      acc_r += cr; acc_g += cg; acc_b += cb_; acc_a += ca;
+    float logit, rgbv[3];
+    ngp_mlp<DEPTH>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+    // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
+    const float T0 = S.T[sl];
+    float alpha = 0.f;
+    if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
+    if (DEPTH) {
+      const float depth = (Wk.st_t[si] * r.zdot) * P.depth_scale;
+      rgbv[0] = rgbv[1] = rgbv[2] = depth;
     }
-    if (inb) {
-      const float inv = 1.0f / (float)P.spp;
-      float4 r;
-      r.w = acc_a * inv;
-      r.x = acc_r * inv + P.bg[0] * P.bg[3] * (1.0f - r.w);
-      r.y = acc_g * inv + P.bg[1] * P.bg[3] * (1.0f - r.w);
-      r.z = acc_b * inv + P.bg[2] * P.bg[3] * (1.0f - r.w);
-      r.w = r.w + P.bg[3] * (1.0f - r.w);
-      *(float4*)(P.out + 4 * ((size_t)py * P.W + px)) = r;
+    // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
+    float pinc = 1.0f - alpha;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      const float o = __shfl_up(pinc, m, 8);
+      if (k >= m) pinc = pinc * o;
+    }
+    float pexc = __shfl_up(pinc, 1, 8);
+    if (k == 0) pexc = 1.0f;
+    const float T_before = T0 * pexc, T_after = T0 * pinc;
+    // the first sample after which T drops below the threshold ends the ray (it is included)
+    const bool ends = valid && (T_after < P.min_T);
+    const unsigned long long bal = __ballot(ends);
+    const unsigned grp = (unsigned)((bal >> (rlane * 8)) & 0xFFull);
+    const int k_term = grp ? (__ffs((int)grp) - 1) : 8;
+    const bool contributes = valid && k <= k_term;
+    const float wgt = contributes ? alpha * T_before : 0.f;
+    float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      cr += __shfl_xor(cr, m, 8);
+      cg += __shfl_xor(cg, m, 8);
+      cb += __shfl_xor(cb, m, 8);
+      ca += __shfl_xor(ca, m, 8);
+    }
+    if (contributes) n_samples += 1;
+    // last valid sample's T_after (or the terminating one) is the ray's new transmittance
+    const unsigned long long vb = __ballot(valid);
+    const unsigned vgrp = (unsigned)((vb >> (rlane * 8)) & 0xFFull);
+    const int n_valid = __popc(vgrp);
+    const int k_last = grp ? k_term : n_valid - 1;
+    const float T_new = (k_last >= 0) ? __shfl(T_after, rlane * 8 + max(k_last, 0), 64) : T0;
+    if (k == 0 && ray_ok) {
+      float4 acc = S.acc[slot];
+      acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
+      const bool terminated = grp != 0;
+      const bool exhausted = Wk.exhausted[slot] != 0;
+      if (terminated || exhausted) {
+        finish_ray(Wk, rid, acc, terminated);
+      } else {
+        const int ns = atomicAdd(next_count, 1);
+        Sn.rid[ns] = rid;
+        Sn.t[ns] = S.t[slot];
+        Sn.T[ns] = T_new;
+        Sn.acc[ns] = acc;
+      }
     }
   }
   if (P.stats) {
-    // wave totals -> 3 atomics per wave
-    for (int m = 32; m >= 1; m >>= 1) {
-      n_samples += __shfl_xor(n_samples, m, 64);
-      n_hit += __shfl_xor(n_hit, m, 64);
+    for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
+    if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
+  }
+}
+
+// Stragglers: wave = 64 live rays (lane = ray), fused march + encode + MLP per step until done.
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  __shared__ half8 s_w[kNumFrags * 64];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
+  __syncthreads();
+  const int n = Wk.counters[round * kCtrStride];
+  const RayState& S = Wk.st[round & 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wh = P.W * P.H;
+  const float half_s = P.aabb_scale * 0.5f;
+  const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
+  unsigned long long n_samples = 0;
+  for (int base = (blockIdx.x * 4 + wave) * 64; base < n; base += gridDim.x * 4 * 64) {
+    const int slot = base + lane;
+    bool alive = slot < n;
+    const int sl = alive ? slot : 0;
+    const unsigned rid = S.rid[sl];
+    const int pix = (int)(rid % (unsigned)wh);
+    const Ray r = make_ray(P, pix % P.W, pix / P.W);
+    unsigned shB0[4], shB1[4];
+    sh_fragments(r.d, shB0, shB1);
+    float t = S.t[sl], T = S.T[sl];
+    float4 acc = S.acc[sl];
+    bool terminated = false;
+    while (__any(alive)) {
+      float pos[3] = {0.5f, 0.5f, 0.5f}, dt = P.dt_lo;
+      if (alive) alive = next_sample(P, r, t, pos, dt);
+      if (!__any(alive)) break;
+      float logit, rgbv[3];
+      ngp_eval<DEPTH>(P, s_w, lane, alive, (pos[0] - scene_lo) * inv_s, (pos[1] - scene_lo) * inv_s,
+                      (pos[2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
+      if (alive) {
+        n_samples += 1;
+        if (DEPTH) rgbv[0] = rgbv[1] = rgbv[2] = (t * r.zdot) * P.depth_scale;
+        const float alpha = 1.0f - expf(-expf(logit) * dt);
+        const float wgt = alpha * T;
+        acc.x += wgt * rgbv[0];
+        acc.y += wgt * rgbv[1];
+        acc.z += wgt * rgbv[2];
+        acc.w += wgt;
+        T = T * (1.0f - alpha);
+        if (T < P.min_T) {
+          terminated = true;
+          alive = false;
+        }
+        t = t + dt;
+      }
     }
-    if (lane == 0) {
-      atomicAdd(P.stats + 0, n_samples);
-      atomicAdd(P.stats + 1, n_hit);
-      atomicAdd(P.stats + 2, n_batches);
+    if (slot < n) finish_ray(Wk, rid, acc, terminated);
+  }
+  if (P.stats) {
+    for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
+    if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicAdd(P.stats + 1, (unsigned long long)Wk.counters[0]);
+      atomicAdd(P.stats + 2, (unsigned long long)n);  // rays left for the tail
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk) {
+  const int wh = P.W * P.H;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= wh) return;
+  float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
+  for (int s = 0; s < P.spp; ++s) {
+    const float4 v = Wk.sppbuf[(size_t)s * wh + pix];
+    ar += v.x; ag += v.y; ab += v.z; aa += v.w;
+  }
+  const float inv = 1.0f / (float)P.spp;
+  float4 o;
+  o.w = aa * inv;
+  o.x = ar * inv + P.bg[0] * P.bg[3] * (1.0f - o.w);
+  o.y = ag * inv + P.bg[1] * P.bg[3] * (1.0f - o.w);
+  o.z = ab * inv + P.bg[2] * P.bg[3] * (1.0f - o.w);
+  o.w = o.w + P.bg[3] * (1.0f - o.w);
+  *(float4*)(P.out + 4 * (size_t)pix) = o;
 }
 
 // Network query at caller-given points (unit tests / debugging): out[n] = (logit, r, g, b).
@@ -474,7 +689,7 @@ __global__ __launch_bounds__(256) void ngp_query_kernel(const NgpParams P, const
     swap32(shB0[k], shB1[k]);
   }
   float logit, rgbv[3];
-  ngp_eval(P, s_w, lane, ok, (pos[3 * ii] - scene_lo) * inv_s, (pos[3 * ii + 1] - scene_lo) * inv_s,
+  ngp_eval<false>(P, s_w, lane, ok, (pos[3 * ii] - scene_lo) * inv_s, (pos[3 * ii + 1] - scene_lo) * inv_s,
            (pos[3 * ii + 2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
   if (ok) {
     out[4 * i] = logit;
@@ -492,6 +707,10 @@ struct pxt_ngp {
   pxt::half8* wfrag = nullptr;
   uint8_t* occ = nullptr;
   pxt::NgpLevel lv[pxt::kMaxLevels];
+  // scratch of the wavefront renderer, grown on demand (rays = W*H*spp)
+  void* scratch = nullptr;
+  size_t scratch_rays = 0;
+  pxt::NgpWork work;
 };
 
 using namespace pxt;
@@ -580,6 +799,7 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (ctx->grid) hipFree(ctx->grid);
   if (ctx->wfrag) hipFree(ctx->wfrag);
   if (ctx->occ) hipFree(ctx->occ);
+  if (ctx->scratch) hipFree(ctx->scratch);
   delete ctx;
   return PXT_OK;
 }
@@ -610,23 +830,52 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
   return PXT_OK;
 }
 
+// Carves the wavefront scratch for `rays` rays out of one allocation (grown on demand).
+static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
+  if (ctx->scratch && ctx->scratch_rays >= rays) return PXT_OK;
+  if (ctx->scratch) {
+    hipError_t e0 = hipDeviceSynchronize();
+    (void)e0;
+    (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+  }
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t samples = rays * kK;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
+  size_t o_rid[2], o_t[2], o_T[2], o_acc[2];
+  for (int i = 0; i < 2; ++i) {
+    o_rid[i] = take(rays * 4); o_t[i] = take(rays * 4); o_T[i] = take(rays * 4); o_acc[i] = take(rays * 16);
+  }
+  const size_t o_cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
+  const size_t o_spos = take(samples * 16), o_stt = take(samples * 4);
+  const size_t o_feat = take(samples * 4 * kMaxLevels), o_exh = take(rays), o_spp = take(rays * 16);
+  hipError_t e = hipMalloc(&ctx->scratch, off);
+  if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
+  char* b = (char*)ctx->scratch;
+  NgpWork& W = ctx->work;
+  for (int i = 0; i < 2; ++i) {
+    W.st[i].rid = (unsigned*)(b + o_rid[i]); W.st[i].t = (float*)(b + o_t[i]);
+    W.st[i].T = (float*)(b + o_T[i]); W.st[i].acc = (float4*)(b + o_acc[i]);
+  }
+  W.counters = (int*)(b + o_cnt);
+  W.spos = (float4*)(b + o_spos);
+  W.st_t = (float*)(b + o_stt);
+  W.feat = (unsigned*)(b + o_feat);
+  W.exhausted = (uint8_t*)(b + o_exh);
+  W.sppbuf = (float4*)(b + o_spp);
+  W.feat_stride = samples;
+  ctx->scratch_rays = rays;
+  return PXT_OK;
+}
+
 extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, uint64_t* stats,
                               void* stream) {
   if (!ctx || !v || !out_rgba) return PXT_E_ARG;
   if (v->width < 1 || v->height < 1 || v->spp < 1 || !(v->focal > 0.f)) return PXT_E_ARG;
+  if (v->mode != 0 && v->mode != 1) return PXT_E_ARG;
   NgpParams P;
   fill_model(ctx, P);
-  P.grid = ctx->grid;
-  P.wfrag = ctx->wfrag;
-  P.occ = ctx->occ;
-  for (int l = 0; l < kMaxLevels; ++l) P.lv[l] = ctx->lv[l < ctx->model.n_levels ? l : 0];
-  P.n_levels = ctx->model.n_levels;
-  P.cascades = ctx->model.grid_cascades;
-  P.aabb_scale = ctx->model.aabb_scale;
-  P.cone_angle = ctx->model.cone_angle;
-  P.depth_scale = ctx->model.depth_scale;
-  P.dt_lo = (float)(std::sqrt(3.0) / 1024.0);
-  P.dt_hi = P.dt_lo * (float)(1 << (P.cascades - 1)) * (float)(1024 / kGrid);
   for (int i = 0; i < 12; ++i) P.cam[i] = v->cam[i];
   P.focal = v->focal;
   P.k1 = v->k1;
@@ -636,11 +885,28 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
   P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = v->mode;
   P.out = out_rgba;
   P.stats = (unsigned long long*)stats;
-  { const char* e = getenv("PXT_NGP_ABLATE"); P.ablate = e ? atoi(e) : 0; }
-  const int n_tiles = ((v->width + 7) / 8) * ((v->height + 7) / 8);
-  int grid = (n_tiles + 3) / 4;
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(ngp_render_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
+  const size_t rays = (size_t)v->width * v->height * v->spp;
+  if (rays > 0x7fffffffull / kK) return PXT_E_ARG;
+  int rc = ensure_scratch(ctx, rays);
+  if (rc != PXT_OK) return rc;
+  const NgpWork& Wk = ctx->work;
+  hipStream_t s = (hipStream_t)stream;
+  PXT_HIP_CHECK(hipMemsetAsync(Wk.counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), s));
+  const int wide = 2048;
+  hipLaunchKernelGGL(ngp_init_kernel, dim3(wide), dim3(256), 0, s, P, Wk);
+  for (int r = 0; r < kRounds; ++r) {
+    hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, s, P, Wk, r);
+    hipLaunchKernelGGL(ngp_encode_kernel, dim3(4096), dim3(256), 0, s, P, Wk, r);
+    if (v->mode == 1)
+      hipLaunchKernelGGL(ngp_shade_kernel<true>, dim3(wide), dim3(256), 0, s, P, Wk, r);
+    else
+      hipLaunchKernelGGL(ngp_shade_kernel<false>, dim3(wide), dim3(256), 0, s, P, Wk, r);
+  }
+  if (v->mode == 1)
+    hipLaunchKernelGGL(ngp_tail_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
+  else
+    hipLaunchKernelGGL(ngp_tail_kernel<false>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
+  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s, P, Wk);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }

@@ -134,6 +134,8 @@ class _NerfSettings:
 class Testbed:
     """pyngp.Testbed stand-in (inference only) backed by the HIP renderer."""
 
+    __test__ = False  # not a pytest class
+
     def __init__(self, mode=TestbedMode.Nerf, device: Optional[torch.device] = None):
         self.mode = mode
         self.device = torch.device(device if device is not None else "cuda:0")
@@ -226,7 +228,7 @@ class Testbed:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 
     def read_stats(self):
-        """(samples evaluated, rays that hit the box, 64-wide network batches) of the last
-        render_device(collect_stats=True)."""
+        """(samples composited, rays that hit the box, rays finished by the straggler kernel) of
+        the last render_device(collect_stats=True)."""
         s = self._stats.cpu().tolist()
-        return {"samples": s[0], "rays_hit": s[1], "batches": s[2]}
+        return {"samples": s[0], "rays_hit": s[1], "tail_rays": s[2]}
