@@ -199,6 +199,13 @@ typedef struct {
 int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
                    uint64_t* stats /* device, 4 counters or NULL */, void* stream);
 
+/* Live HIP-event timing of the renderer's dominant kernel (ngp_encode_kernel), for the
+ * roofline line of bench.py.  While enabled, every encode launch is bracketed by an event
+ * pair recorded on the render's own stream.  pxt_ngp_timing_read synchronises those events,
+ * returns their summed duration (ms) and the launch count, and clears the list. */
+int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable);
+int pxt_ngp_timing_read(pxt_ngp* ctx, float* total_ms_host, int32_t* n_launches_host);
+
 /* Network query at caller-given points, ngp coordinates + unit view directions (device
  * float32 [n][3] each): out[n][4] = (density logit, r, g, b).  Same device code as the
  * renderer's per-sample evaluation; used by the parity tests (SURVEY KAT-7). */

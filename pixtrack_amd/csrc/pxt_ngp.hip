@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace pxt {
@@ -711,6 +712,8 @@ struct pxt_ngp {
   void* scratch = nullptr;
   size_t scratch_rays = 0;
   pxt::NgpWork work;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
 
 using namespace pxt;
@@ -896,7 +899,17 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
   hipLaunchKernelGGL(ngp_init_kernel, dim3(wide), dim3(256), 0, s, P, Wk);
   for (int r = 0; r < kRounds; ++r) {
     hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, s, P, Wk, r);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+      PXT_HIP_CHECK(hipEventCreate(&e0));
+      PXT_HIP_CHECK(hipEventCreate(&e1));
+      PXT_HIP_CHECK(hipEventRecord(e0, s));
+    }
     hipLaunchKernelGGL(ngp_encode_kernel, dim3(4096), dim3(256), 0, s, P, Wk, r);
+    if (ctx->timing) {
+      PXT_HIP_CHECK(hipEventRecord(e1, s));
+      ctx->events.emplace_back(e0, e1);
+    }
     if (v->mode == 1)
       hipLaunchKernelGGL(ngp_shade_kernel<true>, dim3(wide), dim3(256), 0, s, P, Wk, r);
     else
@@ -908,5 +921,28 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
     hipLaunchKernelGGL(ngp_tail_kernel<false>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
   hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s, P, Wk);
   PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable) {
+  if (!ctx) return PXT_E_ARG;
+  ctx->timing = enable != 0;
+  return PXT_OK;
+}
+
+extern "C" int pxt_ngp_timing_read(pxt_ngp* ctx, float* total_ms, int32_t* n_launches) {
+  if (!ctx || !total_ms || !n_launches) return PXT_E_ARG;
+  float tot = 0.f;
+  for (auto& ev : ctx->events) {
+    PXT_HIP_CHECK(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    PXT_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+    tot += ms;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  *total_ms = tot;
+  *n_launches = (int32_t)ctx->events.size();
+  ctx->events.clear();
   return PXT_OK;
 }

@@ -16,6 +16,7 @@
 // folded BatchNorm affine) and ReLU are fused into the epilogue.
 #include "pxt_common.h"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -113,7 +114,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
                                                            const half_t* __restrict__ wts,
                                                            const float* __restrict__ bias,
                                                            int Cout, int relu,
-                                                           half_t* __restrict__ out) {
+                                                           half_t* __restrict__ out,
+                                                           float* __restrict__ partial) {
+  // gridDim.z > 1: split-K over the Cin chunks; every z-slice writes its fp32 partial sums to
+  // partial[z][pixel][cout] and splitk_reduce_kernel finishes (fixed order: deterministic).
   constexpr int BNC = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) half_t smem[];
   half_t* s_in = smem;                  // [kHalo][kPix]
@@ -143,7 +147,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
   }
   const int w_off = r31 * kPix + 8 * khalf;
 
-  for (int c0 = 0; c0 < Cin; c0 += kCK) {
+  const int n_chunks = Cin / kCK;
+  const int per_z = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int c_begin = (int)blockIdx.z * per_z * kCK, c_end = min(Cin, c_begin + per_z * kCK);
+  for (int c0 = c_begin; c0 < c_end; c0 += kCK) {
     __syncthreads();
     // stage the 18x18 halo of this channel chunk (zero outside the image)
     for (int i = tid; i < kHalo * 4; i += 256) {
@@ -193,6 +200,18 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
     const int gy = ty0 + ty, gx = tx0 + tx;
     if (gy >= H || gx >= W) continue;
     half_t* dst = out + ((size_t)gy * W + gx) * Cout + co0;
+    if (gridDim.z > 1) {
+      float* pd = partial + (((size_t)blockIdx.z * H + gy) * W + gx) * Cout + co0;
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = 32 * c + 8 * g + 4 * khalf;
+          *(float4*)(pd + co) = make_float4(acc[p][c][4 * g + 0], acc[p][c][4 * g + 1], acc[p][c][4 * g + 2],
+                                            acc[p][c][4 * g + 3]);
+        }
+      continue;
+    }
 #pragma unroll
     for (int c = 0; c < NT; ++c)
 #pragma unroll
@@ -209,6 +228,91 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
         *(half4*)(dst + co) = o;
       }
   }
+}
+
+// Split-K epilogue: out = relu(sum_z partial[z] + bias) -> fp16, 4 channels per thread.
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, long long n4, int Cout,
+                                     const float* __restrict__ bias, int relu, half_t* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const size_t e = (size_t)i * 4;
+  float4 a = *(const float4*)(partial + e);
+  for (int z = 1; z < splits; ++z) {
+    const float4 b = *(const float4*)(partial + (size_t)z * n4 * 4 + e);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  const float4 bv = *(const float4*)(bias + (e % Cout));
+  a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+  if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  half4 o;
+  o[0] = (half_t)a.x; o[1] = (half_t)a.y; o[2] = (half_t)a.z; o[3] = (half_t)a.w;
+  *(half4*)(out + e) = o;
+}
+
+// ---------------------------------------------------------------------------
+// 1x1 heads on MFMA: rows = output channels (descriptor C, then the uncertainty row),
+// columns = 32 pixels per wave, K = Cin read straight from the NHWC map (one 16-B load per
+// lane per k-step).  Epilogue: optional per-pixel L2 normalisation of the descriptor,
+// confidence = sigmoid(-x), float32 HWC record [C | conf | 0 pad].
+// wts: fp16 [32*NT][Cin] (rows >= C+1 are zero), bias fp32 [32*NT].
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void head_mfma_kernel(const half_t* __restrict__ in, long long npix, int Cin,
+                                                        const half_t* __restrict__ wts,
+                                                        const float* __restrict__ bias, int Cout, int normalize,
+                                                        float* __restrict__ out, int cstride) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long p0 = wave * 32;
+  if (p0 >= npix) return;
+  const int r31 = lane & 31, khalf = lane >> 5;
+  const long long pix = min(p0 + r31, npix - 1);
+  f32x16 acc[NT];
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  const half_t* xp = in + (size_t)pix * Cin + 8 * khalf;
+  const half_t* wp = wts + (size_t)r31 * Cin + 8 * khalf;
+  for (int k0 = 0; k0 < Cin; k0 += 16) {
+    const half8 b = *(const half8*)(xp + k0);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const half8 a = *(const half8*)(wp + (size_t)(32 * c) * Cin + k0);
+      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+    }
+  }
+  // bias, then the descriptor's squared norm over this lane's rows and the partner half's
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const float v = acc[c][r] + bias[co];
+      acc[c][r] = v;
+      if (co < Cout) ss += v * v;
+    }
+  ss += __shfl_xor(ss, 32, 64);
+  const float inv = normalize ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+  if (p0 + r31 >= npix) return;
+  float* o = out + (size_t)(p0 + r31) * cstride;
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = 32 * c + 8 * g + 4 * khalf;
+      if (co >= cstride) continue;
+      float4 v;
+      float* vv = (float*)&v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = acc[c][4 * g + j];
+        const int cj = co + j;
+        vv[j] = (cj < Cout) ? x * inv : (cj == Cout ? 1.f / (1.f + expf(x)) : 0.f);
+      }
+      *(float4*)(o + co) = v;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -272,76 +376,6 @@ __global__ void upcat_kernel(const half_t* __restrict__ prev, int Hp, int Wp, in
 }
 
 // ---------------------------------------------------------------------------
-// 1x1 heads: descriptor (Cout) + uncertainty (1) from a fp16 NHWC map; writes the
-// float32 HWC record [Cout descriptor | confidence = sigmoid(-unc) | zero pad].
-// One wave handles PIX pixels; lane = output channel (strided by 64).
-// ---------------------------------------------------------------------------
-template <int PIX>
-__global__ __launch_bounds__(256) void head_kernel(const half_t* __restrict__ in, long long npix,
-                                                   int Cin, const float* __restrict__ wts,
-                                                   const float* __restrict__ bias, int Cout,
-                                                   int normalize, float* __restrict__ out,
-                                                   int cstride) {
-  const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long p0 = wave * PIX;
-  if (p0 >= npix) return;
-  const int Co1 = Cout + 1;
-  constexpr int MAXR = 3;  // up to 192 outputs (129 used)
-  float acc[MAXR][PIX];
-#pragma unroll
-  for (int r = 0; r < MAXR; ++r) {
-    const int co = lane + 64 * r;
-    const float b = (co < Co1) ? bias[co] : 0.f;
-#pragma unroll
-    for (int p = 0; p < PIX; ++p) acc[r][p] = b;
-  }
-  for (int k = 0; k < Cin; k += 8) {
-    half8 xv[PIX];
-#pragma unroll
-    for (int p = 0; p < PIX; ++p) {
-      const long long pp = min(p0 + p, npix - 1);
-      xv[p] = *(const half8*)(in + (size_t)pp * Cin + k);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-      for (int r = 0; r < MAXR; ++r) {
-        const int co = lane + 64 * r;
-        if (64 * r < Co1) {
-          const float w = (co < Co1) ? wts[(size_t)(k + j) * Co1 + co] : 0.f;
-#pragma unroll
-          for (int p = 0; p < PIX; ++p) acc[r][p] += (float)xv[p][j] * w;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < PIX; ++p) {
-    if (p0 + p >= npix) break;
-    float ss = 0.f;
-#pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-      const int co = lane + 64 * r;
-      if (co < Cout) ss += acc[r][p] * acc[r][p];
-    }
-    ss = group_allreduce_sum<64>(ss);
-    const float inv = normalize ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
-    float* o = out + (size_t)(p0 + p) * cstride;
-#pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
-      const int co = lane + 64 * r;
-      if (co < Cout)
-        o[co] = acc[r][p] * inv;
-      else if (co == Cout)
-        o[co] = 1.f / (1.f + expf(acc[r][p]));  // sigmoid(-x)
-      else if (co < cstride)
-        o[co] = 0.f;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Context
 // ---------------------------------------------------------------------------
 struct UnetLayer {
@@ -353,6 +387,9 @@ struct UnetLayer {
 }  // namespace pxt
 
 struct pxt_unet {
+  void* dev_head = nullptr;            // fp16 [32*NT][Cin] head weights + fp32 padded biases
+  const pxt::half_t* head_w[pxt::kNumHeads];
+  const float* head_b[pxt::kNumHeads];
   void* dev_blob = nullptr;
   int64_t n_bytes = 0;
   pxt::UnetLayer conv[pxt::kNumConv];
@@ -363,11 +400,28 @@ using namespace pxt;
 
 namespace {
 
+// Split-K factor: small maps leave most of the 256 CUs idle with (tiles x Cout blocks)
+// workgroups, so the Cin chunks are spread over gridDim.z until ~2 workgroups per CU exist.
+int choose_splits(int tiles, int nblocks, int n_chunks) {
+  const int wgs = tiles * nblocks;
+  if (wgs >= 384) return 1;
+  int splits = (512 + wgs - 1) / wgs;
+  splits = std::min(splits, std::max(1, n_chunks / 4));
+  return std::max(1, std::min(splits, 32));
+}
+
+size_t splitk_bytes(int H, int W, int cin, int cout) {
+  const int tiles = ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  const int nb = (cout % 64 == 0) ? cout / 64 : cout / 32;
+  const int sp = choose_splits(tiles, nb, cin / kCK);
+  return sp > 1 ? (size_t)sp * H * W * cout * sizeof(float) : 0;
+}
+
 struct Plan {
   int h[5], w[5];          // encoder block resolutions
   int dh[4], dw[4];        // decoder block output resolutions
   // byte offsets into the workspace
-  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_cat[4], dec_out[4], total;
+  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_cat[4], dec_out[4], splitk, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -394,6 +448,13 @@ bool make_plan(const pxt_unet* ctx, int H, int W, Plan& P) {
     P.dec_cat[d] = take(px * ctx->conv[13 + d].cin * 2);
     P.dec_out[d] = take(px * ctx->conv[13 + d].cout * 2);
   }
+  // one split-K partial buffer, sized for the hungriest layer
+  size_t sk = 0;
+  static const int blk_of[13] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};
+  for (int i = 1; i < 13; ++i)
+    sk = std::max(sk, splitk_bytes(P.h[blk_of[i]], P.w[blk_of[i]], ctx->conv[i].cin, ctx->conv[i].cout));
+  for (int d = 0; d < 4; ++d) sk = std::max(sk, splitk_bytes(P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout));
+  P.splitk = take(sk + 256);
   P.total = off;
   return true;
 }
@@ -410,23 +471,33 @@ void set_conv_lds_attr() {
 }
 
 int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out, hipStream_t s,
-                int relu = 1) {
+                int relu = 1, float* partial = nullptr) {
   if (L.cin % kCK != 0 || L.cout % 32 != 0) return PXT_E_ARG;
   set_conv_lds_attr();
   const int tiles = ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
-  if (L.cout % 64 == 0) {
+  const bool wide = L.cout % 64 == 0;
+  const int nb = wide ? L.cout / 64 : L.cout / 32;
+  const int splits = partial ? choose_splits(tiles, nb, L.cin / kCK) : 1;
+  if (wide) {
     const size_t lds = (size_t)(kHalo * kPix + 9 * 64 * kPix) * sizeof(half_t);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, dim3(tiles, L.cout / 64), dim3(256), lds, s, in, H, W,
-                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
+                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
   } else {
     const size_t lds = (size_t)(kHalo * kPix + 9 * 32 * kPix) * sizeof(half_t);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(tiles, L.cout / 32), dim3(256), lds, s, in, H, W,
-                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
+                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
+  }
+  if (splits > 1) {
+    const long long n4 = (long long)H * W * L.cout / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, splits,
+                       n4, L.cout, L.b, relu, out);
   }
   return PXT_OK;
 }
 
 }  // namespace
+
+extern "C" int pxt_unet_destroy(pxt_unet* ctx);
 
 extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_unet** out_ctx) {
   if (!weights_host || !out_ctx || n_bytes < 64) return PXT_E_ARG;
@@ -466,14 +537,45 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
   bool ok = ctx->conv[0].cin == 3 && (ctx->conv[0].cout % 16) == 0;
   for (int i = 1; i < n_conv; ++i) ok = ok && (ctx->conv[i].cin % kCK) == 0 && (ctx->conv[i].cout % 32) == 0;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 8) == 0 && ctx->head[i].cout + 1 <= 192;
+  for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 16) == 0 && ctx->head[i].cout + 1 <= 160;
   if (!ok) { hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
+  // heads: fp16 [32*NT][Cin] row-major weights (rows >= cout+1 zero) + fp32 padded bias
+  {
+    std::vector<char> hb;
+    size_t offs_w[kNumHeads], offs_b[kNumHeads];
+    for (int i = 0; i < n_heads; ++i) {
+      const int cin = ctx->head[i].cin, co1 = ctx->head[i].cout + 1;
+      const int rows = (co1 + 31) / 32 * 32;
+      const float* Wsrc = (const float*)(p + table[4 * (n_conv + i)]);      // [cin][co1]
+      const float* bsrc = (const float*)(p + table[4 * (n_conv + i) + 2]);  // [co1]
+      offs_w[i] = hb.size();
+      hb.resize(hb.size() + (size_t)rows * cin * sizeof(half_t));
+      half_t* wd = (half_t*)(hb.data() + offs_w[i]);
+      for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < cin; ++k) wd[(size_t)r * cin + k] = (half_t)(r < co1 ? Wsrc[(size_t)k * co1 + r] : 0.f);
+      hb.resize((hb.size() + 15) / 16 * 16);
+      offs_b[i] = hb.size();
+      hb.resize(hb.size() + (size_t)rows * sizeof(float));
+      float* bd = (float*)(hb.data() + offs_b[i]);
+      for (int r = 0; r < rows; ++r) bd[r] = r < co1 ? bsrc[r] : 0.f;
+      hb.resize((hb.size() + 15) / 16 * 16);
+    }
+    e = hipMalloc(&ctx->dev_head, hb.size());
+    if (e == hipSuccess) e = hipMemcpy(ctx->dev_head, hb.data(), hb.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_last_error("head weights", e); pxt_unet_destroy(ctx); return PXT_E_HIP; }
+    for (int i = 0; i < n_heads; ++i) {
+      ctx->head_w[i] = (const half_t*)((const char*)ctx->dev_head + offs_w[i]);
+      ctx->head_b[i] = (const float*)((const char*)ctx->dev_head + offs_b[i]);
+    }
+  }
   *out_ctx = ctx;
   return PXT_OK;
 }
 
 extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (!ctx) return PXT_E_ARG;
-  if (ctx->dev_blob) hipFree(ctx->dev_blob);
+  if (ctx->dev_blob) (void)hipFree(ctx->dev_blob);
+  if (ctx->dev_head) (void)hipFree(ctx->dev_head);
   delete ctx;
   return PXT_OK;
 }
@@ -529,7 +631,7 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
     for (int i = (b == 0 ? 1 : 0); i < block_n[b]; ++i) {
       const bool last = i == block_n[b] - 1;
       half_t* o = last ? buf(P.enc_out[b]) : buf(P.enc_tmp[b][i & 1]);
-      int rc = launch_conv(ctx->conv[block_first[b] + i], x, h, w, o, s);
+      int rc = launch_conv(ctx->conv[block_first[b] + i], x, h, w, o, s, 1, (float*)(ws + P.splitk));
       if (rc != PXT_OK) return rc;
       x = o;
     }
@@ -550,7 +652,7 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
     hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prev, ph, pw, pc,
                        skip[sb], P.w[sb], cs, cat);
     half_t* o = buf(P.dec_out[d]);
-    int rc = launch_conv(L, cat, P.dh[d], P.dw[d], o, s);
+    int rc = launch_conv(L, cat, P.dh[d], P.dw[d], o, s, 1, (float*)(ws + P.splitk));
     if (rc != PXT_OK) return rc;
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
@@ -563,10 +665,14 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
     const int i = head_src[k];
     const int hh = (i == 4) ? P.h[4] : P.dh[3 - i], ww = (i == 4) ? P.w[4] : P.dw[3 - i];
     const long long npix = (long long)hh * ww;
-    constexpr int PIX = 4;
-    const long long waves = (npix + PIX - 1) / PIX;
-    hipLaunchKernelGGL(head_kernel<PIX>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, pre[i], npix,
-                       Lh.cin, (const float*)Lh.w, Lh.b, Lh.cout, normalize, out_maps[k], out_cstride[k]);
+    const long long waves = (npix + 31) / 32;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (Lh.cout + 1 <= 64)
+      hipLaunchKernelGGL(head_mfma_kernel<2>, dim3(blocks), dim3(256), 0, s, pre[i], npix, Lh.cin, ctx->head_w[k],
+                         ctx->head_b[k], Lh.cout, normalize, out_maps[k], out_cstride[k]);
+    else
+      hipLaunchKernelGGL(head_mfma_kernel<5>, dim3(blocks), dim3(256), 0, s, pre[i], npix, Lh.cin, ctx->head_w[k],
+                         ctx->head_b[k], Lh.cout, normalize, out_maps[k], out_cstride[k]);
   }
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;

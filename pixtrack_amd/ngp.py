@@ -227,6 +227,15 @@ class Testbed:
     def render(self, width: int, height: int, spp: int = 8, linear: bool = True) -> np.ndarray:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 
+    def timing_enable(self, enable: bool = True):
+        _lib.check(_lib.lib().pxt_ngp_timing_enable(self._ctx, int(enable)), "pxt_ngp_timing_enable")
+
+    def timing_read(self):
+        """(total ms, launches) of ngp_encode_kernel since the last read (HIP events on the render stream)."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        _lib.check(_lib.lib().pxt_ngp_timing_read(self._ctx, C.byref(ms), C.byref(n)), "pxt_ngp_timing_read")
+        return float(ms.value), int(n.value)
+
     def read_stats(self):
         """(samples composited, rays that hit the box, rays finished by the straggler kernel) of
         the last render_device(collect_stats=True)."""
