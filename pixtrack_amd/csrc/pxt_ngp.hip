@@ -386,7 +386,7 @@ __device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, f
 }
 
 struct RayState {  // SoA, indexed by compact slot; two copies ping-pong between rounds
-  unsigned* rid;   // spp_index * W*H + pixel
+  unsigned* rid;   // pixel * spp + spp_index
   float* t;        // next lattice position
   float* T;        // transmittance so far
   float4* acc;     // premultiplied colour (or depth) + alpha so far
@@ -414,13 +414,22 @@ __device__ inline void sh_fragments(const float* d, unsigned* shB0, unsigned* sh
   }
 }
 
+// Ray id = pixel * spp + sample.  Rays are enumerated sample-fastest over 4x2 pixel blocks,
+// so one wave holds the 8 spp passes of 8 neighbouring pixels: at the coarse and middle
+// hash levels those 64 samples share grid cells and their gathers coalesce in the L1.
 __global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const NgpWork Wk) {
-  const int wh = P.W * P.H;
-  const long long total = (long long)wh * P.spp;
+  const int bx = (P.W + 3) / 4, by = (P.H + 1) / 2;
+  const long long total = (long long)bx * by * 8 * P.spp;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int s = (int)(i / wh), pix = (int)(i % wh);
-    const Ray r = make_ray(P, pix % P.W, pix / P.W);
-    Wk.sppbuf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s = (int)(i % P.spp);
+    const long long q = i / P.spp;
+    const int blk = (int)(q / 8), within = (int)(q % 8);
+    const int px = (blk % bx) * 4 + (within & 3), py = (blk / bx) * 2 + (within >> 2);
+    if (px >= P.W || py >= P.H) continue;
+    const int pix = py * P.W + px;
+    const unsigned rid = (unsigned)pix * (unsigned)P.spp + (unsigned)s;
+    const Ray r = make_ray(P, px, py);
+    Wk.sppbuf[rid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!r.hit) continue;
     float t = fmaxf(r.tmin, 0.f) + 1e-6f;
     unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const 
     const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
     t = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
     const int slot = atomicAdd(Wk.counters, 1);
-    Wk.st[0].rid[slot] = (unsigned)i;
+    Wk.st[0].rid[slot] = rid;
     Wk.st[0].t[slot] = t;
     Wk.st[0].T[slot] = 1.f;
     Wk.st[0].acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
   const RayState& S = Wk.st[round & 1];
   const int wh = P.W * P.H;
   for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
-    const int pix = (int)(S.rid[slot] % (unsigned)wh);
+    const int pix = (int)(S.rid[slot] / (unsigned)P.spp);
     const Ray r = make_ray(P, pix % P.W, pix / P.W);
     float t = S.t[slot];
     bool out = false;
@@ -467,6 +476,7 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, cons
   const int n = Wk.counters[round * kCtrStride];
   const long long ns = (long long)n * kK;
   const long long chunks = (ns + 255) / 256;
+  if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)ns);
   const float half_s = P.aabb_scale * 0.5f;
   const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
   for (long long item = blockIdx.x; item < chunks * P.n_levels; item += gridDim.x) {
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     const float dt = ray_ok ? sp.w : 0.f;
     const bool valid = dt != 0.f;
     const unsigned rid = S.rid[sl];
-    const int pix = (int)(rid % (unsigned)wh);
+    const int pix = (int)(rid / (unsigned)P.spp);
     const Ray r = make_ray(P, pix % P.W, pix / P.W);
     unsigned shB0[4], shB1[4];
     sh_fragments(r.d, shB0, shB1);
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
     bool alive = slot < n;
     const int sl = alive ? slot : 0;
     const unsigned rid = S.rid[sl];
-    const int pix = (int)(rid % (unsigned)wh);
+    const int pix = (int)(rid / (unsigned)P.spp);
     const Ray r = make_ray(P, pix % P.W, pix / P.W);
     unsigned shB0[4], shB1[4];
     sh_fragments(r.d, shB0, shB1);
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
   if (pix >= wh) return;
   float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
   for (int s = 0; s < P.spp; ++s) {
-    const float4 v = Wk.sppbuf[(size_t)s * wh + pix];
+    const float4 v = Wk.sppbuf[(size_t)pix * P.spp + s];
     ar += v.x; ag += v.y; ab += v.z; aa += v.w;
   }
   const float inv = 1.0f / (float)P.spp;

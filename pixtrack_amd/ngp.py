@@ -240,4 +240,4 @@ class Testbed:
         """(samples composited, rays that hit the box, rays finished by the straggler kernel) of
         the last render_device(collect_stats=True)."""
         s = self._stats.cpu().tolist()
-        return {"samples": s[0], "rays_hit": s[1], "tail_rays": s[2]}
+        return {"samples": s[0], "rays_hit": s[1], "tail_rays": s[2], "encoded_slots": s[3]}
