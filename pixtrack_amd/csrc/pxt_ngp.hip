@@ -163,96 +163,90 @@ __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, c
 
 // Both MLPs for the wave's 64 samples (lane = sample).  Flo/Fhi: this lane's 32 encoded
 // features as 16 packed dwords (levels 0..7 / 8..15).  All 64 lanes must call (MFMA).
+// One 32-sample column block through both MLPs.  x0/x1: the block's two input B fragments,
+// shb: its SH fragment.  Returns the raw density logit row and the three activated colour rows
+// as held by this lane (rows 0..3 live in the low lane half).
+template <bool DEPTH_ONLY>
+__device__ inline void ngp_mlp_block(const half8* s_w, int lane, half8 x0, half8 x1, half8 shb, float& logit,
+                                     float* rgb) {
+  // ---- density MLP: 32 -> 64 (ReLU) -> 16 ----
+  f32x16 h1[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    f32x16 a = {0};
+    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD1 + 2 * rb) * 64 + lane], x0, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD1 + 2 * rb + 1) * 64 + lane], x1, a, 0, 0, 0);
+    h1[rb] = a;
+  }
+  f32x16 dout = {0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    dout = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD2 + q) * 64 + lane],
+                                                  relu_pack8(h1[q >> 1], 8 * (q & 1), true), dout, 0, 0, 0);
+  logit = dout[0];
+  if (DEPTH_ONLY) {
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+    return;
+  }
+  // ---- colour MLP: [16 density outputs | 16 SH] -> 64 -> 64 -> 16 ----
+  f32x16 c1[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    f32x16 a = {0};
+    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb) * 64 + lane], relu_pack8(dout, 0, false), a,
+                                               0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb + 1) * 64 + lane], shb, a, 0, 0, 0);
+    c1[rb] = a;
+  }
+  f32x16 c2[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    f32x16 a = {0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC2 + 4 * rb + q) * 64 + lane],
+                                                 relu_pack8(c1[q >> 1], 8 * (q & 1), true), a, 0, 0, 0);
+    c2[rb] = a;
+  }
+  f32x16 cout = {0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    cout = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC3 + q) * 64 + lane],
+                                                  relu_pack8(c2[q >> 1], 8 * (q & 1), true), cout, 0, 0, 0);
+  // The activation is applied BEFORE any cross-lane move: v_permlane32_swap reading a register
+  // an MFMA is still writing returned stale rows (regs > 0) on gfx950 / ROCm 7.2; a VALU op in
+  // between gets the MFMA->VALU wait states the compiler does model.
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb[c] = 1.0f / (1.0f + expf(-cout[c]));
+}
+
+// Both MLPs for the wave's 64 samples (lane = sample).  Flo/Fhi: this lane's 32 encoded
+// features as 16 packed dwords (levels 0..7 / 8..15).  All 64 lanes must call (MFMA).
+// The two 32-sample column blocks run one after the other (sched_barrier keeps the compiler
+// from interleaving them), which halves the live accumulators -> 4 waves per SIMD.
 template <bool DEPTH_ONLY>
 __device__ inline void ngp_mlp(const half8* s_w, int lane, unsigned* Flo, unsigned* Fhi, const unsigned* shB0,
                                const unsigned* shB1, float& logit, float* rgbv) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) swap32(Flo[i], Fhi[i]);
-        // B fragments of the feature input: [cb][q]
-        half8 xB[2][2];
+  for (int i = 0; i < 8; ++i) swap32(Flo[i], Fhi[i]);
+  float l0, l1, c0[3], c1[3];
+  ngp_mlp_block<DEPTH_ONLY>(s_w, lane, as_half8(Flo[0], Flo[1], Flo[2], Flo[3]), as_half8(Flo[4], Flo[5], Flo[6], Flo[7]),
+                            as_half8(shB0[0], shB0[1], shB0[2], shB0[3]), l0, c0);
+  __builtin_amdgcn_sched_barrier(0);
+  ngp_mlp_block<DEPTH_ONLY>(s_w, lane, as_half8(Fhi[0], Fhi[1], Fhi[2], Fhi[3]), as_half8(Fhi[4], Fhi[5], Fhi[6], Fhi[7]),
+                            as_half8(shB1[0], shB1[1], shB1[2], shB1[3]), l1, c1);
+  // rows 0..3 of a block sit in the low lane half: bring block 1's to the high lanes
+  // (the logits pass through a VALU op first: same MFMA -> permlane hazard as above)
+  unsigned r0 = __builtin_bit_cast(unsigned, fmaxf(l0, -1e30f)), r1 = __builtin_bit_cast(unsigned, fmaxf(l1, -1e30f));
+  swap32(r0, r1);
+  logit = __builtin_bit_cast(float, r0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          xB[0][q] = as_half8(Flo[4 * q], Flo[4 * q + 1], Flo[4 * q + 2], Flo[4 * q + 3]);
-          xB[1][q] = as_half8(Fhi[4 * q], Fhi[4 * q + 1], Fhi[4 * q + 2], Fhi[4 * q + 3]);
-        }
-        // ---- density MLP: 32 -> 64 (ReLU) -> 16 ----
-        f32x16 h1[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            f32x16 a = {0};
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD1 + 2 * rb + q) * 64 + lane], xB[cb][q], a, 0, 0, 0);
-            h1[rb][cb] = a;
-          }
-        f32x16 dout[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          f32x16 a = {0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragD2 + q) * 64 + lane],
-                                                       relu_pack8(h1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
-          dout[cb] = a;
-        }
-        unsigned r0 = __builtin_bit_cast(unsigned, dout[0][0]), r1 = __builtin_bit_cast(unsigned, dout[1][0]);
-        swap32(r0, r1);
-        logit = __builtin_bit_cast(float, r0);
-        if (DEPTH_ONLY) {
-          rgbv[0] = rgbv[1] = rgbv[2] = 0.f;
-          return;
-        }
-        // ---- colour MLP: [16 density outputs | 16 SH] -> 64 -> 64 -> 16 ----
-        f32x16 c1[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            f32x16 a = {0};
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb) * 64 + lane],
-                                                       relu_pack8(dout[cb], 0, false), a, 0, 0, 0);
-            const half8 shb = cb == 0 ? as_half8(shB0[0], shB0[1], shB0[2], shB0[3])
-                                      : as_half8(shB1[0], shB1[1], shB1[2], shB1[3]);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb + 1) * 64 + lane], shb, a, 0, 0, 0);
-            c1[rb][cb] = a;
-          }
-        f32x16 c2[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            f32x16 a = {0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC2 + 4 * rb + q) * 64 + lane],
-                                                         relu_pack8(c1[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
-            c2[rb][cb] = a;
-          }
-        f32x16 cout[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          f32x16 a = {0};
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC3 + q) * 64 + lane],
-                                                       relu_pack8(c2[q >> 1][cb], 8 * (q & 1), true), a, 0, 0, 0);
-          cout[cb] = a;
-        }
-        // rows 0..3 of column block cb sit in the low half; block 1 is brought to the high lanes.
-        // The activation is applied BEFORE the cross-lane move: v_permlane32_swap reading a
-        // register an MFMA is still writing returned stale rows (regs > 0) on gfx950/ROCm 7.2;
-        // a VALU op in between gets the MFMA->VALU wait states the compiler does model.
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          unsigned a0 = __builtin_bit_cast(unsigned, 1.0f / (1.0f + expf(-cout[0][c])));
-          unsigned a1 = __builtin_bit_cast(unsigned, 1.0f / (1.0f + expf(-cout[1][c])));
-          swap32(a0, a1);
-          rgbv[c] = __builtin_bit_cast(float, a0);
-        }
+  for (int c = 0; c < 3; ++c) {
+    unsigned a0 = __builtin_bit_cast(unsigned, c0[c]), a1 = __builtin_bit_cast(unsigned, c1[c]);
+    swap32(a0, a1);
+    rgbv[c] = __builtin_bit_cast(float, a0);
+  }
 }
-
 
 // Fused encode + MLPs (lane = sample) used by the straggler kernel and the point query.
 template <bool DEPTH_ONLY>
@@ -292,7 +286,7 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // samples; samples a round evaluates past a ray's termination point are discarded.
 // ===========================================================================
 constexpr int kK = 8;          // samples per ray per round
-constexpr int kRounds = 3;     // wavefront rounds before the tail kernel
+constexpr int kRounds = 5;     // wavefront rounds before the tail kernel
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {
@@ -399,6 +393,8 @@ struct NgpWork {
   float* st_t;         // t of each sample (depth mode)
   unsigned* feat;      // [level][sample] packed fp16 pair
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
+  uint8_t* keep;       // per slot: the ray continues into the next round (written by shade)
+  float* cand_t;       // per enumerated ray: start t, or < 0 for rays that miss the box
   float4* sppbuf;      // [spp][H][W] finished rays
   size_t feat_stride;  // samples per level plane
 };
@@ -417,30 +413,102 @@ __device__ inline void sh_fragments(const float* d, unsigned* shB0, unsigned* sh
 // Ray id = pixel * spp + sample.  Rays are enumerated sample-fastest over 4x2 pixel blocks,
 // so one wave holds the 8 spp passes of 8 neighbouring pixels: at the coarse and middle
 // hash levels those 64 samples share grid cells and their gathers coalesce in the L1.
+__device__ inline bool enum_ray(const NgpParams& P, long long i, int& px, int& py, int& s) {
+  const int bx = (P.W + 3) / 4;
+  s = (int)(i % P.spp);
+  const long long q = i / P.spp;
+  const int blk = (int)(q / 8), within = (int)(q % 8);
+  px = (blk % bx) * 4 + (within & 3);
+  py = (blk / bx) * 2 + (within >> 2);
+  return px < P.W && py < P.H;
+}
+
+__device__ inline long long enum_total(const NgpParams& P) {
+  return (long long)((P.W + 3) / 4) * ((P.H + 1) / 2) * 8 * P.spp;
+}
+
 __global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const NgpWork Wk) {
-  const int bx = (P.W + 3) / 4, by = (P.H + 1) / 2;
-  const long long total = (long long)bx * by * 8 * P.spp;
+  const long long total = enum_total(P);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int s = (int)(i % P.spp);
-    const long long q = i / P.spp;
-    const int blk = (int)(q / 8), within = (int)(q % 8);
-    const int px = (blk % bx) * 4 + (within & 3), py = (blk / bx) * 2 + (within >> 2);
-    if (px >= P.W || py >= P.H) continue;
-    const int pix = py * P.W + px;
-    const unsigned rid = (unsigned)pix * (unsigned)P.spp + (unsigned)s;
-    const Ray r = make_ray(P, px, py);
-    Wk.sppbuf[rid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!r.hit) continue;
-    float t = fmaxf(r.tmin, 0.f) + 1e-6f;
-    unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
-    t = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-    const int slot = atomicAdd(Wk.counters, 1);
-    Wk.st[0].rid[slot] = rid;
-    Wk.st[0].t[slot] = t;
-    Wk.st[0].T[slot] = 1.f;
-    Wk.st[0].acc[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int px, py, s;
+    float t0 = -1.f;
+    if (enum_ray(P, i, px, py, s)) {
+      const int pix = py * P.W + px;
+      Wk.sppbuf[(size_t)pix * P.spp + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const Ray r = make_ray(P, px, py);
+      if (r.hit) {
+        float t = fmaxf(r.tmin, 0.f) + 1e-6f;
+        unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
+        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+        const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
+        t0 = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+      }
+    }
+    Wk.cand_t[i] = t0;
+  }
+}
+
+// Order-preserving compaction of 2048-item tiles: ONE global atomic per tile (a single
+// counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue").
+// FROM_INIT: items are enumerated rays (keep = cand_t >= 0), else slots of the previous round.
+constexpr int kTile = 2048;
+template <bool FROM_INIT>
+__global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const long long n = FROM_INIT ? enum_total(P) : (long long)Wk.counters[round * kCtrStride];
+  const RayState& S = Wk.st[round & 1];
+  const RayState& D = FROM_INIT ? Wk.st[0] : Wk.st[(round + 1) & 1];
+  int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long tiles = (n + kTile - 1) / kTile;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long i0 = tile * kTile + (long long)threadIdx.x * 8;
+    bool k[8];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long long i = i0 + j;
+      k[j] = i < n && (FROM_INIT ? (Wk.cand_t[i] >= 0.f) : (Wk.keep[i] != 0));
+      cnt += k[j] ? 1 : 0;
+    }
+    int inc = cnt;  // inclusive scan within the wave
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const int o = __shfl_up(inc, m, 64);
+      if (lane >= m) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int wave_off = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) wave_off += s_wave[w];
+      tile_total += s_wave[w];
+    }
+    if (threadIdx.x == 0) s_base = tile_total ? atomicAdd(out_count, tile_total) : 0;
+    __syncthreads();
+    int dst = s_base + wave_off + inc - cnt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!k[j]) continue;
+      const long long i = i0 + j;
+      if (FROM_INIT) {
+        int px, py, s;
+        enum_ray(P, i, px, py, s);
+        D.rid[dst] = (unsigned)(py * P.W + px) * (unsigned)P.spp + (unsigned)s;
+        D.t[dst] = Wk.cand_t[i];
+        D.T[dst] = 1.f;
+        D.acc[dst] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        D.rid[dst] = S.rid[i];
+        D.t[dst] = S.t[i];
+        D.T[dst] = S.T[i];
+        D.acc[dst] = S.acc[i];
+      }
+      ++dst;
+    }
+    __syncthreads();
   }
 }
 
@@ -507,8 +575,6 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   __syncthreads();
   const int n = Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
-  const RayState& Sn = Wk.st[(round + 1) & 1];
-  int* next_count = Wk.counters + (round + 1) * kCtrStride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
   const int wh = P.W * P.H;
@@ -582,12 +648,11 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
       const bool exhausted = Wk.exhausted[slot] != 0;
       if (terminated || exhausted) {
         finish_ray(Wk, rid, acc, terminated);
-      } else {
-        const int ns = atomicAdd(next_count, 1);
-        Sn.rid[ns] = rid;
-        Sn.t[ns] = S.t[slot];
-        Sn.T[ns] = T_new;
-        Sn.acc[ns] = acc;
+        Wk.keep[slot] = 0;
+      } else {  // the compaction kernel moves the survivors into the next round's list
+        S.T[slot] = T_new;
+        S.acc[slot] = acc;
+        Wk.keep[slot] = 1;
       }
     }
   }
@@ -863,6 +928,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   const size_t o_cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
   const size_t o_spos = take(samples * 16), o_stt = take(samples * 4);
   const size_t o_feat = take(samples * 4 * kMaxLevels), o_exh = take(rays), o_spp = take(rays * 16);
+  const size_t o_keep = take(rays), o_cand = take((rays + 64 * 8) * 4 + 4096);
   hipError_t e = hipMalloc(&ctx->scratch, off);
   if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
   char* b = (char*)ctx->scratch;
@@ -877,6 +943,8 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   W.feat = (unsigned*)(b + o_feat);
   W.exhausted = (uint8_t*)(b + o_exh);
   W.sppbuf = (float4*)(b + o_spp);
+  W.keep = (uint8_t*)(b + o_keep);
+  W.cand_t = (float*)(b + o_cand);
   W.feat_stride = samples;
   ctx->scratch_rays = rays;
   return PXT_OK;
@@ -898,7 +966,8 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
   P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = v->mode;
   P.out = out_rgba;
   P.stats = (unsigned long long*)stats;
-  const size_t rays = (size_t)v->width * v->height * v->spp;
+  // padded to whole 4x2 pixel blocks (the enumeration order of ngp_init_kernel)
+  const size_t rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
   if (rays > 0x7fffffffull / kK) return PXT_E_ARG;
   int rc = ensure_scratch(ctx, rays);
   if (rc != PXT_OK) return rc;
@@ -907,6 +976,7 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
   PXT_HIP_CHECK(hipMemsetAsync(Wk.counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), s));
   const int wide = 2048;
   hipLaunchKernelGGL(ngp_init_kernel, dim3(wide), dim3(256), 0, s, P, Wk);
+  hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, 0);
   for (int r = 0; r < kRounds; ++r) {
     hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, s, P, Wk, r);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -924,6 +994,7 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
       hipLaunchKernelGGL(ngp_shade_kernel<true>, dim3(wide), dim3(256), 0, s, P, Wk, r);
     else
       hipLaunchKernelGGL(ngp_shade_kernel<false>, dim3(wide), dim3(256), 0, s, P, Wk, r);
+    hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(1024), dim3(256), 0, s, P, Wk, r);
   }
   if (v->mode == 1)
     hipLaunchKernelGGL(ngp_tail_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
