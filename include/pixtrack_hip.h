@@ -10,7 +10,8 @@
  * class/method names on top (INTEGRATION.md shows the stub a maintainer would add).
  *
  * Conventions
- *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host (small records such as
+ *     poses, cameras and configuration are read on the host and passed as kernel arguments);
  *   - the caller owns every buffer; the library keeps no reference after return
  *     (work is enqueued on `stream`; buffers must stay alive until it completes);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
@@ -98,7 +99,7 @@ typedef struct {
  */
 int pxt_lm_refine(const float* p3d, const uint8_t* point_mask /* may be NULL */,
                   int32_t n_points, const pxt_lm_level* levels_host, int32_t n_levels,
-                  const float* T_init /* device, 12 */, const pxt_lm_conf* conf_host,
+                  const float* T_init_host /* 12 floats */, const pxt_lm_conf* conf_host,
                   float* out /* device, 16+PXT_MAX_LEVELS */, float* log /* device or NULL */,
                   void* workspace /* device, pxt_lm_workspace_bytes() */, void* stream);
 
@@ -125,7 +126,7 @@ typedef struct {
   int32_t ndist;
 } pxt_sample_level;
 
-int pxt_sample_sparse(const float* p3d, int32_t n_points, const float* T /* device, 12 */,
+int pxt_sample_sparse(const float* p3d, int32_t n_points, const float* T_host /* 12 floats */,
                       const pxt_sample_level* levels_host, int32_t n_levels, int32_t pad,
                       int32_t normalize, uint8_t* valid /* [n_points] */, void* stream);
 

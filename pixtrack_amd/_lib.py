@@ -19,7 +19,7 @@ LIB_PATH = _HERE / "libpixtrack_hip.so"
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class PxtError(RuntimeError):
@@ -173,6 +173,16 @@ def stream_ptr(device: torch.device) -> int:
 def require_gpu(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise PxtError(f"{name} must live on a ROCm device (got {t.device}); no CPU path exists")
+
+
+def host_pose12(T) -> "C.Array":
+    """12 host floats (row-major R, then t) from a Pose / tensor / array, for *_host arguments."""
+    data = T.as12() if hasattr(T, "as12") else T
+    if torch.is_tensor(data):
+        data = data.detach().cpu().reshape(-1).tolist()
+    vals = [float(x) for x in data]
+    assert len(vals) == 12
+    return (C.c_float * 12)(*vals)
 
 
 def dptr(t: Optional[torch.Tensor]) -> Optional[int]:

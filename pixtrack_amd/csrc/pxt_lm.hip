@@ -52,7 +52,7 @@ struct LmParams {
   const uint8_t* mask;
   int n, n_levels;
   LmLevelDev lv[PXT_MAX_LEVELS];
-  const float* T_init;
+  float T_init[12];
   pxt_lm_conf conf;
   float* out;
   float* log;
@@ -552,7 +552,7 @@ struct SampleLevelDev {
 
 struct SampleParams {
   const float* p3d;
-  const float* T;
+  float T[12];
   int n, n_levels, pad, normalize;
   SampleLevelDev lv[PXT_MAX_LEVELS];
   uint8_t* valid;
@@ -676,7 +676,7 @@ extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_
     d.ndist = s.ndist;
     for (int i = 0; i < 6; ++i) d.lambda[i] = s.lambda[i];
   }
-  P.T_init = T_init;
+  for (int i = 0; i < 12; ++i) P.T_init[i] = T_init[i];
   P.conf = *conf;
   P.out = out;
   P.log = log;
@@ -701,7 +701,7 @@ extern "C" int pxt_sample_sparse(const float* p3d, int32_t n_points, const float
   if (n_levels < 1 || n_levels > PXT_MAX_LEVELS || n_points < 1 || pad < 0) return PXT_E_ARG;
   SampleParams P;
   P.p3d = p3d;
-  P.T = T;
+  for (int i = 0; i < 12; ++i) P.T[i] = T[i];
   P.n = n_points;
   P.n_levels = n_levels;
   P.pad = pad;

@@ -111,7 +111,7 @@ def sample_sparse_points2d(fmap: torch.Tensor, Cc: int, pts: torch.Tensor, pad: 
         fm[..., :cs] = fmap
         fmap, cs = fm, C4 + 4
     p3d = torch.cat([pts, torch.ones(N, 1, device=pts.device)], -1).contiguous()
-    T = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32, device=pts.device)
+    T = _lib.host_pose12([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])
     out = torch.empty(N, cs, device=pts.device, dtype=torch.float32)
     valid = torch.empty(N, device=pts.device, dtype=torch.uint8)
     lv = _lib.SampleLevel()
@@ -120,7 +120,7 @@ def sample_sparse_points2d(fmap: torch.Tensor, Cc: int, pts: torch.Tensor, pad: 
     lv.cam[:] = [w, h, 1, 1, 0, 0, 0, 0, 0, 0]
     lv.ndist = 0
     _lib.check(
-        L.pxt_sample_sparse(p3d.data_ptr(), N, T.data_ptr(), C.byref(lv), 1, pad, 0,
+        L.pxt_sample_sparse(p3d.data_ptr(), N, T, C.byref(lv), 1, pad, 0,
                             valid.data_ptr(), _lib.stream_ptr(pts.device)),
         "pxt_sample_sparse",
     )
@@ -259,25 +259,24 @@ class PixTrackOptimizer:
             arr[i].ndist = int(lp.camera._data.shape[-1] - 6)
             arr[i].lambda_[:] = lp.lambda_.float().tolist()
             keep.append(lp)
-        T0 = T_init.as12().detach().to(dev, torch.float32).contiguous()
-        out = torch.zeros(16 + _lib.PXT_MAX_LEVELS, device=dev, dtype=torch.float32)
-        log = (
-            torch.zeros(n_levels, conf.num_iters, _lib.PXT_LM_LOG_STRIDE, device=dev, dtype=torch.float32)
-            if want_log
-            else None
-        )
+        T0 = _lib.host_pose12(T_init)
+        # one buffer for the output record and the iteration log -> one device->host copy
+        n_log = n_levels * conf.num_iters * _lib.PXT_LM_LOG_STRIDE if want_log else 0
+        buf = torch.zeros(16 + _lib.PXT_MAX_LEVELS + n_log, device=dev, dtype=torch.float32)
+        out = buf[: 16 + _lib.PXT_MAX_LEVELS]
+        log = buf[16 + _lib.PXT_MAX_LEVELS:].view(n_levels, conf.num_iters, _lib.PXT_LM_LOG_STRIDE) if want_log else None
         p3d = p3d.to(torch.float32).contiguous()
         if mask is not None:
             mask = mask.to(dev, torch.uint8).contiguous()
         _lib.check(
             L.pxt_lm_refine(
-                p3d.data_ptr(), _lib.dptr(mask), p3d.shape[0], arr, n_levels, T0.data_ptr(),
+                p3d.data_ptr(), _lib.dptr(mask), p3d.shape[0], arr, n_levels, T0,
                 C.byref(conf), out.data_ptr(), _lib.dptr(log), workspace.data_ptr(),
                 _lib.stream_ptr(dev),
             ),
             "pxt_lm_refine",
         )
-        return PendingLM(out, log, n_levels, conf.num_iters, (p3d, mask, T0, keep, workspace))
+        return PendingLM(buf, want_log, n_levels, conf.num_iters, (p3d, mask, keep, workspace))
 
     def run(self, p3D, F_ref, F_query, T_init: Pose, camera: Camera, mask=None, W_ref_query=None):
         """One pyramid level, pixloc calling convention:
@@ -328,20 +327,25 @@ class PixTrackOptimizer:
 
 
 class PendingLM:
-    """Result handle of an enqueued refinement (one device->host copy on .result())."""
+    """Result handle of an enqueued refinement (ONE device->host copy on .result())."""
 
-    def __init__(self, out, log, n_levels, num_iters, keepalive):
-        self.out, self.log_dev = out, log
+    def __init__(self, buf, has_log, n_levels, num_iters, keepalive):
+        self.buf, self.has_log = buf, has_log
         self.n_levels, self.num_iters = n_levels, num_iters
         self._keep = keepalive
 
     def result(self) -> LMResult:
-        out = self.out.cpu()
+        host = self.buf.cpu()
+        nh = 16 + _lib.PXT_MAX_LEVELS
+        out = host[:nh]
         status = int(out[13])
         if status != 0:
             raise _lib.PxtError(f"pxt_lm_refine: in-kernel status {status} (spin bound exceeded)")
         iters = [int(out[16 + l]) for l in range(self.n_levels)]
-        log = self.log_dev.cpu() if self.log_dev is not None else torch.zeros(self.n_levels, 0, 20)
-        costs = [[float(c) for c in log[l, : iters[l], 0]] for l in range(self.n_levels)] if self.log_dev is not None else []
+        if self.has_log:
+            log = host[nh:].view(self.n_levels, self.num_iters, _lib.PXT_LM_LOG_STRIDE)
+            costs = [log[l, : iters[l], 0].tolist() for l in range(self.n_levels)]
+        else:
+            log, costs = torch.zeros(self.n_levels, 0, _lib.PXT_LM_LOG_STRIDE), []
         self._keep = None
         return LMResult(Pose(out[:12].clone()), bool(out[12] != 0), iters, costs, log, int(out[14]))

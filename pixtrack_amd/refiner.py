@@ -151,10 +151,10 @@ class PoseTrackerRefiner:
             arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, OUTPUT_DIMS[i], cs
             arr[i].cam[:] = cam_l.as10().tolist()
             arr[i].ndist = int(cam_l._data.shape[-1] - 6)
-        T12 = T_w2cam.as12().detach().to(self.device, torch.float32).contiguous()
+        T12 = _lib.host_pose12(T_w2cam)
         valid = torch.empty(n, dtype=torch.uint8, device=self.device)
         pad = self.optimizer[0].interpolator.pad
-        _lib.check(L.pxt_sample_sparse(p3d.data_ptr(), n, T12.data_ptr(), arr, len(feature_maps), int(pad), 1,
+        _lib.check(L.pxt_sample_sparse(p3d.data_ptr(), n, T12, arr, len(feature_maps), int(pad), 1,
                                        valid.data_ptr(), _lib.stream_ptr(self.device)), "pxt_sample_sparse")
         return SparseReferenceFeatures(outs, valid, list(p3dids), p3d, OUTPUT_DIMS)
 
@@ -225,9 +225,11 @@ class PoseTrackerRefiner:
         res = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws,
                                               mask=ref.valid).result()
         self.last_lm.append(res)
-        # replay the iteration log into the tracker hooks, level by level
+        # replay the iteration log into the tracker hooks, level by level (only when someone listens:
+        # DebugTracker ignores everything below debug level 1, tracker.py:33-34)
+        listening = self.tracker is not None and getattr(self.tracker, "debug", 1) >= 1
         T_level = T_init
-        for k, level in enumerate(order):
+        for k, level in enumerate(order if listening else []):
             if res.iters[k] == 0:
                 break
             opt = self.optimizer[level] if isinstance(self.optimizer, (list, tuple)) else self.optimizer

@@ -6,8 +6,15 @@ from scipy.spatial.transform import Rotation
 
 
 def geodesic_distance_for_rotations(R1: np.ndarray, R2: np.ndarray) -> float:
-    """Angle (rad) of the relative rotation R1 R2^T (reference pose_utils.py:8-13)."""
-    return float(np.linalg.norm(Rotation.from_matrix(np.asarray(R1) @ np.asarray(R2).T).as_rotvec()))
+    """Angle (rad) of the relative rotation R1 R2^T (reference pose_utils.py:8-13 takes the norm
+    of scipy's rotation vector).  Same value from atan2(|sin|, cos) of the relative rotation --
+    accurate at 0 and pi alike and ~50x cheaper than building a scipy Rotation per call (the
+    tracker evaluates it for every covisible reference each frame)."""
+    Rd = np.asarray(R1, dtype=np.float64) @ np.asarray(R2, dtype=np.float64).T
+    cos = (Rd[0, 0] + Rd[1, 1] + Rd[2, 2] - 1.0) * 0.5
+    sx, sy, sz = Rd[2, 1] - Rd[1, 2], Rd[0, 2] - Rd[2, 0], Rd[1, 0] - Rd[0, 1]
+    sin = 0.5 * np.sqrt(sx * sx + sy * sy + sz * sz)
+    return float(np.arctan2(sin, cos))
 
 
 def get_world_in_camera_from_pixpose(pixpose) -> np.ndarray:

@@ -174,10 +174,10 @@ def test_sample_sparse_matches_oracle(device):
         arr[l].h, arr[l].w, arr[l].C, arr[l].cstride = fq.shape[1], fq.shape[2], Cc, cs
         arr[l].cam[:] = cam_full.scale(sc.scales[l]).as10().tolist()
         arr[l].ndist = 2
-    T = Pose.from_Rt(sc.R_gt, sc.t_gt).as12().float().to(device)
+    T = _lib.host_pose12(Pose.from_Rt(sc.R_gt, sc.t_gt))
     valid = torch.zeros(n, dtype=torch.uint8, device=device)
     pd = torch.from_numpy(p3d).float().to(device)
-    _lib.check(L.pxt_sample_sparse(pd.data_ptr(), n, T.data_ptr(), arr, 3, pad, 1, valid.data_ptr(),
+    _lib.check(L.pxt_sample_sparse(pd.data_ptr(), n, T, arr, 3, pad, 1, valid.data_ptr(),
                                    _lib.stream_ptr(device)), "pxt_sample_sparse")
     torch.cuda.synchronize()
     v = valid.cpu().bool()
