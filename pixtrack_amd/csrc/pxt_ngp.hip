@@ -70,11 +70,20 @@ __device__ inline float calc_dt(float t, float cone, float lo, float hi) {
   return fminf(fmaxf(t * cone, lo), hi);
 }
 
+// frexp exponent of a non-negative float (0 for 0; denormals flush to exponent -126: they only
+// occur within 1e-38 of the cube centre, where every cascade index clamps to 0 anyway).
+__device__ inline int frexp_exp(float v) {
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  const int e = (int)((b >> 23) & 0xffu);
+  return e == 0 ? 0 : e - 126;
+}
+
+// 2^k as a float, k in [-126, 127] (exact; replaces ldexpf(1, k))
+__device__ inline float pow2i(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+
 __device__ inline int mip_from_pos(float x, float y, float z, int cascades) {
   float m = fmaxf(fabsf(x - 0.5f), fmaxf(fabsf(y - 0.5f), fabsf(z - 0.5f)));
-  int e;
-  frexpf(m, &e);
-  return min(max(e + 1, 0), cascades - 1);
+  return min(max(frexp_exp(m) + 1, 0), cascades - 1);
 }
 
 __device__ inline unsigned pack_h2(float a, float b) {
@@ -139,13 +148,14 @@ __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, c
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const unsigned cx = gx + (c & 1), cy = gy + ((c >> 1) & 1), cz = gz + ((c >> 2) & 1);
+    // tcnn: index % level_size.  A hashed level has exactly 2^log2_hashmap entries (mask), a
+    // dense level's index is already < res^3 <= size: no integer division either way.
     unsigned idx;
     if (Lv.hashed)
-      idx = (cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u);
+      idx = ((cx * 1u) ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (Lv.size - 1u);
     else
-      idx = cx + cy * Lv.res + cz * Lv.res * Lv.res;
-    idx = idx % Lv.size + Lv.offset;
-    vals[c] = grid[idx];
+      idx = min(cx + cy * Lv.res + cz * Lv.res * Lv.res, Lv.size - 1u);
+    vals[c] = grid[idx + Lv.offset];
   }
   float f0 = 0.f, f1 = 0.f;
 #pragma unroll
@@ -345,10 +355,9 @@ __device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, f
 #pragma unroll
     for (int a = 0; a < 3; ++a) pos[a] = r.o[a] + t * r.d[a];
     dt = calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-    int e;
-    frexpf(dt * (float)kGrid, &e);
+    const int e = frexp_exp(dt * (float)kGrid);
     const int mip = min(P.cascades - 1, max(e, mip_from_pos(pos[0], pos[1], pos[2], P.cascades)));
-    const float msc = ldexpf(1.0f, -mip);
+    const float msc = pow2i(-mip);
     int ci[3];
     bool inside = true;
 #pragma unroll
@@ -362,7 +371,7 @@ __device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, f
                          (unsigned)mip * (unsigned)(kGrid * kGrid * kGrid);
     if (inside && ((P.occ[lin >> 3] >> (lin & 7u)) & 1u)) return true;
     // advance_to_next_voxel: step in dt increments past the cell border
-    const float res = ldexpf((float)kGrid, -mip);
+    const float res = pow2i(7 - mip), ires = pow2i(mip - 7);  // 128 / 2^mip cells per unit
     float tm = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -371,7 +380,7 @@ __device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, f
       const float tx = (floorf(p + 0.5f + 0.5f * sg) - p) * r.idir[a];
       if (r.d[a] != 0.f) tm = fminf(tm, tx);
     }
-    const float t_target = t + fmaxf(tm / res, 0.f);
+    const float t_target = t + fmaxf(tm * ires, 0.f);  // exact: res is a power of two
     do {
       t = t + calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
     } while (t < t_target);
