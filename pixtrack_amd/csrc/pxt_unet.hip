@@ -107,6 +107,12 @@ constexpr int kTH = 16, kTW = 16;        // output pixels per workgroup
 constexpr int kCK = 32;                  // input channels per staged chunk
 constexpr int kPix = 40;                 // padded halves per LDS pixel/filter row (80 B)
 constexpr int kHalo = (kTH + 2) * (kTW + 2);
+// LDS pitch of one halo row in halves: 768 (1536 B = 0 mod 256 B).  With the natural pitch
+// (18 px * 80 B = 1440 B) the two image rows a 16-lane ds_read_b128 group touches collide on
+// two 16-B slots (SQ_LDS_BANK_CONFLICT was 39 % of the LDS cycles); 1536 B makes them disjoint.
+constexpr int kRowPitch = 768;
+constexpr int kInHalves = (kTH + 2) * kRowPitch;
+constexpr int kHaloLoads = (kHalo * 4 + 255) / 256;  // 16-B staging loads per thread: halo
 
 template <int NT>  // output channels per workgroup = 32 * NT
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restrict__ in, int H,
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
   // partial[z][pixel][cout] and splitk_reduce_kernel finishes (fixed order: deterministic).
   constexpr int BNC = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) half_t smem[];
-  half_t* s_in = smem;                  // [kHalo][kPix]
-  half_t* s_w = smem + kHalo * kPix;    // [9][BNC][kPix]
+  half_t* s_in = smem;                  // [18 rows][kRowPitch], 18 pixels x kPix used per row
+  half_t* s_w = smem + kInHalves;       // [9][BNC][kPix]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -143,38 +149,60 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int ty = 4 * wave + 2 * p + (r31 >> 4), tx = r31 & 15;
-    p_off[p] = (ty * (kTW + 2) + tx) * kPix + 8 * khalf;
+    p_off[p] = ty * kRowPitch + tx * kPix + 8 * khalf;
   }
   const int w_off = r31 * kPix + 8 * khalf;
 
   const int n_chunks = Cin / kCK;
   const int per_z = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
   const int c_begin = (int)blockIdx.z * per_z * kCK, c_end = min(Cin, c_begin + per_z * kCK);
-  for (int c0 = c_begin; c0 < c_end; c0 += kCK) {
-    __syncthreads();
-    // stage the 18x18 halo of this channel chunk (zero outside the image)
-    for (int i = tid; i < kHalo * 4; i += 256) {
+  // Software pipeline (global -> registers -> LDS): the loads of chunk c+1 are issued right
+  // after chunk c has been written to LDS and stay in flight under chunk c's 72 MFMAs.
+  constexpr int kWTotal = 9 * BNC * 4;
+  constexpr int kWLoads = (kWTotal + 255) / 256;
+  half8 r_in[kHaloLoads], r_w[kWLoads];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < kHaloLoads; ++k) {
+      const int i = tid + 256 * k;
       const int pix = i >> 2, seg = i & 3;
       const int hy = pix / (kTW + 2), hx = pix % (kTW + 2);
       const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
       half8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+      if (i < kHalo * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W)
         v = *(const half8*)(in + ((size_t)gy * W + gx) * Cin + c0 + seg * 8);
-      *(half8*)(s_in + pix * kPix + seg * 8) = v;
+      r_in[k] = v;
     }
-    // stage the 9 taps of this chunk for the workgroup's output channels
-    for (int i = tid; i < 9 * BNC * 4; i += 256) {
+#pragma unroll
+    for (int k = 0; k < kWLoads; ++k) {
+      const int i = tid + 256 * k;
       const int row = i >> 2, seg = i & 3;
       const int t = row / BNC, n = row % BNC;
-      const half8 v = *(const half8*)(wts + ((size_t)(co0 + n) * 9 + t) * Cin + c0 + seg * 8);
-      *(half8*)(s_w + row * kPix + seg * 8) = v;
+      if (i < kWTotal) r_w[k] = *(const half8*)(wts + ((size_t)(co0 + n) * 9 + t) * Cin + c0 + seg * 8);
+    }
+  };
+  if (c_begin < c_end) prefetch(c_begin);
+  for (int c0 = c_begin; c0 < c_end; c0 += kCK) {
+    __syncthreads();  // every wave is done reading the previous chunk
+#pragma unroll
+    for (int k = 0; k < kHaloLoads; ++k) {
+      const int i = tid + 256 * k;
+      const int pix = i >> 2, seg = i & 3;
+      if (i < kHalo * 4)
+        *(half8*)(s_in + (pix / (kTW + 2)) * kRowPitch + (pix % (kTW + 2)) * kPix + seg * 8) = r_in[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kWLoads; ++k) {
+      const int i = tid + 256 * k;
+      if (i < kWTotal) *(half8*)(s_w + (i >> 2) * kPix + (i & 3) * 8) = r_w[k];
     }
     __syncthreads();
+    if (c0 + kCK < c_end) prefetch(c0 + kCK);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int tap_in = ((t / 3) * (kTW + 2) + (t % 3)) * kPix;
+      const int tap_in = (t / 3) * kRowPitch + (t % 3) * kPix;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         half8 b[2], a[NT];
@@ -464,9 +492,9 @@ void set_conv_lds_attr() {
   static bool done = false;
   if (done) return;
   hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)((kHalo * kPix + 9 * 64 * kPix) * sizeof(half_t)));
+                      (int)((kInHalves + 9 * 64 * kPix) * sizeof(half_t)));
   hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)((kHalo * kPix + 9 * 32 * kPix) * sizeof(half_t)));
+                      (int)((kInHalves + 9 * 32 * kPix) * sizeof(half_t)));
   done = true;
 }
 
@@ -479,11 +507,11 @@ int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out,
   const int nb = wide ? L.cout / 64 : L.cout / 32;
   const int splits = partial ? choose_splits(tiles, nb, L.cin / kCK) : 1;
   if (wide) {
-    const size_t lds = (size_t)(kHalo * kPix + 9 * 64 * kPix) * sizeof(half_t);
+    const size_t lds = (size_t)(kInHalves + 9 * 64 * kPix) * sizeof(half_t);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
                        L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
   } else {
-    const size_t lds = (size_t)(kHalo * kPix + 9 * 32 * kPix) * sizeof(half_t);
+    const size_t lds = (size_t)(kInHalves + 9 * 32 * kPix) * sizeof(half_t);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
                        L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
   }
