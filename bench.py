@@ -199,8 +199,19 @@ def main():
             c = np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1)
             rot_err.append(float(np.arccos(c)))
             tr_err.append(float(np.linalg.norm(tt - tg)))
+    # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes of this command
+    # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be taken live here)
+    traffic, traffic_src = None, None
+    pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+    if pmc.exists():
+        rec = json.loads(pmc.read_text()).get("pxt::ngp_encode_kernel")
+        if rec:
+            traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
     roofline = {"kernel": "ngp_encode_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_unit": "MB per launch", "traffic_source": traffic_src,
+                "algorithmic_mb_per_launch": round(samples_per_launch * NERF_BYTES_PER_SAMPLE / 1e6, 2),
                 "avg_launch_ms": round(enc_avg_ms, 5), "launches": enc_launches,
                 "samples_per_launch": round(samples_per_launch, 1), "bytes_per_sample": NERF_BYTES_PER_SAMPLE,
                 "samples_per_render": round(stats[0] / max(n_renders, 1), 1)}
