@@ -143,6 +143,7 @@ def main():
 
     timer = StageTimer()
     timer.wrap(tracker.testbed, "render_device", "nerf_render")
+    timer.wrap(tracker.testbed, "render_both_device", "nerf_render")
     timer.wrap(tracker.localizer.extractor.model, "forward_packed", "unet")
     timer.wrap(tracker.localizer.refiner, "refine_pose_using_features", "lm")
     timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")
@@ -231,7 +232,8 @@ def main():
         "config": {"workload": "configs[1]: premier_protein-style object, 640x480, full NeRF render + UNet + LM loop, "
                                "1 sequence per GPU", "width": args.width, "height": args.height, "spp": 8,
                    "n_points_per_reference": int(tracker.localizer.refiner._points_of(tracker.reference_ids)[1].shape[0]),
-                   "parallelism": f"{ws} independent sequence(s), 1 process/GPU, final RCCL all_gather of poses"},
+                   "parallelism": f"{ws} independent sequence(s), 1 process/GPU, final RCCL all_gather of poses",
+                   "mask_and_reference_render_fused": bool(tracker._views_coincide())},
         "tracked_ok": n_ok,
         "frames_total": total_frames,
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot_err)), 6) if rot_err else None,

@@ -200,6 +200,14 @@ typedef struct {
 int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
                    uint64_t* stats /* device, 4 counters or NULL */, void* stream);
 
+/* Shade AND Depth of the SAME view in one march: bit-for-bit what two pxt_ngp_render calls
+ * (mode 0, then mode 1) of this view produce, with the per-sample gathers and the density
+ * network evaluated once.  pixtrack renders the mask (Depth, query camera) and the reference
+ * image (Shade, SfM camera x reference_scale) at the same pose every frame
+ * (pixloc_tracker_r9.py:224,227); when those two cameras coincide the tracker uses this. */
+int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba, float* out_depth_rgba,
+                        uint64_t* stats, void* stream);
+
 /* Live HIP-event timing of the renderer's dominant kernel (ngp_encode_kernel), for the
  * roofline line of bench.py.  While enabled, every encode launch is bracketed by an event
  * pair recorded on the render's own stream.  pxt_ngp_timing_read synchronises those events,

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "pxt_ngp_create": (C.c_int, [C.POINTER(NgpModel), _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
     "pxt_ngp_destroy": (C.c_int, [_VP]),
     "pxt_ngp_render": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP]),
+    "pxt_ngp_render_both": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP, _VP]),
     "pxt_ngp_timing_enable": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_read": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),
     "pxt_ngp_query": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),

@@ -63,6 +63,7 @@ struct NgpParams {
   float min_T;
   int W, H, spp, mode;
   float* out;
+  float* out_depth;  // mode 2 only
   unsigned long long* stats;
 };
 
@@ -393,6 +394,7 @@ struct RayState {  // SoA, indexed by compact slot; two copies ping-pong between
   float* t;        // next lattice position
   float* T;        // transmittance so far
   float4* acc;     // premultiplied colour (or depth) + alpha so far
+  float* accd;     // mode 2 only: premultiplied depth so far
 };
 
 struct NgpWork {
@@ -404,7 +406,8 @@ struct NgpWork {
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
   uint8_t* keep;       // per slot: the ray continues into the next round (written by shade)
   float* cand_t;       // per enumerated ray: start t, or < 0 for rays that miss the box
-  float4* sppbuf;      // [spp][H][W] finished rays
+  float4* sppbuf;      // [pixel][spp] finished rays
+  float* sppbuf_d;     // mode 2: finished rays' depth
   size_t feat_stride;  // samples per level plane
 };
 
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const 
     if (enum_ray(P, i, px, py, s)) {
       const int pix = py * P.W + px;
       Wk.sppbuf[(size_t)pix * P.spp + s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      Wk.sppbuf_d[(size_t)pix * P.spp + s] = 0.f;
       const Ray r = make_ray(P, px, py);
       if (r.hit) {
         float t = fmaxf(r.tmin, 0.f) + 1e-6f;
@@ -509,11 +513,13 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
         D.t[dst] = Wk.cand_t[i];
         D.T[dst] = 1.f;
         D.acc[dst] = make_float4(0.f, 0.f, 0.f, 0.f);
+        D.accd[dst] = 0.f;
       } else {
         D.rid[dst] = S.rid[i];
         D.t[dst] = S.t[i];
         D.T[dst] = S.T[i];
         D.acc[dst] = S.acc[i];
+        D.accd[dst] = S.accd[i];
       }
       ++dst;
     }
@@ -577,7 +583,7 @@ __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, b
   Wk.sppbuf[rid] = acc;
 }
 
-template <bool DEPTH>
+template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
@@ -609,15 +615,14 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
       Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
     }
     float logit, rgbv[3];
-    ngp_mlp<DEPTH>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+    ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
     // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
     const float T0 = S.T[sl];
     float alpha = 0.f;
     if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
-    if (DEPTH) {
-      const float depth = (Wk.st_t[si] * r.zdot) * P.depth_scale;
-      rgbv[0] = rgbv[1] = rgbv[2] = depth;
-    }
+    float depth = 0.f;
+    if (MODE != 0) depth = (Wk.st_t[si] * r.zdot) * P.depth_scale;
+    if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
     // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
     float pinc = 1.0f - alpha;
 #pragma unroll
@@ -635,13 +640,14 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     const int k_term = grp ? (__ffs((int)grp) - 1) : 8;
     const bool contributes = valid && k <= k_term;
     const float wgt = contributes ? alpha * T_before : 0.f;
-    float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt;
+    float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt, cd = wgt * depth;
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) {
       cr += __shfl_xor(cr, m, 8);
       cg += __shfl_xor(cg, m, 8);
       cb += __shfl_xor(cb, m, 8);
       ca += __shfl_xor(ca, m, 8);
+      if (MODE == 2) cd += __shfl_xor(cd, m, 8);
     }
     if (contributes) n_samples += 1;
     // last valid sample's T_after (or the terminating one) is the ray's new transmittance
@@ -653,14 +659,18 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     if (k == 0 && ray_ok) {
       float4 acc = S.acc[slot];
       acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
+      float accd = 0.f;
+      if (MODE == 2) accd = S.accd[slot] + cd;
       const bool terminated = grp != 0;
       const bool exhausted = Wk.exhausted[slot] != 0;
       if (terminated || exhausted) {
+        if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
         finish_ray(Wk, rid, acc, terminated);
         Wk.keep[slot] = 0;
       } else {  // the compaction kernel moves the survivors into the next round's list
         S.T[slot] = T_new;
         S.acc[slot] = acc;
+        if (MODE == 2) S.accd[slot] = accd;
         Wk.keep[slot] = 1;
       }
     }
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
 }
 
 // Stragglers: wave = 64 live rays (lane = ray), fused march + encode + MLP per step until done.
-template <bool DEPTH>
+template <int MODE>
 __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
@@ -695,19 +705,22 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
     sh_fragments(r.d, shB0, shB1);
     float t = S.t[sl], T = S.T[sl];
     float4 acc = S.acc[sl];
+    float accd = (MODE == 2) ? S.accd[sl] : 0.f;
     bool terminated = false;
     while (__any(alive)) {
       float pos[3] = {0.5f, 0.5f, 0.5f}, dt = P.dt_lo;
       if (alive) alive = next_sample(P, r, t, pos, dt);
       if (!__any(alive)) break;
       float logit, rgbv[3];
-      ngp_eval<DEPTH>(P, s_w, lane, alive, (pos[0] - scene_lo) * inv_s, (pos[1] - scene_lo) * inv_s,
+      ngp_eval<MODE == 1>(P, s_w, lane, alive, (pos[0] - scene_lo) * inv_s, (pos[1] - scene_lo) * inv_s,
                       (pos[2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
       if (alive) {
         n_samples += 1;
-        if (DEPTH) rgbv[0] = rgbv[1] = rgbv[2] = (t * r.zdot) * P.depth_scale;
+        const float depth = (MODE != 0) ? (t * r.zdot) * P.depth_scale : 0.f;
+        if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
         const float alpha = 1.0f - expf(-expf(logit) * dt);
         const float wgt = alpha * T;
+        if (MODE == 2) accd += wgt * depth;
         acc.x += wgt * rgbv[0];
         acc.y += wgt * rgbv[1];
         acc.z += wgt * rgbv[2];
@@ -720,7 +733,10 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
         t = t + dt;
       }
     }
-    if (slot < n) finish_ray(Wk, rid, acc, terminated);
+    if (slot < n) {
+      if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
+      finish_ray(Wk, rid, acc, terminated);
+    }
   }
   if (P.stats) {
     for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
@@ -736,12 +752,23 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
   const int wh = P.W * P.H;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= wh) return;
-  float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f;
+  float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f, ad = 0.f;
   for (int s = 0; s < P.spp; ++s) {
     const float4 v = Wk.sppbuf[(size_t)pix * P.spp + s];
     ar += v.x; ag += v.y; ab += v.z; aa += v.w;
+    if (P.out_depth) ad += Wk.sppbuf_d[(size_t)pix * P.spp + s];
   }
   const float inv = 1.0f / (float)P.spp;
+  if (P.out_depth) {  // what a separate Depth-mode render would have written
+    float4 od;
+    od.w = aa * inv;
+    od.x = od.y = od.z = ad * inv;
+    od.x += P.bg[0] * P.bg[3] * (1.0f - od.w);
+    od.y += P.bg[1] * P.bg[3] * (1.0f - od.w);
+    od.z += P.bg[2] * P.bg[3] * (1.0f - od.w);
+    od.w = od.w + P.bg[3] * (1.0f - od.w);
+    *(float4*)(P.out_depth + 4 * (size_t)pix) = od;
+  }
   float4 o;
   o.w = aa * inv;
   o.x = ar * inv + P.bg[0] * P.bg[3] * (1.0f - o.w);
@@ -930,10 +957,12 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   const size_t samples = rays * kK;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
-  size_t o_rid[2], o_t[2], o_T[2], o_acc[2];
+  size_t o_rid[2], o_t[2], o_T[2], o_acc[2], o_accd[2];
   for (int i = 0; i < 2; ++i) {
     o_rid[i] = take(rays * 4); o_t[i] = take(rays * 4); o_T[i] = take(rays * 4); o_acc[i] = take(rays * 16);
+    o_accd[i] = take(rays * 4);
   }
+  const size_t o_sppd = take(rays * 4);
   const size_t o_cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
   const size_t o_spos = take(samples * 16), o_stt = take(samples * 4);
   const size_t o_feat = take(samples * 4 * kMaxLevels), o_exh = take(rays), o_spp = take(rays * 16);
@@ -945,6 +974,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   for (int i = 0; i < 2; ++i) {
     W.st[i].rid = (unsigned*)(b + o_rid[i]); W.st[i].t = (float*)(b + o_t[i]);
     W.st[i].T = (float*)(b + o_T[i]); W.st[i].acc = (float4*)(b + o_acc[i]);
+    W.st[i].accd = (float*)(b + o_accd[i]);
   }
   W.counters = (int*)(b + o_cnt);
   W.spos = (float4*)(b + o_spos);
@@ -952,6 +982,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   W.feat = (unsigned*)(b + o_feat);
   W.exhausted = (uint8_t*)(b + o_exh);
   W.sppbuf = (float4*)(b + o_spp);
+  W.sppbuf_d = (float*)(b + o_sppd);
   W.keep = (uint8_t*)(b + o_keep);
   W.cand_t = (float*)(b + o_cand);
   W.feat_stride = samples;
@@ -959,11 +990,10 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   return PXT_OK;
 }
 
-extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, uint64_t* stats,
-                              void* stream) {
+static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
+                       uint64_t* stats, void* stream) {
   if (!ctx || !v || !out_rgba) return PXT_E_ARG;
   if (v->width < 1 || v->height < 1 || v->spp < 1 || !(v->focal > 0.f)) return PXT_E_ARG;
-  if (v->mode != 0 && v->mode != 1) return PXT_E_ARG;
   NgpParams P;
   fill_model(ctx, P);
   for (int i = 0; i < 12; ++i) P.cam[i] = v->cam[i];
@@ -972,8 +1002,9 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
   for (int i = 0; i < 3; ++i) { P.lo[i] = v->aabb_min[i]; P.hi[i] = v->aabb_max[i]; }
   for (int i = 0; i < 4; ++i) P.bg[i] = v->background[i];
   P.min_T = v->min_transmittance;
-  P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = v->mode;
+  P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = mode;
   P.out = out_rgba;
+  P.out_depth = (mode == 2) ? out_depth : nullptr;
   P.stats = (unsigned long long*)stats;
   // padded to whole 4x2 pixel blocks (the enumeration order of ngp_init_kernel)
   const size_t rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
@@ -999,19 +1030,35 @@ extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rg
       PXT_HIP_CHECK(hipEventRecord(e1, s));
       ctx->events.emplace_back(e0, e1);
     }
-    if (v->mode == 1)
-      hipLaunchKernelGGL(ngp_shade_kernel<true>, dim3(wide), dim3(256), 0, s, P, Wk, r);
+    if (mode == 1)
+      hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(wide), dim3(256), 0, s, P, Wk, r);
+    else if (mode == 2)
+      hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(wide), dim3(256), 0, s, P, Wk, r);
     else
-      hipLaunchKernelGGL(ngp_shade_kernel<false>, dim3(wide), dim3(256), 0, s, P, Wk, r);
+      hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(wide), dim3(256), 0, s, P, Wk, r);
     hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(1024), dim3(256), 0, s, P, Wk, r);
   }
-  if (v->mode == 1)
-    hipLaunchKernelGGL(ngp_tail_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
+  if (mode == 1)
+    hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
+  else if (mode == 2)
+    hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
   else
-    hipLaunchKernelGGL(ngp_tail_kernel<false>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
+    hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
   hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s, P, Wk);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
+}
+
+extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, uint64_t* stats,
+                              void* stream) {
+  if (!v || (v->mode != 0 && v->mode != 1)) return PXT_E_ARG;
+  return render_impl(ctx, v, v->mode, out_rgba, nullptr, stats, stream);
+}
+
+extern "C" int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, float* out_depth_rgba,
+                                   uint64_t* stats, void* stream) {
+  if (!out_depth_rgba) return PXT_E_ARG;
+  return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream);
 }
 
 extern "C" int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable) {

@@ -224,6 +224,22 @@ class Testbed:
         self.n_renders += 1
         return out
 
+    def render_both_device(self, width: int, height: int, spp: int = 8):
+        """(Shade RGBA, Depth RGBA) of the current view from ONE march; each equals what
+        render_device returns in the corresponding render_mode, bit for bit."""
+        assert self._ctx is not None, "load_snapshot first"
+        if not self.snap_to_pixel_centers:
+            raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
+        rgba = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
+        depth = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
+        v = self._view(width, height, spp)
+        _lib.check(
+            _lib.lib().pxt_ngp_render_both(self._ctx, C.byref(v), rgba.data_ptr(), depth.data_ptr(),
+                                           _lib.dptr(self.stats_accum), _lib.stream_ptr(self.device)),
+            "pxt_ngp_render_both")
+        self.n_renders += 1
+        return rgba, depth
+
     def render(self, width: int, height: int, spp: int = 8, linear: bool = True) -> np.ndarray:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 

@@ -111,6 +111,11 @@ class PixLocPoseTrackerR9(PoseTracker):
         self.success = True
         self.camera = None
         self.spp = 8  # run_vis_on_poses.py:29
+        # The mask (Depth, query camera) and the reference image (Shade, SfM camera 1 x
+        # reference_scale) are rendered at the same pose each frame; when the two cameras coincide
+        # (same size and fx: all get_nerf_image reads) one march yields both, bit for bit.
+        self.fuse_identical_views = True
+        self._fused_reference = None  # (pose object, uint8 image) handed from get_mask to get_reference_image
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
 
     # ------------------------------------------------------------------ relocalisation
@@ -151,9 +156,22 @@ class PixLocPoseTrackerR9(PoseTracker):
     def _nerf_pose(self, pose):
         return sfm_to_nerf_pose(self.nerf2sfm, get_camera_in_world_from_pixpose(pose))
 
+    def _reference_camera(self):
+        return PixCamera.from_colmap(self.localizer.model3d.cameras[1]).scale(self.reference_scale)
+
+    def _views_coincide(self) -> bool:
+        if not self.fuse_identical_views or self.camera is None:
+            return False
+        a, b = self._reference_camera(), self.camera
+        return (int(a.size[0]), int(a.size[1]), float(a.f[0])) == (int(b.size[0]), int(b.size[1]), float(b.f[0]))
+
     def get_reference_image(self, pose) -> torch.Tensor:
         """uint8 [H,W,3] NeRF render at ``pose`` with SfM camera 1 scaled by reference_scale."""
-        ref_camera = PixCamera.from_colmap(self.localizer.model3d.cameras[1]).scale(self.reference_scale)
+        if self._fused_reference is not None and self._fused_reference[0] is pose:
+            img = self._fused_reference[1]
+            self._fused_reference = None
+            return img
+        ref_camera = self._reference_camera()
         rgba = get_nerf_image_device(self.testbed, self._nerf_pose(pose), ref_camera, spp=self.spp)
         return rgba_to_u8(rgba, 0.0)
 
@@ -185,7 +203,16 @@ class PixLocPoseTrackerR9(PoseTracker):
 
     def get_mask(self, pose) -> torch.Tensor:
         """uint8 [H,W] on the device: depth render != 0, erode 5x5 x1, dilate 5x5 x5."""
-        depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp)
+        if self._views_coincide():
+            import math
+
+            cam = self.camera
+            self.testbed.fov = math.atan(int(cam.size[0]) / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
+            self.testbed.set_nerf_camera_matrix(np.asarray(self._nerf_pose(pose))[:3, :])
+            rgba, depth = self.testbed.render_both_device(int(cam.size[0]), int(cam.size[1]), self.spp)
+            self._fused_reference = (pose, rgba_to_u8(rgba, 0.0))
+        else:
+            depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp)
         H, W = int(depth.shape[0]), int(depth.shape[1])
         mask = torch.empty(H, W, dtype=torch.uint8, device=self.device)
         tmp = torch.empty(2 * H * W, dtype=torch.uint8, device=self.device)

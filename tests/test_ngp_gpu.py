@@ -144,3 +144,19 @@ def test_network_query_matches_oracle(device, snap):
     got = out.cpu().numpy()
     assert np.abs(got[:, 0] - np.log(den)).max() < 5e-3
     assert np.abs(got[:, 1:] - rgb).max() < 5e-3
+
+
+def test_render_both_equals_two_renders(device, snap):
+    """One march producing Shade and Depth == the two separate renders, bit for bit."""
+    tb = make_testbed(snap, device)
+    tb._cam_ngp = ngp_camera((0.9, 0.5, 0.3), 1.2)
+    tb.fov = 45.0
+    W, H, spp = 72, 50, 3
+    tb.render_mode = RenderMode.Shade
+    a = tb.render_device(W, H, spp, True)
+    tb.render_mode = RenderMode.Depth
+    b = tb.render_device(W, H, spp, True)
+    tb.render_mode = RenderMode.Shade
+    c, d = tb.render_both_device(W, H, spp)
+    assert torch.equal(a, c) and torch.equal(b, d)
+    assert float(b[..., 0].max()) > 0
