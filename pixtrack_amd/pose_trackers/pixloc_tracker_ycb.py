@@ -1,0 +1,127 @@
+"""PixLocPoseTrackerYCB -- the YCB-Video policy variant (reference
+pixtrack/pose_trackers/pixloc_tracker_ycb.py:37-345).  Same kernels as r9,
+different host policy:
+
+* ground-truth pose and camera initialise the track and re-initialise it after a failure
+  (`relocalize`, :101-115); the reference image is the nearest of ALL covisibility keys by
+  rotation (`set_reference_ids`, :117-130);
+* the query is masked EVERY frame (:249-250), image scales stay [1] (:57-59),
+  `reference_scale = 0.3` (:89);
+* success = optimiser success AND t_err < 10 cm AND r_err < 10 deg, where the error is that
+  of `self.pose` BEFORE this frame's update (:280-290, :297-303); `ret["gt_pose"]` is kept.
+
+Frames are (path, image, gt_pose: Pose, gt_camera: Camera) tuples (reference
+pixtrack/utils/io.py:13-72 `YCBVideoIterator`).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+from ..geometry import Pose
+from ..tracker import DebugTracker
+from ..utils.pose_utils import geodesic_distance_for_rotations
+from .pixloc_tracker_r9 import PixLocPoseTrackerR9
+
+
+class GTFrameIterator:
+    """In-memory stand-in for YCBVideoIterator: yields (path, image, gt_pose, gt_camera)."""
+
+    def __init__(self, names, images, gt_poses, camera):
+        self.names, self.images, self.gt_poses, self.camera = list(names), list(images), list(gt_poses), camera
+        self.idx = 0
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return len(self.names)
+
+    def __next__(self):
+        if self.idx > len(self) - 1:
+            raise StopIteration
+        i = self.idx
+        self.idx += 1
+        return self.names[i], self.images[i], self.gt_poses[i], self.camera
+
+
+class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
+    def __init__(self, data_path, loc_path, eval_path, object_path, debug=False, device=None, assets=None):
+        super().__init__(object_path, data_path, loc_path, eval_path, debug=int(debug), device=device, assets=assets)
+        self.reference_scale = 0.3
+        self.localizer.refiner.reference_scale = self.reference_scale
+        self.localizer.refiner.conf.multiscale = [1]
+        self.reference_ids = None
+        self.gt_pose = None
+        self.gt_camera = None
+        self.t_err = self.r_err = float("nan")
+
+    def relocalize(self, query_path):
+        if self.cold_start:
+            self.camera = self.gt_camera
+            self.cold_start = False
+        self.pose = self.gt_pose
+        self.set_reference_ids()
+        self.relocalization_count += 1
+
+    def set_reference_ids(self):
+        R_qry = self.pose.numpy()[0]
+        dbs = self.localizer.model3d.dbs
+        gdists = {ref: geodesic_distance_for_rotations(R_qry, dbs[ref].qvec2rotmat()) for ref in self.covis}
+        self.reference_ids = sorted(gdists, key=lambda x: gdists[x])[:1]
+        return self.reference_ids
+
+    def refine(self, query):
+        query_path, query_image, gt_pose, gt_camera = query
+        self.gt_pose, self.gt_camera = gt_pose, gt_camera
+        refiner = self.localizer.refiner
+        if self.cold_start:
+            self.relocalize(query_path)
+            self.cold_start = False
+        refiner.query_mask = self.get_mask(self.pose)  # every frame
+
+        self.dynamic_id = self.get_dynamic_id(self.pose)
+        rotation, translation = self.pose.numpy()
+        rotation = R.from_matrix(rotation).as_matrix()
+        trackers, rets, costs = {}, {}, {}
+        for ref_id in self.reference_ids:
+            pose_init = Pose.from_Rt(rotation, translation)
+            tracker = DebugTracker(refiner, self.debug)
+            ret = self.localizer.run_query(query_path, self.camera, pose_init, [ref_id], image_query=query_image,
+                                           pose=self.pose, reference_images_raw=None, dynamic_id=self.dynamic_id)
+            rets[ref_id], trackers[ref_id] = ret, tracker
+            last = [c[-1] for res in refiner.last_lm for c in res.costs if len(c)]
+            costs[ref_id] = float(np.mean(last)) if last else float("nan")
+        best_ref_id = min(costs, key=costs.get)
+        ret = rets[best_ref_id]
+        self.calculate_error()
+        ret["camera"] = self.camera
+        ret["reference_ids"] = self.reference_ids
+        ret["query_path"] = query_path
+        ret["gt_pose"] = gt_pose
+        ret["cost"] = costs[best_ref_id]
+        success = bool(ret["success"] and self.t_err < 10 and self.r_err < 10)
+        if success:
+            self.pose = ret["T_refined"]
+        ret["success"] = success
+        self.success = success
+        img_name = os.path.basename(str(query_path))
+        self.pose_history[img_name] = ret
+        self.pose_tracker_history[img_name] = trackers[best_ref_id]
+        return success
+
+    def calculate_error(self):
+        gt_R, gt_T = self.gt_pose.numpy()
+        pr_R, pr_T = self.pose.numpy()
+        self.t_err = float(np.linalg.norm(gt_T - pr_T) * 100.0)
+        self.r_err = float(geodesic_distance_for_rotations(gt_R, pr_R) * 180 / np.pi)
+        if hasattr(self, "pbar") and hasattr(self.pbar, "set_description"):
+            self.pbar.set_description(f"Translation error: {self.t_err:.2f}cm, Rotation error: {self.r_err:.2f} degrees, "
+                                      f"relocalizations: {self.relocalization_count}")
+
+    def get_query_frame_iterator(self, path, max_frames):
+        if isinstance(path, GTFrameIterator):
+            return path
+        raise NotImplementedError("the ycbvideo dataset loader is not part of this build; pass a GTFrameIterator")

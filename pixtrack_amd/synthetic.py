@@ -342,7 +342,7 @@ def surface_points(rng, n: int, aabb, level: float = 0.12):
 def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, n_frames: int = 200,
                          aabb=PREMIER_PROTEIN_AABB, n_points: int = 5600, n_refs: int = 16,
                          step_deg: float = 0.5, jitter_deg: float = 0.3, jitter_trans: float = 0.003,
-                         unet_seed: int = 7):
+                         unet_seed: int = 7, reference_scale: float = 0.5):
     """Returns the dict PixLocPoseTrackerR9(assets=...) consumes plus 'gt_poses' [(R, t)] and
     'query_camera' (COLMAP dict).  All seeded."""
     from .model3d import Model3D
@@ -362,8 +362,9 @@ def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, 
     f_q = 1.2 * max(width, height)
     dist = f_q * extent / (0.5 * min(width, height))
 
-    # reference (mapping) cameras: one COLMAP camera of twice the query resolution
-    Wr, Hr = 2 * width, 2 * height
+    # reference (mapping) cameras: one COLMAP camera whose size x reference_scale is the query size
+    # ("reference camera 2x query resolution x reference_scale 0.5"; 1/0.3 for the YCB policy)
+    Wr, Hr = int(round(width / reference_scale)), int(round(height / reference_scale))
     cameras = {1: ColmapCamera(1, "SIMPLE_RADIAL", Wr, Hr, np.array([1.2 * max(Wr, Hr), Wr / 2.0, Hr / 2.0, 0.0]))}
     up_axis = np.array([0.0, 0.0, 1.0])  # sfm z is the object's long axis (ngp -y ... +y)
     images, obs = {}, {i: [] for i in range(n_points)}

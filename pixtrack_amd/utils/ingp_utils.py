@@ -59,3 +59,30 @@ def nerf_to_sfm_pose(nerf2sfm, nerf_pose: np.ndarray) -> np.ndarray:
     p[2, :] *= -1
     p = p[[1, 0, 2, 3], :]
     return p @ _FLIP_YZ
+
+
+def get_nerf_aabb_from_sfm(model3d, nerf2sfm):
+    """Render box for the YCB policy (reference ingp_utils.py:86-109, used at
+    pixloc_tracker_ycb.py:92): SfM points mapped into NeRF coordinates, DBSCAN(eps 0.1, min 2)
+    fitted as the reference does, box = min/max over ALL points (the reference computes the
+    cluster extremes but returns the global ones), converted to ngp's unit cube (/3 + 0.5) with
+    the (y, z, x) axis cycle."""
+    from sklearn.cluster import DBSCAN
+
+    if not isinstance(nerf2sfm, dict):
+        nerf2sfm = load_nerf2sfm(nerf2sfm)
+    pts = []
+    for p in model3d.points3D.values():
+        T = np.eye(4)
+        T[:3, -1] = p.xyz
+        pts.append(sfm_to_nerf_pose(nerf2sfm, T)[:3, -1])
+    pts = np.array(pts)
+    DBSCAN(eps=0.1, min_samples=2).fit(pts)
+    lo = pts.min(axis=0) / 3.0 + 0.5
+    hi = pts.max(axis=0) / 3.0 + 0.5
+    return [[lo[1], lo[2], lo[0]], [hi[1], hi[2], hi[0]]]
+
+
+def get_object_center_from_sfm(model3d):
+    """Mean of the SfM points (reference ingp_utils.py:112-116)."""
+    return np.mean(np.array([p.xyz for p in model3d.points3D.values()]), axis=0)

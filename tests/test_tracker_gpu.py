@@ -98,3 +98,38 @@ def test_failed_frame_keeps_pose_and_drops_mask(tracked):
     ok = tr.refine(("after_fail.png", frames[-1]))  # Appendix D.3: no mask after a failed frame
     assert tr.localizer.refiner.query_mask is None
     assert ok
+
+
+def test_ycb_policy_tracker(device):
+    """BASELINE configs[2] policy (reference pixloc_tracker_ycb.py): GT init / re-init, mask every
+    frame, reference_scale 0.3 (mask and reference cameras differ -> two separate renders),
+    success gated on the error vs GT of the pose BEFORE the update."""
+    from pixtrack_amd.geometry import Camera, Pose
+    from pixtrack_amd.pose_trackers.pixloc_tracker_ycb import GTFrameIterator, PixLocPoseTrackerYCB
+    from pixtrack_amd.synthetic import CRACKER_BOX_AABB
+
+    assets = make_tracking_assets(seed=1021, width=192, height=144, n_frames=4, n_points=3000,
+                                  aabb=[[0.25, 0.2, 0.3], [0.75, 0.8, 0.7]], reference_scale=0.3)
+    tr = PixLocPoseTrackerYCB("", "", "/tmp", "", debug=True, device=device, assets=assets)
+    tr.spp = 2
+    tr.fuse_identical_views = False  # exercise the two-render path (mask + reference separately)
+    frames = render_query_frames(assets, tr.testbed)
+    f, w, h = assets["query_camera"]["params"][0], assets["width"], assets["height"]
+    cam = Camera.from_colmap(dict(model="OPENCV", width=w, height=h, params=np.array([f, f, w / 2.0, h / 2.0, 0, 0, 0, 0.0])))
+    gts = [Pose.from_Rt(R, t) for R, t in assets["gt_poses"]]
+    it = GTFrameIterator([f"{i:06d}-color.png" for i in range(4)], frames, gts, cam)
+    tr.run(it)
+    assert tr.relocalization_count == 1  # the cold start only
+    assert not tr._views_coincide()
+    assert tr.misses == 3
+    for i in range(4):
+        ret = tr.pose_history[f"{i:06d}-color.png"]
+        assert ret["success"] and "gt_pose" in ret
+        Rr, tt = ret["T_refined"].numpy()
+        Rg, tg = assets["gt_poses"][i]
+        assert geodesic_distance_for_rotations(Rr, Rg) < 2e-2 and np.linalg.norm(tt - tg) < 2e-2
+    # a wrong GT by more than 10 degrees makes the frame fail and triggers a GT re-initialisation
+    bad = Pose.from_Rt(assets["gt_poses"][3][0] @ np.array([[0.94, -0.34, 0], [0.34, 0.94, 0], [0, 0, 1.0]]), assets["gt_poses"][3][1])
+    it2 = GTFrameIterator(["bad-color.png"], [frames[3]], [bad], cam)
+    tr.run(it2)
+    assert not tr.pose_history["bad-color.png"]["success"] and tr.relocalization_count == 2
