@@ -65,7 +65,8 @@ def cpu_baseline(assets, frames, start_pose, ref_id):
     from oracle import lm_oracle as LO
     from oracle import ngp_oracle as NO
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 16-32 threads are the sweet spot of torch-CPU convs on the 2 x 64-core host (256 threads: 35x slower)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     R, t = start_pose
     img = frames[1].cpu().numpy()
     tm = {}
