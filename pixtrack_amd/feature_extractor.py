@@ -50,7 +50,7 @@ class PixTrackFeatureExtractor:
         return image.to(self.device).contiguous()
 
     def extract_packed(self, image, scale_image: int = 1, mask: Optional[torch.Tensor] = None,
-                       normalize: bool = False, ws_slot: int = 0):
+                       normalize: bool = False):
         """-> (maps [h,w,cstride] x3 on device, scales [(sx,sy)] x3)."""
         img = self._to_device_hwc(image)
         H, W = int(img.shape[0]), int(img.shape[1])
@@ -64,7 +64,7 @@ class PixTrackFeatureExtractor:
             _lib.check(_lib.lib().pxt_resize_linear(src.data_ptr(), H, W, 3, dst.data_ptr(), h_new, w_new,
                                                     _lib.stream_ptr(self.device)), "pxt_resize_linear")
             img = dst
-        maps = self.model.forward_packed(img, mask, normalize=normalize, ws_slot=ws_slot)
+        maps = self.model.forward_packed(img, mask, normalize=normalize)
         scales = [(scale_resize[0] / s, scale_resize[1] / s) for s in self.model.scales]
         return maps, scales
 

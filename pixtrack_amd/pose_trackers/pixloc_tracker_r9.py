@@ -115,7 +115,6 @@ class PixLocPoseTrackerR9(PoseTracker):
         # reference_scale) are rendered at the same pose each frame; when the two cameras coincide
         # (same size and fx: all get_nerf_image reads) one march yields both, bit for bit.
         self.fuse_identical_views = True
-        self.overlap_query_unet = True
         self._fused_reference = None  # (pose object, uint8 image) handed from get_mask to get_reference_image
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
 
@@ -233,8 +232,6 @@ class PixLocPoseTrackerR9(PoseTracker):
         elif self.success:
             refiner.conf.multiscale = [1]
             refiner.query_mask = self.get_mask(self.pose)  # multiplied inside the first conv
-            if self.overlap_query_unet and torch.is_tensor(query_image) and query_image.is_cuda:
-                refiner.prefetch_query_features(query_image, 1)  # side stream, overlaps the reference UNet
 
         self.dynamic_id = self.get_dynamic_id(self.pose)
         rotation, translation = self.pose.numpy()

@@ -95,10 +95,6 @@ class PoseTrackerRefiner:
         self._p3d_cache: Dict[int, Tuple[List[int], torch.Tensor]] = {}
         self._ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=self.device)
         self.last_lm = []  # LMResult per image scale of the last refine (costs for the tracker gate)
-        # The query pyramid does not depend on the reference render's pyramid: it is enqueued on a
-        # second HIP stream so the small layers of the two UNets overlap on the 256 CUs.
-        self._side_stream = torch.cuda.Stream(device=self.device)
-        self._query_prefetch = None  # (image object, scale, mask object, maps, scales, event)
 
     # ---- logging hooks (pixloc BaseRefiner) -----------------------------------
     def log_dense(self, **kwargs):
@@ -123,27 +119,8 @@ class PoseTrackerRefiner:
         return self._p3d_cache[key]
 
     # ---- dense features ----------------------------------------------------------
-    def prefetch_query_features(self, image, image_scale: int = 1):
-        """Enqueue the (masked, normalised) query pyramid on the side stream; refine_query_pose
-        picks it up if it is asked for the same image / scale / mask objects."""
-        main = torch.cuda.current_stream(self.device)
-        self._side_stream.wait_stream(main)  # the mask (and the image) are produced on the main stream
-        with torch.cuda.stream(self._side_stream):
-            maps, scales = self.feature_extractor.extract_packed(image, image_scale, self.query_mask, True, ws_slot=1)
-            ev = torch.cuda.Event()
-            ev.record(self._side_stream)
-        self._query_prefetch = (image, image_scale, self.query_mask, maps, scales, ev)
-
     def dense_feature_extraction(self, image, name: str, image_scale: int = 1, mask=None, normalize=False):
         """-> (HWC maps [h,w,cstride] x3 with the confidence as channel C, scales)."""
-        pf = self._query_prefetch
-        if pf is not None and pf[0] is image and pf[1] == image_scale and pf[2] is mask and normalize:
-            self._query_prefetch = None
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(pf[5])
-            for m in pf[3]:
-                m.record_stream(main)  # allocated on the side stream, consumed on the main one
-            return pf[3], pf[4]
         maps, scales = self.feature_extractor.extract_packed(image, image_scale, mask, normalize)
         if self.tracker is not None and getattr(self.tracker, "debug", 0) >= 2:
             feats = [m[..., :c].permute(2, 0, 1) for m, c in zip(maps, OUTPUT_DIMS)]

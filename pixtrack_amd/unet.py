@@ -182,7 +182,7 @@ class UNet:
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().pxt_unet_create(blob, len(blob), C.byref(self._ctx)), "pxt_unet_create")
-        self._ws: Dict[int, torch.Tensor] = {}  # one scratch per concurrent forward (ws_slot)
+        self._ws: Optional[torch.Tensor] = None
 
     def __del__(self):
         try:
@@ -215,7 +215,7 @@ class UNet:
         return [dec[3], dec[1], (hs[4], ws[4])]  # strides 1, 4, 16
 
     def forward_packed(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                       normalize: bool = False, ws_slot: int = 0) -> List[torch.Tensor]:
+                       normalize: bool = False) -> List[torch.Tensor]:
         """image: HWC, 3 channels, 0..255, float32 or uint8, on the device.  Returns the
         three HWC float32 maps [h,w,cstride] (descriptor channels then confidence)."""
         L = _lib.lib()
@@ -226,9 +226,8 @@ class UNet:
         need = int(L.pxt_unet_workspace_bytes(self._ctx, H, W))
         if need <= 0:
             raise _lib.PxtError(f"image {H}x{W} too small for the 4-level encoder")
-        ws = self._ws.get(ws_slot)
-        if ws is None or ws.numel() < need:
-            ws = self._ws[ws_slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         shapes = self.level_shapes(H, W)
         outs = [torch.empty(h, w, cstride_for(c), device=self.device, dtype=torch.float32)
                 for (h, w), c in zip(shapes, OUTPUT_DIMS)]
@@ -238,7 +237,7 @@ class UNet:
             assert mask.dtype == torch.uint8 and mask.shape == (H, W) and mask.is_contiguous()
         _lib.check(
             L.pxt_unet_forward(self._ctx, image.data_ptr(), int(image.dtype == torch.uint8), _lib.dptr(mask),
-                               H, W, ptrs, cs, int(normalize), ws.data_ptr(), _lib.stream_ptr(self.device)),
+                               H, W, ptrs, cs, int(normalize), self._ws.data_ptr(), _lib.stream_ptr(self.device)),
             "pxt_unet_forward",
         )
         return outs
