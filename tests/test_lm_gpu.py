@@ -189,3 +189,24 @@ def test_sample_sparse_matches_oracle(device):
         exp_f = O.l2_normalize(obs_ref[l][:, :Cc], dim=1)
         assert torch.allclose(got[v, :Cc], exp_f[v], atol=2e-5)
         assert torch.allclose(got[v, Cc], obs_ref[l][v, Cc], atol=2e-5)
+
+
+def test_config5_sized_problem(device):
+    """BASELINE configs[4] sizes: N = 10 000 points against 1024x576 maps (a 1920x1080 query after
+    the extractor's resize): same parity bar, and every workgroup count stays deterministic."""
+    sc = make_lm_scene(seed=1008, width=1024, height=576, n_points=10000, sigma_px=2.0)
+    lam = lambdas(CONSTS)
+    ref = O.refine_pose_using_features(
+        sc.feats_query, sc.scales, sc.camera._data, torch.from_numpy(sc.R_init), torch.from_numpy(sc.t_init),
+        sc.feats_ref, torch.from_numpy(sc.p3d), lam, O.LMConf())
+    opt = PixTrackOptimizer(dict(num_iters=150, pad=1))
+    packs = []
+    for level in reversed(range(3)):
+        fmap, fref, Cc, cam = pack_level(sc, level, device, sc.camera)
+        packs.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    res = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws).result()
+    assert ref["success"] and not res.failed
+    assert O.rotation_angle_rad(res.T.R.double(), ref["R"]) < ROT_TOL
+    assert float((res.T.t.double() - ref["t"]).norm()) < TRANS_TOL

@@ -100,3 +100,8 @@ def test_unet_module_call_convention(device):
         assert pred["confidences"][k].shape == (1,) + tuple(confs[k].shape)
         cos = F.cosine_similarity(pred["feature_maps"][k][0].cpu(), feats[k], dim=0)
         assert cos.min().item() > 0.9995
+
+
+def test_unet_config5_resolution(device):
+    """1024x576 (what a 1920x1080 query becomes after the extractor's resize)."""
+    _compare_pyramid(device, 576, 1024, normalize=True, seed=9, bn_trivial=True)
