@@ -86,15 +86,15 @@ def save_snapshot(path: str, snap: NerfSnapshot) -> None:
 
 
 def load_snapshot_file(path: str) -> NerfSnapshot:
+    """Reads ``weights.msgpack``: this package's own container (save_snapshot) or an instant-ngp
+    snapshot (``snapshot.params_binary``; see from_instant_ngp)."""
     import msgpack
 
     with open(path, "rb") as f:
-        d = msgpack.unpackb(f.read(), raw=False)
+        d = msgpack.unpackb(f.read(), raw=False, strict_map_key=False)
     enc, s = d["encoding"], d["snapshot"]
     if "grid_binary" not in s:
-        raise _lib.PxtError(
-            "this is not a pixtrack_amd snapshot (instant-ngp's params_binary layout is not "
-            "wired up yet: SURVEY.md section 8f rank 2)")
+        return from_instant_ngp(d)
     nerf = s["nerf"]
     return NerfSnapshot(
         grid=np.frombuffer(s["grid_binary"], np.float16).reshape(-1, enc["n_features_per_level"]).copy(),
@@ -105,6 +105,150 @@ def load_snapshot_file(path: str) -> NerfSnapshot:
         aabb_scale=nerf["aabb_scale"], cone_angle=nerf["cone_angle_constant"], scale=nerf["dataset"]["scale"],
         offset=nerf["dataset"]["offset"][0], k1=nerf["dataset"].get("k1", 0.0),
     )
+
+
+# ---------------------------------------------------------------------------------------------
+# instant-ngp's own snapshot layout (reference ingp_utils.py:27 load_snapshot
+# of `instant-ngp/snapshots/weights.msgpack`).  instant-ngp (NVlabs/instant-ngp @ b551bf1, an
+# un-vendored submodule: .gitmodules:7-11) is absent from the reference tree and no real snapshot
+# exists here, so this follows its published layout from recall and is UNVERIFIED against a real
+# file; the round trip through to_instant_ngp below is what the tests pin.
+#
+#   snapshot.params_binary : fp16 [n_params] = density MLP | rgb MLP | hash grid (| dir enc: none)
+#       MLP matrices row-major [out][in]: 64x32, 16x64 | 64x32, 64x64, 16x64 (tiny-cuda-nn
+#       FullyFusedMLP); rgb input = density outputs (16) then SH (16); grid = levels
+#       concatenated, F halves per entry (tiny-cuda-nn GridEncoding) -> 13,074,912 in total.
+#   snapshot.density_grid_binary : [cascades][128^3] density per cell in Morton order (x bit 0),
+#       fp16 or fp32 by byte count; occupancy bit = density > min(0.01, mean over cascade 0),
+#       then each coarser cascade ORs in the 2x2x2 max-pool of the finer one over its centre
+#       half (instant-ngp update_density_grid_mean_and_bitfield / bitfield_max_pool).
+#   snapshot.nerf.dataset.{scale, offset, aabb_scale, metadata[0].camera_distortion}
+_NGP_GRID = 128
+_NGP_MIN_OPTICAL_THICKNESS = 0.01
+_MLP_PARAMS = sum(r * c for _, r, c in MLP_SHAPES)
+
+
+def _morton_index_table() -> np.ndarray:
+    """morton[z, y, x] for a 128^3 grid: bit i of x -> bit 3i, y -> 3i+1, z -> 3i+2."""
+    def spread(v):
+        out = np.zeros_like(v)
+        for i in range(7):
+            out |= ((v >> i) & 1) << (3 * i)
+        return out
+
+    a = spread(np.arange(_NGP_GRID, dtype=np.int64))
+    return (a[None, None, :]) | (a[None, :, None] << 1) | (a[:, None, None] << 2)
+
+
+def _grid_entries(n_levels, log2_hashmap, base_res, per_level_scale) -> int:
+    total, T = 0, 1 << log2_hashmap
+    for l in range(n_levels):
+        scale = 2.0 ** (l * math.log2(per_level_scale)) * base_res - 1.0
+        res = int(math.ceil(scale)) + 1
+        n = min(res**3, T)
+        total += min((n + 7) // 8 * 8, T)
+    return total
+
+
+def occupancy_from_density_grid(density: np.ndarray) -> np.ndarray:
+    """density: float [cascades, 128^3] in Morton order -> uint8 bitfield, x fastest."""
+    cascades = density.shape[0]
+    morton = _morton_index_table().reshape(-1)
+    mean = float(np.maximum(density[0].astype(np.float64), 0.0).mean())
+    thresh = min(_NGP_MIN_OPTICAL_THICKNESS, mean)
+    G, h, q = _NGP_GRID, _NGP_GRID // 2, _NGP_GRID // 4
+    levels = []
+    for c in range(cascades):
+        occ = (density[c].astype(np.float32)[morton] > thresh).reshape(G, G, G)  # [z, y, x]
+        if c > 0:
+            pooled = levels[-1].reshape(h, 2, h, 2, h, 2).any(axis=(1, 3, 5))
+            occ[q:q + h, q:q + h, q:q + h] |= pooled
+        levels.append(occ)
+    bits = np.stack(levels).reshape(-1)
+    return np.packbits(bits, bitorder="little")
+
+
+def from_instant_ngp(d: Dict) -> NerfSnapshot:
+    """Unpacked instant-ngp snapshot dict -> NerfSnapshot (layout in the comment above)."""
+    enc, s = d["encoding"], d["snapshot"]
+    if enc.get("otype", "HashGrid") != "HashGrid":
+        raise _lib.PxtError(f"unsupported position encoding {enc.get('otype')!r}: the renderer implements HashGrid")
+    net, rgb = d.get("network", {}), d.get("rgb_network", {})
+    if (net.get("n_neurons", 64), net.get("n_hidden_layers", 1), rgb.get("n_neurons", 64),
+            rgb.get("n_hidden_layers", 2)) != (64, 1, 64, 2):
+        raise _lib.PxtError("unsupported MLP shape: the renderer implements 64-wide 1+2 hidden layer networks "
+                            "(instant-ngp configs/nerf/base.json)")
+    if s.get("params_type", "__half") != "__half":
+        raise _lib.PxtError(f"unsupported params_type {s.get('params_type')!r} (expected __half)")
+    nerf = s.get("nerf", {})
+    ds = nerf.get("dataset", {})
+    aabb_scale = float(ds.get("aabb_scale", nerf.get("aabb_scale", 1)))
+    n_levels, F = int(enc.get("n_levels", 16)), int(enc.get("n_features_per_level", 2))
+    log2_T, base = int(enc.get("log2_hashmap_size", 19)), int(enc.get("base_resolution", 16))
+    pls = float(enc.get("per_level_scale", 0.0))
+    if pls <= 0.0:  # instant-ngp derives it from desired_resolution (2048) x aabb_scale
+        desired = float(enc.get("desired_resolution", 2048.0))
+        pls = math.exp(math.log(desired * aabb_scale / base) / (n_levels - 1))
+    params = np.frombuffer(s["params_binary"], np.float16)
+    n_grid = _grid_entries(n_levels, log2_T, base, pls) * F
+    if params.size != _MLP_PARAMS + n_grid:
+        raise _lib.PxtError(f"params_binary holds {params.size} values; expected {_MLP_PARAMS} MLP + {n_grid} "
+                            "hash-grid values for this encoding config")
+    cells = _NGP_GRID**3
+    raw = s["density_grid_binary"]
+    expect_c = int(round(math.log2(max(aabb_scale, 1.0)))) + 1
+    for c, dt in ((expect_c, np.float16), (expect_c, np.float32), (8, np.float16), (8, np.float32)):
+        if len(raw) == c * cells * np.dtype(dt).itemsize:
+            density = np.frombuffer(raw, dt).reshape(c, cells)[:expect_c]
+            break
+    else:
+        raise _lib.PxtError(f"density_grid_binary has {len(raw)} bytes: not [cascades][128^3] fp16/fp32")
+    offset = ds.get("offset", [0.5, 0.5, 0.5])
+    if max(offset) != min(offset):
+        raise _lib.PxtError(f"per-axis dataset offset {offset} is not supported")
+    k1 = 0.0
+    meta = ds.get("metadata") or []
+    if meta and isinstance(meta[0], dict):
+        cd = meta[0].get("camera_distortion") or meta[0].get("lens") or {}
+        prm = cd.get("params") or [0.0]
+        k1 = float(prm[0]) if int(cd.get("mode", 1)) == 1 else 0.0  # 1 = Iso (radial k1, k2, p1, p2)
+    return NerfSnapshot(
+        grid=params[_MLP_PARAMS:].reshape(-1, F).copy(), mlp=params[:_MLP_PARAMS].copy(),
+        occupancy=occupancy_from_density_grid(density), n_levels=n_levels, n_features=F, log2_hashmap=log2_T,
+        base_res=base, per_level_scale=pls, cascades=expect_c, aabb_scale=aabb_scale,
+        cone_angle=0.0 if aabb_scale <= 1.0 else 1.0 / 256.0, scale=float(ds.get("scale", 0.33)),
+        offset=float(offset[0]), k1=k1)
+
+
+def to_instant_ngp(snap: NerfSnapshot) -> Dict:
+    """NerfSnapshot -> dict in instant-ngp's snapshot layout (inverse of from_instant_ngp up to
+    the density values: occupied cells get density 1, free cells 0)."""
+    cells = _NGP_GRID**3
+    bits = np.unpackbits(snap.occupancy, bitorder="little")[: snap.cascades * cells].reshape(snap.cascades, cells)
+    morton = _morton_index_table().reshape(-1)
+    density = np.zeros((snap.cascades, cells), np.float16)
+    for c in range(snap.cascades):
+        density[c, morton] = bits[c].astype(np.float16)
+    params = np.concatenate([snap.mlp.astype(np.float16).reshape(-1), snap.grid.astype(np.float16).reshape(-1)])
+    return {
+        "encoding": {"otype": "HashGrid", "n_levels": snap.n_levels, "n_features_per_level": snap.n_features,
+                     "log2_hashmap_size": snap.log2_hashmap, "base_resolution": snap.base_res,
+                     "per_level_scale": snap.per_level_scale},
+        "dir_encoding": {"otype": "Composite", "nested": [
+            {"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4},
+            {"otype": "Identity", "n_bins": 4, "degree": 4}]},
+        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                    "n_hidden_layers": 1},
+        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                        "n_neurons": 64, "n_hidden_layers": 2},
+        "snapshot": {
+            "version": 1, "n_params": int(params.size), "params_type": "__half",
+            "params_binary": params.tobytes(), "density_grid_size": _NGP_GRID,
+            "density_grid_binary": density.tobytes(),
+            "nerf": {"dataset": {"scale": snap.scale, "offset": [snap.offset] * 3, "aabb_scale": snap.aabb_scale,
+                                 "metadata": [{"camera_distortion": {"mode": 1, "params": [snap.k1, 0.0, 0.0, 0.0]}}]}},
+        },
+    }
 
 
 def nerf_matrix_to_ngp(nerf_c2w: np.ndarray, scale: float, offset: float) -> np.ndarray:

@@ -276,9 +276,20 @@ class PixLocPoseTrackerR9(PoseTracker):
             return image_folder
         return ImageIterator(image_folder, max_frames)
 
-    def save_poses(self):
-        with open(os.path.join(self.eval_path, "poses.pkl"), "wb") as f:
-            pkl.dump(self.pose_history, f)
+    def save_poses(self, pixloc_pickles: bool = False):
+        """poses.pkl (reference :281-284).  ``pixloc_pickles`` writes Pose/Camera under pixloc's
+        class path so the reference's own tools (run_vis_on_poses.py, GetMetrics.ipynb) load it."""
+        _dump(self.pose_history, os.path.join(self.eval_path, "poses.pkl"), pixloc_pickles)
+
+
+def _dump(obj, path, pixloc_pickles: bool):
+    if pixloc_pickles:
+        from ..utils.io import dump_reference_pickle
+
+        dump_reference_pickle(obj, path)
+    else:
+        with open(path, "wb") as f:
+            pkl.dump(obj, f)
 
 
 def main(argv=None):
@@ -288,6 +299,8 @@ def main(argv=None):
     parser.add_argument("--out_dir", type=Path)
     parser.add_argument("--frames", type=int, default=None)
     parser.add_argument("--debug", type=int, default=0)
+    parser.add_argument("--pixloc_pickles", action="store_true",
+                        help="write poses.pkl/trackers.pkl with pixloc's Pose/Camera class paths")
     args = parser.parse_args(argv)
     data_path = args.object_path / "pixtrack/pixsfm/dataset"
     eval_path = args.out_dir
@@ -296,10 +309,9 @@ def main(argv=None):
     tracker = PixLocPoseTrackerR9(object_path=str(args.object_path), data_path=str(data_path),
                                   eval_path=str(eval_path), loc_path=str(loc_path), debug=args.debug)
     tracker.run(args.query, max_frames=args.frames if args.frames is not None else np.inf)
-    tracker.save_poses()
+    tracker.save_poses(args.pixloc_pickles)
     print("Cache hits: %d, misses: %d" % (tracker.hits, tracker.misses))
-    with open(os.path.join(tracker.eval_path, "trackers.pkl"), "wb") as f:
-        pkl.dump(tracker.pose_tracker_history, f)
+    _dump(tracker.pose_tracker_history, os.path.join(tracker.eval_path, "trackers.pkl"), args.pixloc_pickles)
     print("Done")
 
 

@@ -270,7 +270,8 @@ class PoseTrackerLocalizer:
     """Builds model3d + extractor + the three per-level optimizers + refiner
     (reference pixloc_pose_refiners.py:28-118).  ``experiment`` weights come either from a
     dict of tensors (``conf["weights"]``: UNet names of pixtrack_amd.unet + "optimizer.{i}.
-    dampingnet.const") or from ``conf["weights_path"]`` (a torch file of that dict)."""
+    dampingnet.const") or from ``conf["weights_path"]`` (a torch file of that dict, or a pixloc
+    ``checkpoint_best.tar``; see unet.load_weights)."""
 
     def __init__(self, paths, conf, device: Optional[torch.device] = None, model3d: Optional[Model3D] = None):
         if device is None:
@@ -283,7 +284,9 @@ class PoseTrackerLocalizer:
         conf = Conf(conf)
         weights = conf.get("weights")
         if weights is None:
-            weights = torch.load(conf["weights_path"], map_location="cpu")
+            from .unet import load_weights
+
+            weights = load_weights(conf["weights_path"])
         conf_optim = merge({"num_iters": 100}, conf.get("optimizer", {}))
         extractor = UNet(weights, self.device)
         optimizer = []

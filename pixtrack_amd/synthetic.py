@@ -433,3 +433,46 @@ def render_query_frames(assets, testbed, noise_sigma: float = 2.0, seed: int = 5
             img = (img + noise.to(img.device)).clamp_(0, 255).round_()
         frames.append(img.contiguous())
     return frames
+
+
+def write_object_dir(assets, object_path, query_dir=None, frames=None, ngp_layout: bool = True,
+                     pixloc_checkpoint: bool = True):
+    """Writes ``assets`` in the reference's on-disk layout (SURVEY 8b "CLI to preserve"):
+    ``pixtrack/{aug_nerf_sfm/aug_sfm/*.bin, pixsfm/dataset/nerf2sfm.pkl,
+    instant-ngp/snapshots/weights.msgpack, pixloc_megadepth.pt}`` and, when ``frames`` (HWC
+    0..255 arrays/tensors) are given, ``query_dir/%06d.png``.  ``ngp_layout`` stores the snapshot
+    in instant-ngp's params_binary layout, ``pixloc_checkpoint`` stores the weights as a pixloc
+    ``{"model": state_dict}`` checkpoint, so the CLI run exercises both importers."""
+    import pickle
+    from pathlib import Path
+
+    import msgpack
+
+    from .ngp import save_snapshot, to_instant_ngp
+    from .unet import to_pixloc_state_dict
+    from .utils.colmap import write_model_binary
+
+    root = Path(object_path) / "pixtrack"
+    sfm = root / "aug_nerf_sfm" / "aug_sfm"
+    sfm.mkdir(parents=True, exist_ok=True)
+    m = assets["model3d"]
+    write_model_binary(str(sfm), m.cameras, m.dbs, m.points3D)
+    (root / "pixsfm" / "dataset").mkdir(parents=True, exist_ok=True)
+    with open(root / "pixsfm" / "dataset" / "nerf2sfm.pkl", "wb") as f:
+        pickle.dump(assets["nerf2sfm"], f)
+    snaps = root / "instant-ngp" / "snapshots"
+    snaps.mkdir(parents=True, exist_ok=True)
+    if ngp_layout:
+        (snaps / "weights.msgpack").write_bytes(msgpack.packb(to_instant_ngp(assets["snapshot"]), use_bin_type=True))
+    else:
+        save_snapshot(str(snaps / "weights.msgpack"), assets["snapshot"])
+    w = assets["weights"]
+    torch.save({"model": to_pixloc_state_dict(w)} if pixloc_checkpoint else w, root / "pixloc_megadepth.pt")
+    if frames is not None:
+        from PIL import Image
+
+        q = Path(query_dir)
+        q.mkdir(parents=True, exist_ok=True)
+        for i, fr in enumerate(frames):
+            a = fr.detach().cpu().numpy() if torch.is_tensor(fr) else np.asarray(fr)
+            Image.fromarray(np.clip(np.rint(a), 0, 255).astype(np.uint8)).save(q / f"{i:06d}.png")

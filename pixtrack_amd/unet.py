@@ -110,6 +110,46 @@ def from_pixloc_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tenso
     return out
 
 
+def to_pixloc_state_dict(w: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Inverse of from_pixloc_state_dict (``extractor.*`` + ``optimizer.*`` keys): what a pixloc
+    ``checkpoint_best.tar`` holds under "model".  Used to write test checkpoints."""
+    out: Dict[str, torch.Tensor] = {}
+    for b, convs in enumerate(ENC_BLOCKS):
+        first = 0 if b == 0 else 1
+        for i in range(len(convs)):
+            for part in ("weight", "bias"):
+                out[f"extractor.encoder.{b}.{first + 2 * i}.{part}"] = w[f"enc{b}_{i}.{part}"]
+    for d in range(len(DECODER)):
+        out[f"extractor.decoder.{d}.layers.0.weight"] = w[f"dec{d}.weight"]
+        for src, dst in (("bn_weight", "weight"), ("bn_bias", "bias"), ("bn_mean", "running_mean"),
+                         ("bn_var", "running_var")):
+            out[f"extractor.decoder.{d}.layers.1.{dst}"] = w[f"dec{d}.{src}"]
+        out[f"extractor.decoder.{d}.layers.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    for k in range(len(OUTPUT_SCALES)):
+        for part in ("weight", "bias"):
+            out[f"extractor.adaptation.{k}.0.{part}"] = w[f"adapt{k}.{part}"]
+            out[f"extractor.uncertainty.{k}.0.{part}"] = w[f"unc{k}.{part}"]
+    for k, v in w.items():
+        if k.startswith("optimizer."):
+            out[k] = v
+    return out
+
+
+def load_weights(path) -> Dict[str, torch.Tensor]:
+    """Reads either this package's flat tensor dict or a pixloc experiment checkpoint
+    (``checkpoint_best.tar``: {"model": state_dict, "conf": ...}; reference
+    pixloc_pose_refiners.py:49-60 loads it through pixloc's load_experiment).  Returns the
+    canonical names of this module plus any ``optimizer.{i}.dampingnet.const``."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(blob, dict) and "model" in blob and isinstance(blob["model"], dict):
+        blob = blob["model"]
+    if any(k.startswith("extractor.") for k in blob):
+        out = from_pixloc_state_dict(blob)
+        out.update({k: v for k, v in blob.items() if k.startswith("optimizer.")})
+        return out
+    return blob
+
+
 def _align16(n: int) -> int:
     return (n + 15) // 16 * 16
 
