@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libpixtrack_hip.so"
+# PIXTRACK_HIP_LIB points at another build of the same ABI (A/B experiments, packaging)
+LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_LIB") else _HERE / "libpixtrack_hip.so"
 
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
