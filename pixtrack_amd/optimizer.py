@@ -260,10 +260,13 @@ class PixTrackOptimizer:
             arr[i].lambda_[:] = lp.lambda_.float().tolist()
             keep.append(lp)
         T0 = _lib.host_pose12(T_init)
-        # one buffer for the output record and the iteration log -> one device->host copy
+        # One buffer for the output record and the iteration log, in pinned host memory: the
+        # kernel's (write-only) stores land on the host directly, so the frame's critical path
+        # has no device->host copy to enqueue and wait for after the kernel - only the event.
         n_log = n_levels * conf.num_iters * _lib.PXT_LM_LOG_STRIDE if want_log else 0
-        buf = torch.zeros(16 + _lib.PXT_MAX_LEVELS + n_log, device=dev, dtype=torch.float32)
+        buf = _pinned_record(16 + _lib.PXT_MAX_LEVELS + n_log)
         out = buf[: 16 + _lib.PXT_MAX_LEVELS]
+        out.zero_()
         log = buf[16 + _lib.PXT_MAX_LEVELS:].view(n_levels, conf.num_iters, _lib.PXT_LM_LOG_STRIDE) if want_log else None
         p3d = p3d.to(torch.float32).contiguous()
         if mask is not None:
@@ -276,7 +279,9 @@ class PixTrackOptimizer:
             ),
             "pxt_lm_refine",
         )
-        return PendingLM(buf, want_log, n_levels, conf.num_iters, (p3d, mask, keep, workspace))
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return PendingLM(buf, want_log, n_levels, conf.num_iters, (p3d, mask, keep, workspace), done)
 
     def run(self, p3D, F_ref, F_query, T_init: Pose, camera: Camera, mask=None, W_ref_query=None):
         """One pyramid level, pixloc calling convention:
@@ -326,26 +331,44 @@ class PixTrackOptimizer:
             T_prev = T
 
 
-class PendingLM:
-    """Result handle of an enqueued refinement (ONE device->host copy on .result())."""
+_PINNED: dict = {}
 
-    def __init__(self, buf, has_log, n_levels, num_iters, keepalive):
+
+def _pinned_record(n_floats: int) -> torch.Tensor:
+    """Reusable pinned host buffers, two per size (a result may still be read while the next
+    refinement is enqueued)."""
+    slot = _PINNED.setdefault(n_floats, [[], 0])
+    if len(slot[0]) < 2:
+        slot[0].append(torch.zeros(n_floats, dtype=torch.float32).pin_memory())
+    slot[1] = (slot[1] + 1) % 2
+    return slot[0][min(slot[1], len(slot[0]) - 1)]
+
+
+class PendingLM:
+    """Result handle of an enqueued refinement; .result() waits for the kernel's event and reads
+    the record the kernel wrote into pinned host memory."""
+
+    def __init__(self, buf, has_log, n_levels, num_iters, keepalive, done):
         self.buf, self.has_log = buf, has_log
         self.n_levels, self.num_iters = n_levels, num_iters
-        self._keep = keepalive
+        self._keep, self._done = keepalive, done
 
     def result(self) -> LMResult:
-        host = self.buf.cpu()
+        # This sits on the frame's critical path (the next frame's render waits for the pose):
+        # one blocking copy, then plain numpy/Python on the host record.
+        self._done.synchronize()
+        host = self.buf.clone()  # the pinned buffer is reused two refinements later
+        h = host.numpy()
         nh = 16 + _lib.PXT_MAX_LEVELS
-        out = host[:nh]
-        status = int(out[13])
+        status = int(h[13])
         if status != 0:
             raise _lib.PxtError(f"pxt_lm_refine: in-kernel status {status} (spin bound exceeded)")
-        iters = [int(out[16 + l]) for l in range(self.n_levels)]
+        iters = [int(h[16 + l]) for l in range(self.n_levels)]
         if self.has_log:
             log = host[nh:].view(self.n_levels, self.num_iters, _lib.PXT_LM_LOG_STRIDE)
-            costs = [log[l, : iters[l], 0].tolist() for l in range(self.n_levels)]
+            lg = h[nh:].reshape(self.n_levels, self.num_iters, _lib.PXT_LM_LOG_STRIDE)
+            costs = [lg[l, : iters[l], 0].tolist() for l in range(self.n_levels)]
         else:
             log, costs = torch.zeros(self.n_levels, 0, _lib.PXT_LM_LOG_STRIDE), []
         self._keep = None
-        return LMResult(Pose(out[:12].clone()), bool(out[12] != 0), iters, costs, log, int(out[14]))
+        return LMResult(Pose(host[:12].clone()), bool(h[12] != 0), iters, costs, log, int(h[14]))

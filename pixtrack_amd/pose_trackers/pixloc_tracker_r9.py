@@ -116,6 +116,8 @@ class PixLocPoseTrackerR9(PoseTracker):
         # (same size and fx: all get_nerf_image reads) one march yields both, bit for bit.
         self.fuse_identical_views = True
         self._fused_reference = None  # (pose object, uint8 image) handed from get_mask to get_reference_image
+        self._ref_cam_cache = None
+        self._coincide_cache = None
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
 
     # ------------------------------------------------------------------ relocalisation
@@ -157,13 +159,25 @@ class PixLocPoseTrackerR9(PoseTracker):
         return sfm_to_nerf_pose(self.nerf2sfm, get_camera_in_world_from_pixpose(pose))
 
     def _reference_camera(self):
-        return PixCamera.from_colmap(self.localizer.model3d.cameras[1]).scale(self.reference_scale)
+        key = float(self.reference_scale)
+        if self._ref_cam_cache is None or self._ref_cam_cache[0] != key:
+            self._ref_cam_cache = (key, PixCamera.from_colmap(self.localizer.model3d.cameras[1]).scale(key))
+        return self._ref_cam_cache[1]
+
+    @staticmethod
+    def _view_key(cam):
+        """(width, height, fx): all that get_nerf_image reads from a camera (run_vis_on_poses.py:30-36)."""
+        return int(cam.size[0]), int(cam.size[1]), float(cam.f[0])
 
     def _views_coincide(self) -> bool:
         if not self.fuse_identical_views or self.camera is None:
             return False
-        a, b = self._reference_camera(), self.camera
-        return (int(a.size[0]), int(a.size[1]), float(a.f[0])) == (int(b.size[0]), int(b.size[1]), float(b.f[0]))
+        # per-frame call: the answer only changes with the camera object or the reference scale
+        key = (id(self.camera), float(self.reference_scale))
+        if self._coincide_cache is None or self._coincide_cache[0] != key:
+            qk = self._view_key(self.camera)
+            self._coincide_cache = (key, self._view_key(self._reference_camera()) == qk, qk)
+        return self._coincide_cache[1]
 
     def get_reference_image(self, pose) -> torch.Tensor:
         """uint8 [H,W,3] NeRF render at ``pose`` with SfM camera 1 scaled by reference_scale."""
@@ -206,10 +220,10 @@ class PixLocPoseTrackerR9(PoseTracker):
         if self._views_coincide():
             import math
 
-            cam = self.camera
-            self.testbed.fov = math.atan(int(cam.size[0]) / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
+            width, height, fl_x = self._coincide_cache[2]
+            self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
             self.testbed.set_nerf_camera_matrix(np.asarray(self._nerf_pose(pose))[:3, :])
-            rgba, depth = self.testbed.render_both_device(int(cam.size[0]), int(cam.size[1]), self.spp)
+            rgba, depth = self.testbed.render_both_device(width, height, self.spp)
             self._fused_reference = (pose, rgba_to_u8(rgba, 0.0))
         else:
             depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp)

@@ -19,6 +19,8 @@ import ctypes as C
 import logging
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import math
+
 import numpy as np
 import torch
 
@@ -240,9 +242,14 @@ class PoseTrackerRefiner:
         ret = {"T_init": T_init}
         if res.failed:
             return {**ret, "success": False}
-        T_opt = Pose(res.T.as12().cpu().double())
-        dR, dt = (Pose(T_init.as12().cpu().double()).inv() @ T_opt).magnitude()
-        return {**ret, "success": True, "T_refined": T_opt, "diff_R": dR.item(), "diff_t": dt.item()}
+        T_opt = Pose(res.T.as12().double())  # already on the host (pixloc: T_opt.cpu().double())
+        # (T_init^-1 @ T_opt).magnitude() in float64, as pixloc does, without a dozen tiny torch ops
+        a, b = T_init.as12().detach().cpu().double().numpy(), T_opt.as12().numpy()
+        R0, R1 = a[:9].reshape(3, 3), b[:9].reshape(3, 3)
+        cos = min(1.0, max(-1.0, (float(np.trace(R0.T @ R1)) - 1.0) / 2.0))
+        dR = abs(math.acos(cos)) / math.pi * 180.0
+        dt = float(np.linalg.norm(R0.T @ (b[9:] - a[9:])))
+        return {**ret, "success": True, "T_refined": T_opt, "diff_R": dR, "diff_t": dt}
 
 
 class Paths(dict):
