@@ -145,7 +145,7 @@ def main():
     timer = StageTimer()
     timer.wrap(tracker.testbed, "render_device", "nerf_render")
     timer.wrap(tracker.testbed, "render_both_device", "nerf_render")
-    timer.wrap(tracker.localizer.extractor.model, "forward_packed", "unet")
+    timer.wrap(tracker.localizer.extractor.model, "forward_packed_batch", "unet")
     timer.wrap(tracker.localizer.refiner, "refine_pose_using_features", "lm")
     timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")
     tracker.testbed.stats_accum = torch.zeros(4, dtype=torch.int64, device=dev)

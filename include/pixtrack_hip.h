@@ -155,6 +155,21 @@ int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8, cons
                      int32_t H, int32_t W, float* const out_maps[3], const int32_t out_cstride[3],
                      int32_t normalize, void* workspace, void* stream);
 
+/* The same pass over n_images (<= PXT_UNET_MAX_BATCH) equally sized images in one set of
+ * launches: a frame's reference render and its masked query
+ * (pixloc_pose_refiners.py:282-290 and :255, two model() calls per frame in the
+ * reference) share every weight fetch, and the small deep layers get twice the tiles.
+ * images[i] / image_is_u8[i] / masks[i] (masks may be NULL, entries may be NULL) /
+ * normalize[i] as in pxt_unet_forward; out_maps[3*i + l] = image i, level l.  Each image's
+ * result is independent of its batch neighbours; a layer's split-K factor depends on the
+ * batch size, so a batched map equals the single-image one up to fp32 summation order. */
+#define PXT_UNET_MAX_BATCH 8
+int64_t pxt_unet_workspace_bytes_batch(const pxt_unet* ctx, int32_t n_images, int32_t H, int32_t W);
+int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* images,
+                           const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H, int32_t W,
+                           float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
+                           void* workspace, void* stream);
+
 /* One 3x3 convolution (pad 1) of the pyramid as a stand-alone call, for layer-by-layer
  * parity tests against torch.nn.functional.conv2d (SURVEY KAT-6) and for profiling:
  * in  [H][W][Cin]  fp16 NHWC (Cin % 32 == 0), weights [Cout][3][3][Cin] fp16

@@ -120,6 +120,12 @@ PROTOTYPES = {
         C.c_int,
         [_VP, _VP, _I32, _VP, _I32, _I32, C.POINTER(_VP), C.POINTER(_I32), _I32, _VP, _VP],
     ),
+    "pxt_unet_workspace_bytes_batch": (_I64, [_VP, _I32, _I32, _I32]),
+    "pxt_unet_forward_batch": (
+        C.c_int,
+        [_VP, _I32, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_VP), _I32, _I32, C.POINTER(_VP), C.POINTER(_I32),
+         C.POINTER(_I32), _VP, _VP],
+    ),
     "pxt_conv3x3_nhwc_f16": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _I32, _I32, _VP, _VP]),
     "pxt_ngp_create": (C.c_int, [C.POINTER(NgpModel), _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
     "pxt_ngp_destroy": (C.c_int, [_VP]),

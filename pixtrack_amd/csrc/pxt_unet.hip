@@ -131,9 +131,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  // blockIdx.x = image * tiles_per_image + tile: a batch is just more tiles (same weights, the
+  // halo is clipped per image)
   const int tiles_x = (W + kTW - 1) / kTW;
-  const int ty0 = (blockIdx.x / tiles_x) * kTH, tx0 = (blockIdx.x % tiles_x) * kTW;
+  const int tiles_per = tiles_x * ((H + kTH - 1) / kTH);
+  const int img = blockIdx.x / tiles_per, tile = blockIdx.x % tiles_per;
+  const int n_img = gridDim.x / tiles_per;
+  const int ty0 = (tile / tiles_x) * kTH, tx0 = (tile % tiles_x) * kTW;
   const int co0 = blockIdx.y * BNC;
+  in += (size_t)img * H * W * Cin;
+  out += (size_t)img * H * W * Cout;
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
     if (gy >= H || gx >= W) continue;
     half_t* dst = out + ((size_t)gy * W + gx) * Cout + co0;
     if (gridDim.z > 1) {
-      float* pd = partial + (((size_t)blockIdx.z * H + gy) * W + gx) * Cout + co0;
+      float* pd = partial + ((((size_t)blockIdx.z * n_img + img) * H + gy) * W + gx) * Cout + co0;
 #pragma unroll
       for (int c = 0; c < NT; ++c)
 #pragma unroll
@@ -302,13 +309,20 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const half_t* __restrict
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   const half_t* xp = in + (size_t)pix * Cin + 8 * khalf;
   const half_t* wp = wts + (size_t)r31 * Cin + 8 * khalf;
-  for (int k0 = 0; k0 < Cin; k0 += 16) {
-    const half8 b = *(const half8*)(xp + k0);
+  // Cin % 32 == 0 for every head (32 / 128 / 512): two k-steps per trip keep twice the loads
+  // in flight (the coarsest head is pure load latency: 38 waves, K = 512).
+  for (int k0 = 0; k0 < Cin; k0 += 32) {
+    const half8 b0 = *(const half8*)(xp + k0), b1 = *(const half8*)(xp + k0 + 16);
+    half8 a0[NT], a1[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-      const half8 a = *(const half8*)(wp + (size_t)(32 * c) * Cin + k0);
-      acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[c], 0, 0, 0);
+      a0[c] = *(const half8*)(wp + (size_t)(32 * c) * Cin + k0);
+      a1[c] = *(const half8*)(wp + (size_t)(32 * c) * Cin + k0 + 16);
     }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[c], b0, acc[c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[c], b1, acc[c], 0, 0, 0);
   }
   // bias, then the descriptor's squared norm over this lane's rows and the partner half's
   float ss = 0.f;
@@ -347,12 +361,16 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const half_t* __restrict
 // 2x2 max-pool stride 2 (floor), NHWC fp16, 8 channels per thread.
 // ---------------------------------------------------------------------------
 __global__ void maxpool2_kernel(const half_t* __restrict__ in, int H, int W, int C,
-                                half_t* __restrict__ out, int Ho, int Wo) {
+                                half_t* __restrict__ out, int Ho, int Wo, int n_img) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c8 = C / 8;
-  if (i >= (long long)Ho * Wo * c8) return;
+  if (i >= (long long)n_img * Ho * Wo * c8) return;
   const int c = (int)(i % c8) * 8;
-  const long long p = i / c8;
+  long long p = i / c8;
+  const int img = (int)(p / ((long long)Ho * Wo));
+  p -= (long long)img * Ho * Wo;
+  in += (size_t)img * H * W * C;
+  out += (size_t)img * Ho * Wo * C;
   const int x = (int)(p % Wo), y = (int)(p / Wo);
   const half_t* s = in + ((size_t)(2 * y) * W + 2 * x) * C + c;
   half8 a = *(const half8*)s, b = *(const half8*)(s + C), d = *(const half8*)(s + (size_t)W * C),
@@ -371,14 +389,19 @@ __global__ void maxpool2_kernel(const half_t* __restrict__ in, int H, int W, int
 // Decoder input: cat([bilinear x2 upsample(prev) (align_corners=False), skip[:hu,:wu]]).
 // ---------------------------------------------------------------------------
 __global__ void upcat_kernel(const half_t* __restrict__ prev, int Hp, int Wp, int Cp,
-                             const half_t* __restrict__ skip, int Ws, int Cs,
-                             half_t* __restrict__ out) {
+                             const half_t* __restrict__ skip, int Hs, int Ws, int Cs,
+                             half_t* __restrict__ out, int n_img) {
   const int Ho = 2 * Hp, Wo = 2 * Wp, Ct = Cp + Cs;
   const int c8 = Ct / 8;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)Ho * Wo * c8) return;
+  if (i >= (long long)n_img * Ho * Wo * c8) return;
   const int c = (int)(i % c8) * 8;
-  const long long p = i / c8;
+  long long p = i / c8;
+  const int img = (int)(p / ((long long)Ho * Wo));
+  p -= (long long)img * Ho * Wo;
+  prev += (size_t)img * Hp * Wp * Cp;
+  skip += (size_t)img * Hs * Ws * Cs;
+  out += (size_t)img * Ho * Wo * Ct;
   const int x = (int)(p % Wo), y = (int)(p / Wo);
   half8 o;
   if (c < Cp) {
@@ -438,11 +461,11 @@ int choose_splits(int tiles, int nblocks, int n_chunks) {
   return std::max(1, std::min(splits, 32));
 }
 
-size_t splitk_bytes(int H, int W, int cin, int cout) {
-  const int tiles = ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+size_t splitk_bytes(int n_img, int H, int W, int cin, int cout) {
+  const int tiles = n_img * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
   const int nb = (cout % 64 == 0) ? cout / 64 : cout / 32;
   const int sp = choose_splits(tiles, nb, cin / kCK);
-  return sp > 1 ? (size_t)sp * H * W * cout * sizeof(float) : 0;
+  return sp > 1 ? (size_t)sp * n_img * H * W * cout * sizeof(float) : 0;
 }
 
 struct Plan {
@@ -454,7 +477,10 @@ struct Plan {
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-bool make_plan(const pxt_unet* ctx, int H, int W, Plan& P) {
+// Workspace layout for a batch of n_img equally sized images: every activation buffer holds
+// the images back to back ([n_img][h][w][C]).
+bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
+  if (n_img < 1 || n_img > PXT_UNET_MAX_BATCH) return false;
   P.h[0] = H; P.w[0] = W;
   for (int b = 1; b < 5; ++b) { P.h[b] = P.h[b - 1] / 2; P.w[b] = P.w[b - 1] / 2; }
   if (P.h[4] < 1 || P.w[4] < 1) return false;
@@ -465,14 +491,14 @@ bool make_plan(const pxt_unet* ctx, int H, int W, Plan& P) {
   static const int enc_c[5] = {64, 128, 256, 512, 512};
   static const int enc_in[5] = {3, 64, 128, 256, 512};
   for (int b = 0; b < 5; ++b) {
-    const size_t px = (size_t)P.h[b] * P.w[b];
+    const size_t px = (size_t)n_img * P.h[b] * P.w[b];
     P.enc_pool[b] = (b > 0) ? take(px * enc_in[b] * 2) : 0;
     P.enc_tmp[b][0] = take(px * enc_c[b] * 2);
     P.enc_tmp[b][1] = take(px * enc_c[b] * 2);
     P.enc_out[b] = take(px * enc_c[b] * 2);
   }
   for (int d = 0; d < 4; ++d) {
-    const size_t px = (size_t)P.dh[d] * P.dw[d];
+    const size_t px = (size_t)n_img * P.dh[d] * P.dw[d];
     P.dec_cat[d] = take(px * ctx->conv[13 + d].cin * 2);
     P.dec_out[d] = take(px * ctx->conv[13 + d].cout * 2);
   }
@@ -480,8 +506,9 @@ bool make_plan(const pxt_unet* ctx, int H, int W, Plan& P) {
   size_t sk = 0;
   static const int blk_of[13] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};
   for (int i = 1; i < 13; ++i)
-    sk = std::max(sk, splitk_bytes(P.h[blk_of[i]], P.w[blk_of[i]], ctx->conv[i].cin, ctx->conv[i].cout));
-  for (int d = 0; d < 4; ++d) sk = std::max(sk, splitk_bytes(P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout));
+    sk = std::max(sk, splitk_bytes(n_img, P.h[blk_of[i]], P.w[blk_of[i]], ctx->conv[i].cin, ctx->conv[i].cout));
+  for (int d = 0; d < 4; ++d)
+    sk = std::max(sk, splitk_bytes(n_img, P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout));
   P.splitk = take(sk + 256);
   P.total = off;
   return true;
@@ -499,10 +526,10 @@ void set_conv_lds_attr() {
 }
 
 int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out, hipStream_t s,
-                int relu = 1, float* partial = nullptr) {
+                int relu = 1, float* partial = nullptr, int n_img = 1) {
   if (L.cin % kCK != 0 || L.cout % 32 != 0) return PXT_E_ARG;
   set_conv_lds_attr();
-  const int tiles = ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  const int tiles = n_img * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
   const bool wide = L.cout % 64 == 0;
   const int nb = wide ? L.cout / 64 : L.cout / 32;
   const int splits = partial ? choose_splits(tiles, nb, L.cin / kCK) : 1;
@@ -516,7 +543,7 @@ int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out,
                        L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
   }
   if (splits > 1) {
-    const long long n4 = (long long)H * W * L.cout / 4;
+    const long long n4 = (long long)n_img * H * W * L.cout / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, splits,
                        n4, L.cout, L.b, relu, out);
   }
@@ -608,23 +635,32 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   return PXT_OK;
 }
 
-extern "C" int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W) {
+extern "C" int64_t pxt_unet_workspace_bytes_batch(const pxt_unet* ctx, int32_t n_images, int32_t H, int32_t W) {
   if (!ctx) return PXT_E_ARG;
   Plan P;
-  if (!make_plan(ctx, H, W, P)) return 0;
+  if (!make_plan(ctx, n_images, H, W, P)) return 0;
   return (int64_t)P.total;
 }
 
-extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8,
-                                const uint8_t* mask, int32_t H, int32_t W, float* const out_maps[3],
-                                const int32_t out_cstride[3], int32_t normalize, void* workspace,
-                                void* stream) {
-  if (!ctx || !image || !out_maps || !out_cstride || !workspace) return PXT_E_ARG;
+extern "C" int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W) {
+  return pxt_unet_workspace_bytes_batch(ctx, 1, H, W);
+}
+
+extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* images,
+                                      const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H,
+                                      int32_t W, float* const* out_maps, const int32_t out_cstride[3],
+                                      const int32_t* normalize, void* workspace, void* stream) {
+  if (!ctx || !images || !image_is_u8 || !out_maps || !out_cstride || !normalize || !workspace) return PXT_E_ARG;
   Plan P;
-  if (!make_plan(ctx, H, W, P)) return PXT_E_ARG;
+  const int B = n_images;
+  if (!make_plan(ctx, B, H, W, P)) return PXT_E_ARG;
+  for (int i = 0; i < B; ++i) {
+    if (!images[i]) return PXT_E_ARG;
+    for (int k = 0; k < 3; ++k)
+      if (!out_maps[3 * i + k]) return PXT_E_ARG;
+  }
   for (int k = 0; k < 3; ++k)
-    if (!out_maps[k] || out_cstride[k] < ctx->head[k].cout + 1 || (out_cstride[k] % 4) != 0)
-      return PXT_E_ARG;
+    if (out_cstride[k] < ctx->head[k].cout + 1 || (out_cstride[k] % 4) != 0) return PXT_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   auto buf = [&](size_t off) { return (half_t*)(ws + off); };
@@ -637,29 +673,35 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
     const int h = P.h[b], w = P.w[b];
     const half_t* x;
     if (b == 0) {
+      // the images differ in type (u8 render / float frame) and mask: one launch each, all
+      // writing into the batched activation buffer
       const UnetLayer& L0 = ctx->conv[0];
       const long long threads = (long long)h * w * (L0.cout / 16);
       const size_t lds = (size_t)(28 * L0.cout) * sizeof(float);
       half_t* o = buf(P.enc_tmp[0][0]);
-      if (image_is_u8)
-        hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
-                           image, mask, h, w, (const float*)L0.w, L0.b, L0.cout, o);
-      else
-        hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
-                           image, mask, h, w, (const float*)L0.w, L0.b, L0.cout, o);
+      for (int i = 0; i < B; ++i) {
+        half_t* oi = o + (size_t)i * h * w * L0.cout;
+        const uint8_t* m = masks ? masks[i] : nullptr;
+        if (image_is_u8[i])
+          hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
+                             images[i], m, h, w, (const float*)L0.w, L0.b, L0.cout, oi);
+        else
+          hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
+                             images[i], m, h, w, (const float*)L0.w, L0.b, L0.cout, oi);
+      }
       x = o;
     } else {
       const int cin = ctx->conv[block_first[b]].cin;
       half_t* o = buf(P.enc_pool[b]);
-      const long long n = (long long)h * w * (cin / 8);
+      const long long n = (long long)B * h * w * (cin / 8);
       hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cur, P.h[b - 1],
-                         P.w[b - 1], cin, o, h, w);
+                         P.w[b - 1], cin, o, h, w, B);
       x = o;
     }
     for (int i = (b == 0 ? 1 : 0); i < block_n[b]; ++i) {
       const bool last = i == block_n[b] - 1;
       half_t* o = last ? buf(P.enc_out[b]) : buf(P.enc_tmp[b][i & 1]);
-      int rc = launch_conv(ctx->conv[block_first[b] + i], x, h, w, o, s, 1, (float*)(ws + P.splitk));
+      int rc = launch_conv(ctx->conv[block_first[b] + i], x, h, w, o, s, 1, (float*)(ws + P.splitk), B);
       if (rc != PXT_OK) return rc;
       x = o;
     }
@@ -676,17 +718,17 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
     const int sb = 3 - d;
     const int cs = L.cin - pc;
     half_t* cat = buf(P.dec_cat[d]);
-    const long long n = (long long)P.dh[d] * P.dw[d] * (L.cin / 8);
+    const long long n = (long long)B * P.dh[d] * P.dw[d] * (L.cin / 8);
     hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prev, ph, pw, pc,
-                       skip[sb], P.w[sb], cs, cat);
+                       skip[sb], P.h[sb], P.w[sb], cs, cat, B);
     half_t* o = buf(P.dec_out[d]);
-    int rc = launch_conv(L, cat, P.dh[d], P.dw[d], o, s, 1, (float*)(ws + P.splitk));
+    int rc = launch_conv(L, cat, P.dh[d], P.dw[d], o, s, 1, (float*)(ws + P.splitk), B);
     if (rc != PXT_OK) return rc;
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
     pre[3 - d] = o;
   }
-  // heads at output scales 0, 2, 4
+  // heads at output scales 0, 2, 4 (per image: separate output tensors and normalisation flags)
   static const int head_src[3] = {0, 2, 4};
   for (int k = 0; k < 3; ++k) {
     const UnetLayer& Lh = ctx->head[k];
@@ -694,16 +736,32 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
     const int hh = (i == 4) ? P.h[4] : P.dh[3 - i], ww = (i == 4) ? P.w[4] : P.dw[3 - i];
     const long long npix = (long long)hh * ww;
     const long long waves = (npix + 31) / 32;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (Lh.cout + 1 <= 64)
-      hipLaunchKernelGGL(head_mfma_kernel<2>, dim3(blocks), dim3(256), 0, s, pre[i], npix, Lh.cin, ctx->head_w[k],
-                         ctx->head_b[k], Lh.cout, normalize, out_maps[k], out_cstride[k]);
-    else
-      hipLaunchKernelGGL(head_mfma_kernel<5>, dim3(blocks), dim3(256), 0, s, pre[i], npix, Lh.cin, ctx->head_w[k],
-                         ctx->head_b[k], Lh.cout, normalize, out_maps[k], out_cstride[k]);
+    // small maps: one wave per workgroup so the few waves spread over as many CUs
+    const int tpb = waves < 1024 ? 64 : 256;
+    const unsigned blocks = (unsigned)((waves * 64 + tpb - 1) / tpb);
+    for (int im = 0; im < B; ++im) {
+      const half_t* src = pre[i] + (size_t)im * npix * Lh.cin;
+      if (Lh.cout + 1 <= 64)
+        hipLaunchKernelGGL(head_mfma_kernel<2>, dim3(blocks), dim3(tpb), 0, s, src, npix, Lh.cin, ctx->head_w[k],
+                           ctx->head_b[k], Lh.cout, normalize[im], out_maps[3 * im + k], out_cstride[k]);
+      else
+        hipLaunchKernelGGL(head_mfma_kernel<5>, dim3(blocks), dim3(tpb), 0, s, src, npix, Lh.cin, ctx->head_w[k],
+                           ctx->head_b[k], Lh.cout, normalize[im], out_maps[3 * im + k], out_cstride[k]);
+    }
   }
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
+}
+
+extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8,
+                                const uint8_t* mask, int32_t H, int32_t W, float* const out_maps[3],
+                                const int32_t out_cstride[3], int32_t normalize, void* workspace,
+                                void* stream) {
+  if (!out_maps) return PXT_E_ARG;
+  const void* images[1] = {image};
+  const uint8_t* masks[1] = {mask};
+  return pxt_unet_forward_batch(ctx, 1, images, &image_is_u8, masks, H, W, out_maps, out_cstride, &normalize,
+                                workspace, stream);
 }
 
 extern "C" int pxt_conv3x3_nhwc_f16(const void* in, int32_t H, int32_t W, int32_t Cin,

@@ -115,6 +115,7 @@ class PixLocPoseTrackerR9(PoseTracker):
         # reference_scale) are rendered at the same pose each frame; when the two cameras coincide
         # (same size and fx: all get_nerf_image reads) one march yields both, bit for bit.
         self.fuse_identical_views = True
+        self.batch_frame_images = True  # reference render + masked query in one batched UNet pass
         self._fused_reference = None  # (pose object, uint8 image) handed from get_mask to get_reference_image
         self._ref_cam_cache = None
         self._coincide_cache = None
@@ -247,6 +248,12 @@ class PixLocPoseTrackerR9(PoseTracker):
             refiner.conf.multiscale = [1]
             refiner.query_mask = self.get_mask(self.pose)  # multiplied inside the first conv
 
+        # The masked query is fully known here, before the reference render is encoded: announce
+        # it so both images of the frame go through the UNet in one batched pass.
+        if self.batch_frame_images and refiner.conf.multiscale == [1]:
+            refiner.feature_extractor.stage(query_image, 1, refiner.query_mask, True)
+        else:
+            refiner.feature_extractor.unstage()
         self.dynamic_id = self.get_dynamic_id(self.pose)
         rotation, translation = self.pose.numpy()
         rotation = R.from_matrix(rotation).as_matrix()

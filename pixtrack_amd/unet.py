@@ -258,27 +258,39 @@ class UNet:
                        normalize: bool = False) -> List[torch.Tensor]:
         """image: HWC, 3 channels, 0..255, float32 or uint8, on the device.  Returns the
         three HWC float32 maps [h,w,cstride] (descriptor channels then confidence)."""
+        return self.forward_packed_batch([(image, mask, normalize)])[0]
+
+    def forward_packed_batch(self, items) -> List[List[torch.Tensor]]:
+        """items: [(image, mask or None, normalize)], images of one size -> per image the three
+        maps of forward_packed, from ONE set of launches (pxt_unet_forward_batch)."""
         L = _lib.lib()
-        _lib.require_gpu(image, "image")
-        assert image.dim() == 3 and image.shape[2] == 3 and image.is_contiguous()
-        assert image.dtype in (torch.float32, torch.uint8)
-        H, W = int(image.shape[0]), int(image.shape[1])
-        need = int(L.pxt_unet_workspace_bytes(self._ctx, H, W))
+        n = len(items)
+        H, W = int(items[0][0].shape[0]), int(items[0][0].shape[1])
+        for image, mask, _ in items:
+            _lib.require_gpu(image, "image")
+            assert image.dim() == 3 and image.shape[2] == 3 and image.is_contiguous()
+            assert image.dtype in (torch.float32, torch.uint8)
+            assert (int(image.shape[0]), int(image.shape[1])) == (H, W), "a batch holds images of one size"
+            if mask is not None:
+                assert mask.dtype == torch.uint8 and mask.shape == (H, W) and mask.is_contiguous()
+        need = int(L.pxt_unet_workspace_bytes_batch(self._ctx, n, H, W))
         if need <= 0:
-            raise _lib.PxtError(f"image {H}x{W} too small for the 4-level encoder")
+            raise _lib.PxtError(f"image {H}x{W} (batch {n}) is not supported by the 4-level encoder")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         shapes = self.level_shapes(H, W)
-        outs = [torch.empty(h, w, cstride_for(c), device=self.device, dtype=torch.float32)
-                for (h, w), c in zip(shapes, OUTPUT_DIMS)]
-        ptrs = (C.c_void_p * 3)(*[o.data_ptr() for o in outs])
-        cs = (C.c_int32 * 3)(*[o.shape[2] for o in outs])
-        if mask is not None:
-            assert mask.dtype == torch.uint8 and mask.shape == (H, W) and mask.is_contiguous()
+        outs = [[torch.empty(h, w, cstride_for(c), device=self.device, dtype=torch.float32)
+                 for (h, w), c in zip(shapes, OUTPUT_DIMS)] for _ in range(n)]
+        images = (C.c_void_p * n)(*[it[0].data_ptr() for it in items])
+        is_u8 = (C.c_int32 * n)(*[int(it[0].dtype == torch.uint8) for it in items])
+        masks = (C.c_void_p * n)(*[_lib.dptr(it[1]) for it in items])
+        norm = (C.c_int32 * n)(*[int(bool(it[2])) for it in items])
+        ptrs = (C.c_void_p * (3 * n))(*[o.data_ptr() for per in outs for o in per])
+        cs = (C.c_int32 * 3)(*[o.shape[2] for o in outs[0]])
         _lib.check(
-            L.pxt_unet_forward(self._ctx, image.data_ptr(), int(image.dtype == torch.uint8), _lib.dptr(mask),
-                               H, W, ptrs, cs, int(normalize), self._ws.data_ptr(), _lib.stream_ptr(self.device)),
-            "pxt_unet_forward",
+            L.pxt_unet_forward_batch(self._ctx, n, images, is_u8, masks, H, W, ptrs, cs, norm,
+                                     self._ws.data_ptr(), _lib.stream_ptr(self.device)),
+            "pxt_unet_forward_batch",
         )
         return outs
 

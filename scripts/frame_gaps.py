@@ -30,7 +30,7 @@ def wrap(obj, name, label):
     setattr(obj, name, g)
 
 wrap(NGP.Testbed, "render_both_device", "render")
-wrap(U.UNet, "forward_packed", "unet")
+wrap(U.UNet, "forward_packed_batch", "unet")
 wrap(O.PixTrackOptimizer, "refine_levels", "lm_launch")
 wrap(O.PendingLM, "result", "lm_result")
 wrap(RF.PoseTrackerRefiner, "interp_sparse_observations", "sample")

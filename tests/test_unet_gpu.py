@@ -105,3 +105,36 @@ def test_unet_module_call_convention(device):
 def test_unet_config5_resolution(device):
     """1024x576 (what a 1920x1080 query becomes after the extractor's resize)."""
     _compare_pyramid(device, 576, 1024, normalize=True, seed=9, bn_trivial=True)
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (48, 80)])
+def test_unet_batch_matches_single_images_and_oracle(device, H, W):
+    """pxt_unet_forward_batch: a u8 image and a masked float image in one pass.  Each image's
+    maps equal its single-image maps up to fp32 summation order (the split-K factor depends
+    on the batch), do not depend on the batch neighbour, and match the CPU oracle."""
+    w = make_synthetic_unet_weights(seed=5)
+    rng = np.random.default_rng(9)
+    a = np.floor(rng.uniform(0, 255, size=(H, W, 3))).astype(np.uint8)
+    b = rng.uniform(0, 255, size=(H, W, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(H, W)) > 0.3).astype(np.uint8)
+    net = UNet(w, device)
+    ta, tb, tm = torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), torch.from_numpy(mask).to(device)
+    single_a = [o.clone() for o in net.forward_packed(ta, None, normalize=False)]
+    single_b = [o.clone() for o in net.forward_packed(tb, tm, normalize=True)]
+    both = net.forward_packed_batch([(ta, None, False), (tb, tm, True)])
+    swapped = net.forward_packed_batch([(tb, tm, True), (ta, None, False)])
+    other = net.forward_packed_batch([(ta, None, False), (ta, None, False)])
+    torch.cuda.synchronize()
+    for k in range(3):
+        for got, ref in ((both[0][k], single_a[k]), (both[1][k], single_b[k])):
+            scale = ref.abs().max().item()
+            assert (got - ref).abs().max().item() < 2e-3 * scale, k
+        assert torch.equal(both[0][k], swapped[1][k]) and torch.equal(both[1][k], swapped[0][k])
+        assert torch.equal(both[0][k], other[0][k]) and torch.equal(other[0][k], other[1][k])
+    feats, confs = UO.unet_forward(w, torch.from_numpy(b * mask[..., None]).permute(2, 0, 1) / 255.0)
+    for k, c in enumerate(OUTPUT_DIMS):
+        f_ref = feats[k].permute(1, 2, 0)
+        f_ref = f_ref / f_ref.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        cos = F.cosine_similarity(both[1][k][..., :c].cpu(), f_ref, dim=-1)
+        assert cos.min().item() > 0.9995, (k, cos.min().item())
+        assert (both[1][k][..., c].cpu() - confs[k][0]).abs().max().item() < 5e-3
