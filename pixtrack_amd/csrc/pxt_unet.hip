@@ -114,14 +114,23 @@ constexpr int kRowPitch = 768;
 constexpr int kInHalves = (kTH + 2) * kRowPitch;
 constexpr int kHaloLoads = (kHalo * 4 + 255) / 256;  // 16-B staging loads per thread: halo
 
-template <int NT>  // output channels per workgroup = 32 * NT
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restrict__ in, int H,
+// Decoder input cat([bilinear x2 upsample(prev) (align_corners=False), skip[:2Hp, :2Wp]]) formed
+// while staging (UPCAT): channels [0, Cp) of the conv input are interpolated from `prev`
+// [Hp][Wp][Cp], the rest come from `in` = skip [Hs][Ws][Cin - Cp].  Same fp32 lerp and fp16
+// rounding as a materialised concat would give.
+struct UpSrc {
+  const half_t* prev;
+  int Hp, Wp, Cp, Hs, Ws;
+};
+
+template <int NT, bool UPCAT>  // output channels per workgroup = 32 * NT
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const half_t* __restrict__ in, int H,
                                                            int W, int Cin,
                                                            const half_t* __restrict__ wts,
                                                            const float* __restrict__ bias,
                                                            int Cout, int relu,
                                                            half_t* __restrict__ out,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, UpSrc up) {
   // gridDim.z > 1: split-K over the Cin chunks; every z-slice writes its fp32 partial sums to
   // partial[z][pixel][cout] and splitk_reduce_kernel finishes (fixed order: deterministic).
   constexpr int BNC = 32 * NT;
@@ -139,7 +148,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
   const int n_img = gridDim.x / tiles_per;
   const int ty0 = (tile / tiles_x) * kTH, tx0 = (tile % tiles_x) * kTW;
   const int co0 = blockIdx.y * BNC;
-  in += (size_t)img * H * W * Cin;
+  const int Cs = UPCAT ? Cin - up.Cp : Cin;       // channels held by `in`
+  const int in_w = UPCAT ? up.Ws : W;              // its row pitch in pixels
+  in += (size_t)img * (UPCAT ? up.Hs : H) * in_w * Cs;
+  const half_t* prev = UPCAT ? up.prev + (size_t)img * up.Hp * up.Wp * up.Cp : nullptr;
   out += (size_t)img * H * W * Cout;
 
   f32x16 acc[2][NT];
@@ -168,19 +180,74 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const half_t* __restr
   constexpr int kWTotal = 9 * BNC * 4;
   constexpr int kWLoads = (kWTotal + 255) / 256;
   half8 r_in[kHaloLoads], r_w[kWLoads];
-  auto prefetch = [&](int c0) {
+  // Offsets are 32-bit element indices from wave-uniform bases (saddr loads): every map of the
+  // pyramid has < 2^31 elements per image.
+  // UPCAT: per staged halo element, the bilinear footprint is chunk-invariant.  It is kept as ONE
+  // offset + ONE flag word (x/y neighbour present, the weights are exactly 0, 1/4 or 3/4) so that
+  // the loop-invariant state costs 12 VGPRs rather than 36 (which would cost the second wave).
+  unsigned up_off[UPCAT ? kHaloLoads : 1], up_flg[UPCAT ? kHaloLoads : 1];
+  if (UPCAT) {
 #pragma unroll
     for (int k = 0; k < kHaloLoads; ++k) {
       const int i = tid + 256 * k;
       const int pix = i >> 2, seg = i & 3;
       const int hy = pix / (kTW + 2), hx = pix % (kTW + 2);
       const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-      half8 v;
+      const bool ok = i < kHalo * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float sy = fmaxf(((float)gy + 0.5f) * 0.5f - 0.5f, 0.f);
+      const float sx = fmaxf(((float)gx + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = min(y0 + 1, up.Hp - 1), x1 = min(x0 + 1, up.Wp - 1);
+      const float ay = sy - (float)y0, ax = sx - (float)x0;  // exactly 0, 0.25 or 0.75
+      up_off[k] = ok ? (unsigned)(y0 * up.Wp + x0) * (unsigned)up.Cp + (unsigned)(seg * 8) : 0u;
+      up_flg[k] = (ok ? 64u : 0u) | (x1 != x0 ? 1u : 0u) | (y1 != y0 ? 2u : 0u) |
+                  (ax == 0.25f ? 4u : ax == 0.75f ? 8u : 0u) | (ay == 0.25f ? 16u : ay == 0.75f ? 32u : 0u);
+    }
+  }
+  auto prefetch = [&](int c0) {
+    if (UPCAT && c0 < up.Cp) {
+      const unsigned step_x = (unsigned)up.Cp, step_y = (unsigned)(up.Wp * up.Cp);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-      if (i < kHalo * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = *(const half8*)(in + ((size_t)gy * W + gx) * Cin + c0 + seg * 8);
-      r_in[k] = v;
+      for (int k = 0; k < kHaloLoads; ++k) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+        const unsigned f = up_flg[k];
+        if (f & 64u) {
+          const unsigned o00 = up_off[k] + (unsigned)c0;
+          const unsigned dx = (f & 1u) ? step_x : 0u, dy = (f & 2u) ? step_y : 0u;
+          const float ax = (f & 4u) ? 0.25f : (f & 8u) ? 0.75f : 0.f;
+          const float ay = (f & 16u) ? 0.25f : (f & 32u) ? 0.75f : 0.f;
+          const half8 a = *(const half8*)(prev + o00);
+          const half8 b = *(const half8*)(prev + (o00 + dx));
+          const half8 d = *(const half8*)(prev + (o00 + dy));
+          const half8 e = *(const half8*)(prev + (o00 + dy + dx));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float top = (float)a[j] * (1.f - ax) + (float)b[j] * ax;
+            const float bot = (float)d[j] * (1.f - ax) + (float)e[j] * ax;
+            v[j] = (half_t)(top * (1.f - ay) + bot * ay);
+          }
+        }
+        r_in[k] = v;
+        // one element's taps (4 x 16 B) in flight at a time keeps the kernel within 256 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const unsigned cc = (unsigned)(c0 - (UPCAT ? up.Cp : 0));
+#pragma unroll
+      for (int k = 0; k < kHaloLoads; ++k) {
+        const int i = tid + 256 * k;
+        const int pix = i >> 2, seg = i & 3;
+        const int hy = pix / (kTW + 2), hx = pix % (kTW + 2);
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+        if (i < kHalo * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = *(const half8*)(in + ((unsigned)(gy * in_w + gx) * (unsigned)Cs + cc + (unsigned)(seg * 8)));
+        r_in[k] = v;
+      }
     }
 #pragma unroll
     for (int k = 0; k < kWLoads; ++k) {
@@ -386,47 +453,6 @@ __global__ void maxpool2_kernel(const half_t* __restrict__ in, int H, int W, int
 }
 
 // ---------------------------------------------------------------------------
-// Decoder input: cat([bilinear x2 upsample(prev) (align_corners=False), skip[:hu,:wu]]).
-// ---------------------------------------------------------------------------
-__global__ void upcat_kernel(const half_t* __restrict__ prev, int Hp, int Wp, int Cp,
-                             const half_t* __restrict__ skip, int Hs, int Ws, int Cs,
-                             half_t* __restrict__ out, int n_img) {
-  const int Ho = 2 * Hp, Wo = 2 * Wp, Ct = Cp + Cs;
-  const int c8 = Ct / 8;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)n_img * Ho * Wo * c8) return;
-  const int c = (int)(i % c8) * 8;
-  long long p = i / c8;
-  const int img = (int)(p / ((long long)Ho * Wo));
-  p -= (long long)img * Ho * Wo;
-  prev += (size_t)img * Hp * Wp * Cp;
-  skip += (size_t)img * Hs * Ws * Cs;
-  out += (size_t)img * Ho * Wo * Ct;
-  const int x = (int)(p % Wo), y = (int)(p / Wo);
-  half8 o;
-  if (c < Cp) {
-    float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.f);
-    float sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.f);
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = min(y0 + 1, Hp - 1), x1 = min(x0 + 1, Wp - 1);
-    const float ay = sy - (float)y0, ax = sx - (float)x0;
-    const half8 a = *(const half8*)(prev + ((size_t)y0 * Wp + x0) * Cp + c);
-    const half8 b = *(const half8*)(prev + ((size_t)y0 * Wp + x1) * Cp + c);
-    const half8 d = *(const half8*)(prev + ((size_t)y1 * Wp + x0) * Cp + c);
-    const half8 e = *(const half8*)(prev + ((size_t)y1 * Wp + x1) * Cp + c);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float top = (float)a[j] * (1.f - ax) + (float)b[j] * ax;
-      const float bot = (float)d[j] * (1.f - ax) + (float)e[j] * ax;
-      o[j] = (half_t)(top * (1.f - ay) + bot * ay);
-    }
-  } else {
-    o = *(const half8*)(skip + ((size_t)y * Ws + x) * Cs + (c - Cp));
-  }
-  *(half8*)(out + ((size_t)y * Wo + x) * Ct + c) = o;
-}
-
-// ---------------------------------------------------------------------------
 // Context
 // ---------------------------------------------------------------------------
 struct UnetLayer {
@@ -472,7 +498,7 @@ struct Plan {
   int h[5], w[5];          // encoder block resolutions
   int dh[4], dw[4];        // decoder block output resolutions
   // byte offsets into the workspace
-  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_cat[4], dec_out[4], splitk, total;
+  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_out[4], splitk, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -499,7 +525,6 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
   }
   for (int d = 0; d < 4; ++d) {
     const size_t px = (size_t)n_img * P.dh[d] * P.dw[d];
-    P.dec_cat[d] = take(px * ctx->conv[13 + d].cin * 2);
     P.dec_out[d] = take(px * ctx->conv[13 + d].cout * 2);
   }
   // one split-K partial buffer, sized for the hungriest layer
@@ -518,16 +543,21 @@ void set_conv_lds_attr() {
   // the conv kernels stage > 64 KiB of LDS (gfx950 has 160 KiB per CU)
   static bool done = false;
   if (done) return;
-  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)((kInHalves + 9 * 64 * kPix) * sizeof(half_t)));
-  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)((kInHalves + 9 * 32 * kPix) * sizeof(half_t)));
+  const int lds2 = (int)((kInHalves + 9 * 64 * kPix) * sizeof(half_t));
+  const int lds1 = (int)((kInHalves + 9 * 32 * kPix) * sizeof(half_t));
+  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
   done = true;
 }
 
 int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out, hipStream_t s,
-                int relu = 1, float* partial = nullptr, int n_img = 1) {
+                int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr) {
   if (L.cin % kCK != 0 || L.cout % 32 != 0) return PXT_E_ARG;
+  if (up && (up->Cp % kCK != 0 || up->Cp >= L.cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
+    return PXT_E_ARG;
+  const UpSrc u = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
   set_conv_lds_attr();
   const int tiles = n_img * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
   const bool wide = L.cout % 64 == 0;
@@ -535,12 +565,20 @@ int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out,
   const int splits = partial ? choose_splits(tiles, nb, L.cin / kCK) : 1;
   if (wide) {
     const size_t lds = (size_t)(kInHalves + 9 * 64 * kPix) * sizeof(half_t);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
-                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
+    if (up)
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<2, true>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
+                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
+    else
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<2, false>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
+                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
   } else {
     const size_t lds = (size_t)(kInHalves + 9 * 32 * kPix) * sizeof(half_t);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
-                       L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial);
+    if (up)
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<1, true>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
+                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
+    else
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<1, false>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
+                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
   }
   if (splits > 1) {
     const long long n4 = (long long)n_img * H * W * L.cout / 4;
@@ -717,12 +755,10 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     const UnetLayer& L = ctx->conv[13 + d];
     const int sb = 3 - d;
     const int cs = L.cin - pc;
-    half_t* cat = buf(P.dec_cat[d]);
-    const long long n = (long long)B * P.dh[d] * P.dw[d] * (L.cin / 8);
-    hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, prev, ph, pw, pc,
-                       skip[sb], P.h[sb], P.w[sb], cs, cat, B);
+    if (cs <= 0) return PXT_E_ARG;
+    const UpSrc up{prev, ph, pw, pc, P.h[sb], P.w[sb]};  // upsample + concat happen in the conv's staging
     half_t* o = buf(P.dec_out[d]);
-    int rc = launch_conv(L, cat, P.dh[d], P.dw[d], o, s, 1, (float*)(ws + P.splitk), B);
+    int rc = launch_conv(L, skip[sb], P.dh[d], P.dw[d], o, s, 1, (float*)(ws + P.splitk), B, &up);
     if (rc != PXT_OK) return rc;
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
