@@ -34,70 +34,71 @@ constexpr int kNumHeads = 3;
 // First layer: image (HWC, 0..255, float or u8) [* mask] -> /255 -> ImageNet
 // normalisation -> conv3x3 (3 -> Cout) + bias + ReLU -> fp16 NHWC.  HBM-bound.
 // ---------------------------------------------------------------------------
+// A workgroup owns a 64 x 4 pixel strip: the normalised 66 x 6 x 3 input window is computed once
+// into LDS; then thread = pixel, all Cout channels, 16 at a time.  The filter index is
+// wave-uniform, so the 27 x Cout weights arrive as scalar loads (SGPR operands of the FMAs):
+// no LDS or vector-memory traffic for them at all.
+constexpr int kFW = 64, kFH = 4;
 template <bool U8>
 __global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict__ image,
                                                          const uint8_t* __restrict__ mask, int H,
                                                          int W, const float* __restrict__ wts,
                                                          const float* __restrict__ bias, int Cout,
                                                          half_t* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [27][Cout] + bias[Cout]
-  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
-    int co = i / 27, k = i % 27;
-    s_w[k * Cout + co] = wts[i];
-  }
-  for (int i = threadIdx.x; i < Cout; i += blockDim.x) s_w[27 * Cout + i] = bias[i];
-  __syncthreads();
-  const int groups = Cout / 16;  // threads per pixel, 16 output channels each
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long pix = gid / groups;
-  const int cg = (int)(gid % groups);
-  if (pix >= (long long)H * W) return;
-  const int y = (int)(pix / W), x = (int)(pix % W);
+  __shared__ float s_px[(kFH + 2) * (kFW + 2) * 3];
+  const int tiles_x = (W + kFW - 1) / kFW;
+  const int tx0 = (blockIdx.x % tiles_x) * kFW, ty0 = (blockIdx.x / tiles_x) * kFH;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
   const float istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+  for (int i = threadIdx.x; i < (kFH + 2) * (kFW + 2); i += 256) {
+    const int hy = i / (kFW + 2), hx = i % (kFW + 2);
+    const int yy = ty0 + hy - 1, xx = tx0 + hx - 1;
+    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    float m = 1.f;
+    if (ok && mask) m = (float)mask[(size_t)yy * W + xx];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = 0.f;
+      if (ok) {
+        const size_t idx = ((size_t)yy * W + xx) * 3 + c;
+        float raw = U8 ? (float)((const uint8_t*)image)[idx] : ((const float*)image)[idx];
+        if (mask) raw *= m;
+        v = (raw / 255.0f - mean[c]) * istd[c];
+      }
+      s_px[i * 3 + c] = v;
+    }
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int x = tx0 + lx, y = ty0 + ly;
   float in[27];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int yy = y + ky - 1, xx = x + kx - 1;
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float v = 0.f;
-        if (ok) {
-          const size_t idx = ((size_t)yy * W + xx) * 3 + c;
-          float raw = U8 ? (float)((const uint8_t*)image)[idx] : ((const float*)image)[idx];
-          if (mask) raw *= (float)mask[(size_t)yy * W + xx];
-          v = (raw / 255.0f - mean[c]) * istd[c];
-        }
-        in[(ky * 3 + kx) * 3 + c] = v;
-      }
+      for (int c = 0; c < 3; ++c) in[(ky * 3 + kx) * 3 + c] = s_px[((ly + ky) * (kFW + 2) + lx + kx) * 3 + c];
+  if (x >= W || y >= H) return;
+  half_t* dst = out + ((size_t)y * W + x) * Cout;
+  for (int cg = 0; cg < Cout / 16; ++cg) {  // uniform: wts / bias below are scalar loads
+    const float* wg = wts + (size_t)cg * 16 * 27;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
+    // same accumulation order as a k-major loop per output channel: acc_j += in_k * w_jk, k = 0..26
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] += in[k] * wg[j * 27 + k];
+    half8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0[j] = (half_t)fmaxf(acc[j], 0.f);
+      o1[j] = (half_t)fmaxf(acc[8 + j], 0.f);
     }
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = s_w[27 * Cout + cg * 16 + j];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const float4* wr = (const float4*)(s_w + k * Cout + cg * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 w4 = wr[q];
-      acc[4 * q + 0] += in[k] * w4.x;
-      acc[4 * q + 1] += in[k] * w4.y;
-      acc[4 * q + 2] += in[k] * w4.z;
-      acc[4 * q + 3] += in[k] * w4.w;
-    }
+    *(half8*)(dst + cg * 16) = o0;
+    *(half8*)(dst + cg * 16 + 8) = o1;
   }
-  half8 o0, o1;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    o0[j] = (half_t)fmaxf(acc[j], 0.f);
-    o1[j] = (half_t)fmaxf(acc[8 + j], 0.f);
-  }
-  half_t* dst = out + (size_t)pix * Cout + cg * 16;
-  *(half8*)dst = o0;
-  *(half8*)(dst + 8) = o1;
 }
 
 // ---------------------------------------------------------------------------
@@ -714,18 +715,17 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
       // the images differ in type (u8 render / float frame) and mask: one launch each, all
       // writing into the batched activation buffer
       const UnetLayer& L0 = ctx->conv[0];
-      const long long threads = (long long)h * w * (L0.cout / 16);
-      const size_t lds = (size_t)(28 * L0.cout) * sizeof(float);
+      const unsigned nblk = (unsigned)(((w + kFW - 1) / kFW) * ((h + kFH - 1) / kFH));
       half_t* o = buf(P.enc_tmp[0][0]);
       for (int i = 0; i < B; ++i) {
         half_t* oi = o + (size_t)i * h * w * L0.cout;
         const uint8_t* m = masks ? masks[i] : nullptr;
         if (image_is_u8[i])
-          hipLaunchKernelGGL(conv_first_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
-                             images[i], m, h, w, (const float*)L0.w, L0.b, L0.cout, oi);
+          hipLaunchKernelGGL(conv_first_kernel<true>, dim3(nblk), dim3(256), 0, s, images[i], m, h, w,
+                             (const float*)L0.w, L0.b, L0.cout, oi);
         else
-          hipLaunchKernelGGL(conv_first_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s,
-                             images[i], m, h, w, (const float*)L0.w, L0.b, L0.cout, oi);
+          hipLaunchKernelGGL(conv_first_kernel<false>, dim3(nblk), dim3(256), 0, s, images[i], m, h, w,
+                             (const float*)L0.w, L0.b, L0.cout, oi);
       }
       x = o;
     } else {
