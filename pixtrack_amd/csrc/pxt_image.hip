@@ -41,6 +41,66 @@ __global__ void morph5_kernel(const uint8_t* __restrict__ src, int H, int W, uin
   dst[(size_t)y * W + x] = r;
 }
 
+// The whole mask in one pass.  n erosions (dilations) with the 5x5 box and OpenCV's default
+// borders are one erosion (dilation) with the (4n+1)^2 box over the in-image pixels, and a box is
+// separable, so a 64x16 tile needs the `!= 0` plane over a (re + rd) halo and four 1-D passes in
+// LDS: erode rows, erode columns, dilate rows, dilate columns.  Values are 0/1: min = AND, max = OR.
+constexpr int kMW = 64, kMH = 16;
+__global__ __launch_bounds__(256) void depth_mask_fused_kernel(const float* __restrict__ rgba, int H, int W, int re,
+                                                               int rd, uint8_t* __restrict__ out) {
+  extern __shared__ uint8_t sm[];
+  const int R = re + rd;
+  const int aw = kMW + 2 * R, ah = kMH + 2 * R;     // input plane
+  const int bw = kMW + 2 * rd;                       // after the row erosion (height ah)
+  const int ch = kMH + 2 * rd;                       // after the column erosion (width bw)
+  uint8_t* A = sm;                 // [ah][aw]
+  uint8_t* B = A + ah * aw;        // [ah][bw]
+  uint8_t* Cc = B + ah * bw;       // [ch][bw]
+  uint8_t* D = Cc + ch * bw;       // [ch][kMW]
+  const int x0 = blockIdx.x * kMW, y0 = blockIdx.y * kMH;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = tid; i < ah * aw; i += 256) {
+    const int yy = y0 - R + i / aw, xx = x0 - R + i % aw;
+    uint8_t v = 1;  // outside the image: neutral for the erosion
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const float f = rgba[4 * ((size_t)yy * W + xx)] * 255.0f;
+      v = (((long long)f & 255) != 0) ? 1 : 0;  // numpy float32 -> uint8 astype, then != 0
+    }
+    A[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < ah * bw; i += 256) {
+    const int r = i / bw, c = i % bw;
+    uint8_t v = 1;
+    for (int d = 0; d <= 2 * re; ++d) v &= A[r * aw + c + d];
+    B[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < ch * bw; i += 256) {
+    const int r = i / bw, c = i % bw;
+    uint8_t v = 1;
+    for (int d = 0; d <= 2 * re; ++d) v &= B[(r + d) * bw + c];
+    const int yy = y0 - rd + r, xx = x0 - rd + c;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) v = 0;  // outside the image: neutral for the dilation
+    Cc[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < ch * kMW; i += 256) {
+    const int r = i / kMW, c = i % kMW;
+    uint8_t v = 0;
+    for (int d = 0; d <= 2 * rd; ++d) v |= Cc[r * bw + c + d];
+    D[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < kMH * kMW; i += 256) {
+    const int r = i / kMW, c = i % kMW;
+    uint8_t v = 0;
+    for (int d = 0; d <= 2 * rd; ++d) v |= D[(r + d) * kMW + c];
+    const int yy = y0 + r, xx = x0 + c;
+    if (yy < H && xx < W) out[(size_t)yy * W + xx] = v;
+  }
+}
+
 // get_nerf_image tail (run_vis_on_poses.py:52-54): zero where alpha < thresh, *255,
 // astype(uint8).
 __global__ void rgba_to_u8_kernel(const float* __restrict__ rgba, int n, float alpha_thresh,
@@ -90,6 +150,15 @@ extern "C" int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int
     return PXT_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int n = H * W;
+  const int re = 2 * n_erode, rd = 2 * n_dilate, R = re + rd;
+  if (R <= 16) {
+    const int aw = kMW + 2 * R, ah = kMH + 2 * R, bw = kMW + 2 * rd, ch = kMH + 2 * rd;
+    const size_t lds = (size_t)ah * aw + (size_t)ah * bw + (size_t)ch * bw + (size_t)ch * kMW;
+    hipLaunchKernelGGL(depth_mask_fused_kernel, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(64, 4), lds, s,
+                       depth_rgba, H, W, re, rd, mask_out);
+    PXT_HIP_CHECK(hipGetLastError());
+    return PXT_OK;
+  }
   uint8_t* a = tmp;
   uint8_t* b = tmp + n;
   hipLaunchKernelGGL(depth_nonzero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, depth_rgba, n, a);

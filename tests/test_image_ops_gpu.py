@@ -17,12 +17,15 @@ def np_morph(img, erode):
     return (np.min if erode else np.max)(np.stack(stack, 0), axis=0)
 
 
-def test_depth_mask_matches_cv2_semantics(device):
+@pytest.mark.parametrize("H,W,ne,nd,y0,x0", [(60, 84, 1, 5, 15, 20), (60, 84, 1, 5, 0, 44), (97, 150, 2, 3, 67, 0),
+                                              (60, 84, 2, 7, 15, 20), (40, 70, 0, 2, 10, 30)])
+def test_depth_mask_matches_cv2_semantics(device, H, W, ne, nd, y0, x0):
+    """(1, 5) is the tracker's setting (single fused pass); (2, 7) exceeds the fused kernel's halo
+    and takes the iterated kernels; blobs touching the border exercise OpenCV's border rule."""
     rng = np.random.default_rng(1)
-    H, W = 60, 84
     depth = np.zeros((H, W, 4), np.float32)
     blob = np.zeros((H, W), np.float32)
-    blob[15:45, 20:60] = rng.uniform(0.5, 2.0, size=(30, 40))
+    blob[y0:y0 + 30, x0:x0 + 40] = rng.uniform(0.5, 2.0, size=(30, 40))
     blob[rng.uniform(size=(H, W)) > 0.97] = 1.0   # speckles the erosion must remove
     blob[30, 40] = 0.0                            # pin-hole the erosion must widen
     blob[5, 5] = 0.003                            # < 1/255 -> uint8 0
@@ -30,13 +33,14 @@ def test_depth_mask_matches_cv2_semantics(device):
     depth[..., :3] = blob[..., None]
     ref = ((depth[..., 0] * 255.0).astype(np.int64) & 255) != 0
     ref = ref.astype(np.uint8)
-    ref = np_morph(ref, True)
-    for _ in range(5):
+    for _ in range(ne):
+        ref = np_morph(ref, True)
+    for _ in range(nd):
         ref = np_morph(ref, False)
     d = torch.from_numpy(depth).to(device)
     out = torch.zeros(H, W, dtype=torch.uint8, device=device)
     tmp = torch.zeros(2 * H * W, dtype=torch.uint8, device=device)
-    _lib.check(_lib.lib().pxt_depth_mask(d.data_ptr(), H, W, 1, 5, out.data_ptr(), tmp.data_ptr(),
+    _lib.check(_lib.lib().pxt_depth_mask(d.data_ptr(), H, W, ne, nd, out.data_ptr(), tmp.data_ptr(),
                                          _lib.stream_ptr(device)), "pxt_depth_mask")
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), ref)
