@@ -567,11 +567,10 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, cons
     const long long s = (item % chunks) * 256 + threadIdx.x;
     if (s >= ns) continue;
     const float4 sp = Wk.spos[s];
-    unsigned pk = 0u;
-    if (sp.w != 0.f)
-      pk = ngp_encode_level(P.grid, P.lv[l], (sp.x - scene_lo) * inv_s, (sp.y - scene_lo) * inv_s,
-                            (sp.z - scene_lo) * inv_s);
-    Wk.feat[(size_t)l * Wk.feat_stride + s] = pk;
+    if (sp.w == 0.f) continue;  // no sample in this slot: shade never reads its features
+    Wk.feat[(size_t)l * Wk.feat_stride + s] =
+        ngp_encode_level(P.grid, P.lv[l], (sp.x - scene_lo) * inv_s, (sp.y - scene_lo) * inv_s,
+                         (sp.z - scene_lo) * inv_s);
   }
 }
 
@@ -614,8 +613,10 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
       Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
       Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
     }
-    float logit, rgbv[3];
-    ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+    float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
+    // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
+    // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
+    if (__any(valid)) ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
     // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
     const float T0 = S.T[sl];
     float alpha = 0.f;

@@ -34,6 +34,9 @@ wrap(U.UNet, "forward_packed_batch", "unet")
 wrap(O.PixTrackOptimizer, "refine_levels", "lm_launch")
 wrap(O.PendingLM, "result", "lm_result")
 wrap(RF.PoseTrackerRefiner, "interp_sparse_observations", "sample")
+wrap(RF.PoseTrackerRefiner, "dense_feature_extraction", "dense")
+wrap(RF.PoseTrackerRefiner, "refine_pose_using_features", "rpuf")
+wrap(RF.PoseTrackerRefiner, "refine", "refine")
 
 for i in range(5):
     tr.run_single_frame((names[i], frames[i]))
