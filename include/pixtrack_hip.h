@@ -89,7 +89,8 @@ typedef struct {
 /* Output record (device, floats):
  *   out[0..11]  T_refined (12)        out[12] failed (0/1)
  *   out[13]     status (0 ok, PXT_E_TIMEOUT as float if a spin bound tripped)
- *   out[14]     total iterations      out[15] reserved
+ *   out[14]     total iterations      out[15] 1.0, stored last with system-scope release
+ *               (a host polling `out` in pinned memory may read the record once it sees it)
  *   out[16 + l] iterations run at level l (execution order), l < n_levels
  * Log (device, optional, may be NULL): log[(l*num_iters + i)*PXT_LM_LOG_STRIDE + k]
  *   k=0 masked-mean cost BEFORE the update of iteration i (tracker.py:40-41)

@@ -172,7 +172,8 @@ class Pose(TensorWrapper):
         return torch.cat([J_t, J_rot], dim=-1)
 
     def numpy(self) -> Tuple[np.ndarray, np.ndarray]:
-        return self.R.numpy(), self.t.numpy()
+        a = self._data.numpy()  # one conversion (this sits on the per-frame critical path)
+        return a[..., :9].reshape(a.shape[:-1] + (3, 3)), a[..., 9:]
 
     def magnitude(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(rotation angle in DEGREES, translation norm)."""

@@ -356,7 +356,16 @@ class PendingLM:
     def result(self) -> LMResult:
         # This sits on the frame's critical path (the next frame's render waits for the pose):
         # one blocking copy, then plain numpy/Python on the host record.
-        self._done.synchronize()
+        # The kernel's last store (system-scope release) sets out[15]: poll it in the pinned
+        # buffer - cheaper than an event wake-up on the frame's critical path.  The event is the
+        # fallback for a kernel that never gets there (it then reports through `status`).
+        flag = self.buf.numpy()
+        spins = 0
+        while flag[15] == 0.0:
+            spins += 1
+            if spins > 2_000_000 or (spins & 0x3FFF) == 0 and self._done.query():
+                self._done.synchronize()
+                break
         host = self.buf.clone()  # the pinned buffer is reused two refinements later
         h = host.numpy()
         nh = 16 + _lib.PXT_MAX_LEVELS

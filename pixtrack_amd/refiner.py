@@ -243,12 +243,13 @@ class PoseTrackerRefiner:
         if res.failed:
             return {**ret, "success": False}
         T_opt = Pose(res.T.as12().double())  # already on the host (pixloc: T_opt.cpu().double())
-        # (T_init^-1 @ T_opt).magnitude() in float64, as pixloc does, without a dozen tiny torch ops
-        a, b = T_init.as12().detach().cpu().double().numpy(), T_opt.as12().numpy()
-        R0, R1 = a[:9].reshape(3, 3), b[:9].reshape(3, 3)
-        cos = min(1.0, max(-1.0, (float(np.trace(R0.T @ R1)) - 1.0) / 2.0))
+        # (T_init^-1 @ T_opt).magnitude() in float64 as pixloc does, on 24 Python floats: this runs
+        # between the LM result and the next frame's first launch
+        a, b = T_init.as12().detach().cpu().double().tolist(), T_opt.as12().tolist()
+        cos = min(1.0, max(-1.0, (sum(a[i] * b[i] for i in range(9)) - 1.0) / 2.0))  # trace(R0^T R1)
         dR = abs(math.acos(cos)) / math.pi * 180.0
-        dt = float(np.linalg.norm(R0.T @ (b[9:] - a[9:])))
+        d = (b[9] - a[9], b[10] - a[10], b[11] - a[11])
+        dt = math.sqrt(sum((a[j] * d[0] + a[3 + j] * d[1] + a[6 + j] * d[2]) ** 2 for j in range(3)))  # |R0^T d|
         return {**ret, "success": True, "T_refined": T_opt, "diff_R": dR, "diff_t": dt}
 
 
