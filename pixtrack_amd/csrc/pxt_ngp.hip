@@ -406,6 +406,7 @@ struct NgpWork {
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
   uint8_t* keep;       // per slot: the ray continues into the next round (written by shade)
   float* cand_t;       // per enumerated ray: start t, or < 0 for rays that miss the box
+  float4* raydir;      // [pixel * spp + s] = (unit direction, d . camera z): what shading needs of a ray
   float4* sppbuf;      // [pixel][spp] finished rays
   float* sppbuf_d;     // mode 2: finished rays' depth
   size_t feat_stride;  // samples per level plane
@@ -455,6 +456,9 @@ __global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const 
         h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
         const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
         t0 = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+        // the shade kernel runs 8 lanes per ray per round: it reads these instead of redoing
+        // make_ray's fourteen divisions in every lane
+        Wk.raydir[(size_t)pix * P.spp + s] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
       }
     }
     Wk.cand_t[i] = t0;
@@ -603,10 +607,10 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     const float dt = ray_ok ? sp.w : 0.f;
     const bool valid = dt != 0.f;
     const unsigned rid = S.rid[sl];
-    const int pix = (int)(rid / (unsigned)P.spp);
-    const Ray r = make_ray(P, pix % P.W, pix / P.W);
+    const float4 rd = Wk.raydir[rid];
+    const float rdir[3] = {rd.x, rd.y, rd.z};
     unsigned shB0[4], shB1[4];
-    sh_fragments(r.d, shB0, shB1);
+    sh_fragments(rdir, shB0, shB1);
     unsigned Flo[8], Fhi[8];
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     float alpha = 0.f;
     if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
     float depth = 0.f;
-    if (MODE != 0) depth = (Wk.st_t[si] * r.zdot) * P.depth_scale;
+    if (MODE != 0) depth = (Wk.st_t[si] * rd.w) * P.depth_scale;
     if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
     // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
     float pinc = 1.0f - alpha;
@@ -968,6 +972,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   const size_t o_spos = take(samples * 16), o_stt = take(samples * 4);
   const size_t o_feat = take(samples * 4 * kMaxLevels), o_exh = take(rays), o_spp = take(rays * 16);
   const size_t o_keep = take(rays), o_cand = take((rays + 64 * 8) * 4 + 4096);
+  const size_t o_rdir = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
   if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
   char* b = (char*)ctx->scratch;
@@ -986,6 +991,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   W.sppbuf_d = (float*)(b + o_sppd);
   W.keep = (uint8_t*)(b + o_keep);
   W.cand_t = (float*)(b + o_cand);
+  W.raydir = (float4*)(b + o_rdir);
   W.feat_stride = samples;
   ctx->scratch_rays = rays;
   return PXT_OK;
