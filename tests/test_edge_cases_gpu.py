@@ -1,0 +1,174 @@
+"""Edge cases and size-independent properties of the hot path through the C ABI: argument
+errors, degenerate inputs, and full-size (BASELINE configs[1]) invariants that need no oracle run."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from pixtrack_amd import _lib
+from pixtrack_amd.geometry import Camera, Pose
+from pixtrack_amd.ngp import RenderMode, Testbed
+from pixtrack_amd.optimizer import LevelPack, PixTrackOptimizer, cstride_for
+from pixtrack_amd.synthetic import PREMIER_PROTEIN_AABB, look_at_pose, make_lm_scene, make_synthetic_nerf
+from pixtrack_amd.unet import UNet, make_synthetic_unet_weights
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ C-ABI argument errors
+def test_entry_points_reject_bad_arguments(device):
+    L = _lib.lib()
+    ws = torch.zeros(int(L.pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    out = torch.zeros(24, device=device)
+    p3d = torch.zeros(16, 3, device=device)
+    conf = PixTrackOptimizer(dict(num_iters=5)).native_conf()
+    lv = (_lib.LmLevel * 1)()
+    T0 = (C.c_float * 12)(1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0)
+    # null map pointers / zero points / too many levels
+    assert L.pxt_lm_refine(p3d.data_ptr(), None, 16, lv, 1, T0, C.byref(conf), out.data_ptr(), None, ws.data_ptr(),
+                           None) == -1
+    assert L.pxt_lm_refine(p3d.data_ptr(), None, 0, lv, 1, T0, C.byref(conf), out.data_ptr(), None, ws.data_ptr(),
+                           None) == -1
+    assert L.pxt_lm_refine(p3d.data_ptr(), None, 16, lv, 9, T0, C.byref(conf), out.data_ptr(), None, ws.data_ptr(),
+                           None) == -1
+    assert L.pxt_unet_create(None, 0, C.byref(C.c_void_p())) == -1
+    assert L.pxt_ngp_render(None, None, None, None, None) == -1
+    assert L.pxt_depth_mask(None, 4, 4, 1, 5, None, None, None) == -1
+    with pytest.raises(_lib.PxtError):
+        _lib.check(-1, "probe")
+
+
+def test_unet_rejects_images_it_cannot_encode(device):
+    net = UNet(make_synthetic_unet_weights(1), device)
+    with pytest.raises(_lib.PxtError):  # 8 px: the fourth pooling would have nothing left
+        net.forward_packed(torch.zeros(8, 8, 3, device=device), None, False)
+    with pytest.raises(AssertionError):  # a batch holds one image size
+        net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False),
+                                  (torch.zeros(32, 48, 3, device=device), None, False)])
+    with pytest.raises(_lib.PxtError):  # PXT_UNET_MAX_BATCH
+        net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False)] * 9)
+
+
+# ------------------------------------------------------------------ LM degenerate inputs
+def _packs(sc, device):
+    lam = [10.0 ** (-6 + torch.sigmoid(torch.full((6,), -2.0)) * 11) for _ in range(3)]
+    packs = []
+    for level in reversed(range(3)):
+        fq = sc.feats_query[level]
+        Cc = fq.shape[0] - 1
+        cs = cstride_for(Cc)
+        fmap = torch.zeros(fq.shape[1], fq.shape[2], cs)
+        fmap[..., :Cc] = (fq[:-1] / fq[:-1].norm(dim=0, keepdim=True).clamp_min(1e-12)).permute(1, 2, 0)
+        fmap[..., Cc] = fq[-1]
+        fr = sc.feats_ref[level]
+        fref = torch.zeros(fr.shape[0], cs)
+        fref[:, :Cc] = fr[:, :-1] / fr[:, :-1].norm(dim=1, keepdim=True).clamp_min(1e-12)
+        fref[:, Cc] = fr[:, -1]
+        packs.append(LevelPack(fmap.to(device), fref.to(device), Cc, sc.camera.scale(sc.scales[level]), lam[level]))
+    return packs
+
+
+def test_lm_all_points_behind_the_camera_or_outside_the_image(device):
+    """No valid point at all: failed, pose returned unchanged, no NaN anywhere in the record."""
+    sc = make_lm_scene(seed=1007, width=160, height=120, n_points=300, sigma_px=2.0)
+    packs = _packs(sc, device)
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    conf = PixTrackOptimizer(dict(num_iters=20, pad=1)).native_conf()
+    behind = torch.from_numpy(sc.p3d).float().to(device)
+    R, t = sc.T_init.R.double().numpy(), sc.T_init.t.double().numpy()
+    flip = Pose.from_Rt(torch.from_numpy(np.diag([1.0, 1.0, -1.0]) @ R), torch.from_numpy(np.diag([1.0, 1.0, -1.0]) @ t))
+    for T0 in (flip, Pose.from_Rt(torch.from_numpy(R), torch.from_numpy(t + np.array([50.0, 0.0, 0.0])))):
+        res = PixTrackOptimizer.refine_levels(behind, packs, T0, conf, ws).result()
+        assert res.failed and res.total_iters == 1
+        assert torch.isfinite(res.T.as12()).all()
+        assert torch.allclose(res.T.as12(), T0.as12().float(), atol=1e-6)
+
+
+def test_lm_single_point_and_odd_counts(device):
+    """N = 1 (and N not a multiple of the lane-group size) run without touching memory past N."""
+    for n in (1, 11, 257):
+        sc = make_lm_scene(seed=1008, width=160, height=120, n_points=n, sigma_px=2.0)
+        packs = _packs(sc, device)
+        ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+        conf = PixTrackOptimizer(dict(num_iters=30, pad=1)).native_conf()
+        p3d = torch.from_numpy(sc.p3d).float().to(device)
+        res = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, conf, ws).result()
+        assert torch.isfinite(res.T.as12()).all()
+        assert res.failed == (n < 10)
+
+
+def test_lm_is_bitwise_repeatable_at_full_size(device):
+    """Fixed-order cross-workgroup reduction: the same inputs give the same bits, run after run."""
+    sc = make_lm_scene(seed=1009, width=640, height=480, n_points=2287, sigma_px=2.0)
+    packs = _packs(sc, device)
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    conf = PixTrackOptimizer(dict(num_iters=150, pad=1)).native_conf()
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    first = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, conf, ws).result()
+    for _ in range(4):
+        again = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, conf, ws).result()
+        assert torch.equal(first.T.as12(), again.T.as12()) and first.iters == again.iters
+        assert first.costs == again.costs
+    assert not first.failed
+
+
+# ------------------------------------------------------------------ NeRF full-size properties
+@pytest.fixture(scope="module")
+def testbed(device):
+    tb = Testbed(device=device)
+    tb.load_snapshot(make_synthetic_nerf(11))
+    tb.background_color = [255, 255, 255, 0.0]
+    tb.snap_to_pixel_centers = True
+    tb.nerf.rendering_min_transmittance = 1e-7
+    tb.render_aabb.min, tb.render_aabb.max = PREMIER_PROTEIN_AABB
+    lo, hi = np.array(PREMIER_PROTEIN_AABB)
+    c = 0.5 * (lo + hi)
+    eye = c + np.array([0.9, 0.5, 0.3]) / np.linalg.norm([0.9, 0.5, 0.3]) * 1.69
+    R, _ = look_at_pose(eye, c, up=np.array([0, 1.0, 0]))
+    tb._cam_ngp = np.concatenate([R.T, eye[:, None]], 1)
+    tb.fov = math.degrees(2 * math.atan(640 / (2 * 1.2 * 640)))
+    return tb
+
+
+def test_full_size_render_properties(testbed):
+    """640x480, spp 8 (BASELINE configs[1]) without an oracle run: bit-repeatable (the live-ray
+    compaction order is not fixed, the image is), premultiplied colour bounded by alpha, alpha in
+    [0, 1], background exactly zero, Depth's alpha channel equals Shade's."""
+    tb = testbed
+    tb.render_mode = RenderMode.Shade
+    a = tb.render_device(640, 480, 8, True)
+    b = tb.render_device(640, 480, 8, True)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all()
+    alpha = a[..., 3]
+    assert float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0 + 1e-6
+    assert bool((a[..., :3] <= alpha[..., None] + 1e-6).all()) and float(a[..., :3].min()) >= 0.0
+    assert bool((a[alpha == 0] == 0).all())
+    assert 0.05 < float((alpha > 0.5).float().mean()) < 0.5
+    tb.render_mode = RenderMode.Depth
+    d = tb.render_device(640, 480, 8, True)
+    tb.render_mode = RenderMode.Shade
+    assert torch.equal(d[..., 3], alpha)
+    rgba, depth = tb.render_both_device(640, 480, 8)
+    assert torch.equal(rgba, a) and torch.equal(depth, d)
+
+
+def test_render_of_a_camera_that_sees_nothing(testbed):
+    tb = testbed
+    keep = tb._cam_ngp.copy()
+    tb._cam_ngp = keep.copy()
+    tb._cam_ngp[:, 3] = keep[:, 3] + keep[:, 2] * -5.0  # far away ...
+    tb._cam_ngp[:, 2] = -keep[:, 2]                      # ... and looking the other way
+    tb._cam_ngp[:, 0] = -keep[:, 0]
+    out = tb.render_device(96, 64, 4, True)
+    tb._cam_ngp = keep
+    assert bool((out == 0).all())
+
+
+def test_single_pixel_and_ragged_renders(testbed):
+    """1x1, 3x5 (smaller than one 4x2 enumeration block) and spp 1 / 5 renders complete."""
+    for (w, h, spp) in ((1, 1, 1), (3, 5, 5), (7, 2, 8)):
+        out = testbed.render_device(w, h, spp, True)
+        assert out.shape == (h, w, 4) and torch.isfinite(out).all()
