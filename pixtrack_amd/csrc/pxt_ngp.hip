@@ -915,10 +915,10 @@ extern "C" int pxt_ngp_create(const pxt_ngp_model* model, const void* grid_param
 
 extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (!ctx) return PXT_E_ARG;
-  if (ctx->grid) hipFree(ctx->grid);
-  if (ctx->wfrag) hipFree(ctx->wfrag);
-  if (ctx->occ) hipFree(ctx->occ);
-  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->grid) (void)hipFree(ctx->grid);
+  if (ctx->wfrag) (void)hipFree(ctx->wfrag);
+  if (ctx->occ) (void)hipFree(ctx->occ);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
   delete ctx;
   return PXT_OK;
 }

@@ -546,10 +546,10 @@ void set_conv_lds_attr() {
   if (done) return;
   const int lds2 = (int)((kInHalves + 9 * 64 * kPix) * sizeof(half_t));
   const int lds1 = (int)((kInHalves + 9 * 32 * kPix) * sizeof(half_t));
-  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-  hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
   done = true;
 }
 
@@ -612,7 +612,7 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
   hipError_t e = hipMalloc(&ctx->dev_blob, (size_t)n_bytes);
   if (e != hipSuccess) { set_last_error("hipMalloc(unet weights)", e); delete ctx; return PXT_E_HIP; }
   e = hipMemcpy(ctx->dev_blob, weights_host, (size_t)n_bytes, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { set_last_error("hipMemcpy(unet weights)", e); hipFree(ctx->dev_blob); delete ctx; return PXT_E_HIP; }
+  if (e != hipSuccess) { set_last_error("hipMemcpy(unet weights)", e); (void)hipFree(ctx->dev_blob); delete ctx; return PXT_E_HIP; }
   const char* d = (const char*)ctx->dev_blob;
   for (int i = 0; i < n_conv + n_heads; ++i) {
     UnetLayer& L = (i < n_conv) ? ctx->conv[i] : ctx->head[i - n_conv];
@@ -625,14 +625,14 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
     if (i == 0) { want_w = (int64_t)L.cout * 27 * 4; want_b = L.cout * 4; }
     else if (i < n_conv) { want_w = (int64_t)L.cout * 9 * L.cin * 2; want_b = L.cout * 4; }
     else { want_w = (int64_t)L.cin * (L.cout + 1) * 4; want_b = (L.cout + 1) * 4; }
-    if (wbytes != want_w || bbytes != want_b) { hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
+    if (wbytes != want_w || bbytes != want_b) { (void)hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
   }
   // architecture checks (VGG16-UNet wiring the forward pass assumes)
   bool ok = ctx->conv[0].cin == 3 && (ctx->conv[0].cout % 16) == 0;
   for (int i = 1; i < n_conv; ++i) ok = ok && (ctx->conv[i].cin % kCK) == 0 && (ctx->conv[i].cout % 32) == 0;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 8) == 0 && ctx->head[i].cout + 1 <= 192;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 16) == 0 && ctx->head[i].cout + 1 <= 160;
-  if (!ok) { hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
+  if (!ok) { (void)hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
   // heads: fp16 [32*NT][Cin] row-major weights (rows >= cout+1 zero) + fp32 padded bias
   {
     std::vector<char> hb;
