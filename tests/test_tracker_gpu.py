@@ -175,3 +175,20 @@ def test_cli_on_disk_assets(tracked, tmp_path, monkeypatch, capsys):
             assert geodesic_distance_for_rotations(R, R0) < 1e-3 and np.linalg.norm(t - t0) < 1e-3
     trackers = load_reference_pickle(out / "trackers.pkl")
     assert len(trackers) == len(frames)
+
+
+def test_frames_larger_than_the_extractor_limit(device):
+    """BASELINE configs[4]-style input: frames above 1024 px are resized by the extractor
+    (feature_extractor.py:42-45: linear, mask multiplied in first), the cameras of the mask and
+    reference renders stay at full size, the LM runs on the resized pyramid with rescaled cameras."""
+    assets = make_tracking_assets(seed=1005, width=1280, height=960, n_frames=3, n_points=5000)
+    tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+    tr.spp = 2
+    frames = render_query_frames(assets, tr.testbed)
+    for i, f in enumerate(frames):
+        tr.run_single_frame((f"{i:06d}.png", f))
+        assert tr.success
+        (R, t), (Rg, tg) = tr.pose.numpy(), assets["gt_poses"][i]
+        assert geodesic_distance_for_rotations(R, Rg) < 2e-2 and np.linalg.norm(t - tg) < 2e-2
+    maps = tr.localizer.refiner.last_lm[0]
+    assert maps.iters[0] >= 1 and not maps.failed
