@@ -447,8 +447,6 @@ __global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const 
     float t0 = -1.f;
     if (enum_ray(P, i, px, py, s)) {
       const int pix = py * P.W + px;
-      Wk.sppbuf[(size_t)pix * P.spp + s] = make_float4(0.f, 0.f, 0.f, 0.f);
-      Wk.sppbuf_d[(size_t)pix * P.spp + s] = 0.f;
       const Ray r = make_ray(P, px, py);
       if (r.hit) {
         float t = fmaxf(r.tmin, 0.f) + 1e-6f;
@@ -754,15 +752,31 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
 }
 
 __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk) {
+  // Eight lanes per pixel: lane j fetches spp pass j, j + 8, ... (coalesced 16-B reads), lane 0 of
+  // the group then adds them in pass order - the fixed order of a sequential mean.  All passes of
+  // a pixel share one ray (snap_to_pixel_centers), so a pixel whose ray misses the box has no
+  // finished rays to read: init never zero-fills the buffers.
   const int wh = P.W * P.H;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= wh) return;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int pix = gid >> 3, j = gid & 7;
+  const bool in_img = pix < wh;
+  const int pc = in_img ? pix : 0;
+  const bool hit = in_img && make_ray(P, pc % P.W, pc / P.W).hit;
   float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f, ad = 0.f;
-  for (int s = 0; s < P.spp; ++s) {
-    const float4 v = Wk.sppbuf[(size_t)pix * P.spp + s];
-    ar += v.x; ag += v.y; ab += v.z; aa += v.w;
-    if (P.out_depth) ad += Wk.sppbuf_d[(size_t)pix * P.spp + s];
+  for (int s0 = 0; s0 < P.spp; s0 += 8) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float vd = 0.f;
+    if (hit && s0 + j < P.spp) {
+      v = Wk.sppbuf[(size_t)pc * P.spp + s0 + j];
+      if (P.out_depth) vd = Wk.sppbuf_d[(size_t)pc * P.spp + s0 + j];
+    }
+    const int cnt = min(8, P.spp - s0);
+    for (int k = 0; k < cnt; ++k) {  // sequential: ((v0 + v1) + v2) + ...
+      ar += __shfl(v.x, k, 8); ag += __shfl(v.y, k, 8); ab += __shfl(v.z, k, 8); aa += __shfl(v.w, k, 8);
+      if (P.out_depth) ad += __shfl(vd, k, 8);
+    }
   }
+  if (!in_img || j != 0) return;
   const float inv = 1.0f / (float)P.spp;
   if (P.out_depth) {  // what a separate Depth-mode render would have written
     float4 od;
@@ -1051,7 +1065,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
   else
     hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
-  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s, P, Wk);
+  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height * 8 + 255) / 256), dim3(256), 0, s, P, Wk);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }
