@@ -284,7 +284,8 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // rays, and the encoder runs LEVEL-MAJOR: blocks are dispatched in level order, so at any
 // moment the whole chip gathers from one ~2 MB level, which every XCD's L2 holds.
 //
-//   init     : ray per (pixel, spp); rays that hit the render box enter the live list
+//   init     : (inside the first compaction) ray per (pixel, spp); rays that hit the render box
+//              enter the live list
 //   round r  : march   -- each live ray collects its next K occupied lattice samples
 //              encode  -- level-major gathers -> feat[level][sample] (fp16 x2)
 //              shade   -- 8 rays x K=8 samples per wave: MLPs on MFMA, in-order compositing,
@@ -405,7 +406,6 @@ struct NgpWork {
   unsigned* feat;      // [level][sample] packed fp16 pair
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
   uint8_t* keep;       // per slot: the ray continues into the next round (written by shade)
-  float* cand_t;       // per enumerated ray: start t, or < 0 for rays that miss the box
   float4* raydir;      // [pixel * spp + s] = (unit direction, d . camera z): what shading needs of a ray
   float4* sppbuf;      // [pixel][spp] finished rays
   float* sppbuf_d;     // mode 2: finished rays' depth
@@ -440,32 +440,20 @@ __device__ inline long long enum_total(const NgpParams& P) {
   return (long long)((P.W + 3) / 4) * ((P.H + 1) / 2) * 8 * P.spp;
 }
 
-__global__ __launch_bounds__(256) void ngp_init_kernel(const NgpParams P, const NgpWork Wk) {
-  const long long total = enum_total(P);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    int px, py, s;
-    float t0 = -1.f;
-    if (enum_ray(P, i, px, py, s)) {
-      const int pix = py * P.W + px;
-      const Ray r = make_ray(P, px, py);
-      if (r.hit) {
-        float t = fmaxf(r.tmin, 0.f) + 1e-6f;
-        unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
-        h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-        const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
-        t0 = t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-        // the shade kernel runs 8 lanes per ray per round: it reads these instead of redoing
-        // make_ray's fourteen divisions in every lane
-        Wk.raydir[(size_t)pix * P.spp + s] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
-      }
-    }
-    Wk.cand_t[i] = t0;
-  }
+// Start of a ray (pixel, spp pass): the box entry plus the per-(pixel, pass) jitter, or < 0 when
+// the pixel's ray misses the render box.
+__device__ inline float ray_start(const NgpParams& P, const Ray& r, int pix, int s) {
+  if (!r.hit) return -1.f;
+  const float t = fmaxf(r.tmin, 0.f) + 1e-6f;
+  unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
 }
 
 // Order-preserving compaction of 2048-item tiles: ONE global atomic per tile (a single
 // counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue").
-// FROM_INIT: items are enumerated rays (keep = cand_t >= 0), else slots of the previous round.
+// FROM_INIT: items are the enumerated rays, generated in place; else slots of the previous round.
 constexpr int kTile = 2048;
 template <bool FROM_INIT>
 __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, const NgpWork Wk, int round) {
@@ -481,10 +469,37 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
     const long long i0 = tile * kTile + (long long)threadIdx.x * 8;
     bool k[8];
     int cnt = 0;
+    // FROM_INIT: the rays are generated here (no separate init pass, no candidate buffer).  A
+    // thread's 8 consecutive rays are the passes of one pixel when spp = 8: one make_ray for all.
+    float t_start[8];
+    unsigned rid_new[8];
+    int last_pix = -1;
+    Ray r;
+    r.hit = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long long i = i0 + j;
-      k[j] = i < n && (FROM_INIT ? (Wk.cand_t[i] >= 0.f) : (Wk.keep[i] != 0));
+      if (FROM_INIT) {
+        int px, py, sp;
+        k[j] = false;
+        t_start[j] = -1.f;
+        rid_new[j] = 0u;
+        if (i < n && enum_ray(P, i, px, py, sp)) {
+          const int pix = py * P.W + px;
+          if (pix != last_pix) {
+            r = make_ray(P, px, py);
+            last_pix = pix;
+          }
+          t_start[j] = ray_start(P, r, pix, sp);
+          rid_new[j] = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
+          k[j] = t_start[j] >= 0.f;
+          // the shade kernel runs 8 lanes per ray per round: it reads the direction instead of
+          // redoing make_ray's fourteen divisions in every lane
+          if (k[j]) Wk.raydir[rid_new[j]] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
+        }
+      } else {
+        k[j] = i < n && Wk.keep[i] != 0;
+      }
       cnt += k[j] ? 1 : 0;
     }
     int inc = cnt;  // inclusive scan within the wave
@@ -509,10 +524,8 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
       if (!k[j]) continue;
       const long long i = i0 + j;
       if (FROM_INIT) {
-        int px, py, s;
-        enum_ray(P, i, px, py, s);
-        D.rid[dst] = (unsigned)(py * P.W + px) * (unsigned)P.spp + (unsigned)s;
-        D.t[dst] = Wk.cand_t[i];
+        D.rid[dst] = rid_new[j];
+        D.t[dst] = t_start[j];
         D.T[dst] = 1.f;
         D.acc[dst] = make_float4(0.f, 0.f, 0.f, 0.f);
         D.accd[dst] = 0.f;
@@ -755,7 +768,7 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
   // Eight lanes per pixel: lane j fetches spp pass j, j + 8, ... (coalesced 16-B reads), lane 0 of
   // the group then adds them in pass order - the fixed order of a sequential mean.  All passes of
   // a pixel share one ray (snap_to_pixel_centers), so a pixel whose ray misses the box has no
-  // finished rays to read: init never zero-fills the buffers.
+  // finished rays to read: nothing zero-fills the buffers.
   const int wh = P.W * P.H;
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int pix = gid >> 3, j = gid & 7;
@@ -985,7 +998,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   const size_t o_cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
   const size_t o_spos = take(samples * 16), o_stt = take(samples * 4);
   const size_t o_feat = take(samples * 4 * kMaxLevels), o_exh = take(rays), o_spp = take(rays * 16);
-  const size_t o_keep = take(rays), o_cand = take((rays + 64 * 8) * 4 + 4096);
+  const size_t o_keep = take(rays);
   const size_t o_rdir = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
   if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
@@ -1004,7 +1017,6 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   W.sppbuf = (float4*)(b + o_spp);
   W.sppbuf_d = (float*)(b + o_sppd);
   W.keep = (uint8_t*)(b + o_keep);
-  W.cand_t = (float*)(b + o_cand);
   W.raydir = (float4*)(b + o_rdir);
   W.feat_stride = samples;
   ctx->scratch_rays = rays;
@@ -1027,7 +1039,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   P.out = out_rgba;
   P.out_depth = (mode == 2) ? out_depth : nullptr;
   P.stats = (unsigned long long*)stats;
-  // padded to whole 4x2 pixel blocks (the enumeration order of ngp_init_kernel)
+  // padded to whole 4x2 pixel blocks (the enumeration order of enum_ray)
   const size_t rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
   if (rays > 0x7fffffffull / kK) return PXT_E_ARG;
   int rc = ensure_scratch(ctx, rays);
@@ -1036,7 +1048,6 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   hipStream_t s = (hipStream_t)stream;
   PXT_HIP_CHECK(hipMemsetAsync(Wk.counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), s));
   const int wide = 2048;
-  hipLaunchKernelGGL(ngp_init_kernel, dim3(wide), dim3(256), 0, s, P, Wk);
   hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, 0);
   for (int r = 0; r < kRounds; ++r) {
     hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, s, P, Wk, r);
