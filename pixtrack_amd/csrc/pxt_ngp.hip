@@ -307,6 +307,21 @@ struct Ray {
   bool hit;
 };
 
+// Slab test against the render box clipped to the scene box.
+__device__ inline void ray_clip(const NgpParams& P, Ray& r) {
+  const float half_s = P.aabb_scale * 0.5f;
+  r.tmin = -INFINITY;
+  r.tmax = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = fmaxf(P.lo[a], 0.5f - half_s), hi = fminf(P.hi[a], 0.5f + half_s);
+    const float t0 = (lo - r.o[a]) * r.idir[a], t1 = (hi - r.o[a]) * r.idir[a];
+    r.tmin = fmaxf(r.tmin, fminf(t0, t1));
+    r.tmax = fminf(r.tmax, fmaxf(t0, t1));
+  }
+  r.hit = r.tmax > fmaxf(r.tmin, 0.f);
+}
+
 __device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
   Ray r;
   const float u = ((float)px + 0.5f) / (float)P.W, vv = ((float)py + 0.5f) / (float)P.H;
@@ -335,17 +350,23 @@ __device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
   }
   const float fn = sqrtf((P.cam[2] * P.cam[2] + P.cam[6] * P.cam[6]) + P.cam[10] * P.cam[10]);
   r.zdot = (r.d[0] * (P.cam[2] / fn) + r.d[1] * (P.cam[6] / fn)) + r.d[2] * (P.cam[10] / fn);
-  const float half_s = P.aabb_scale * 0.5f;
-  r.tmin = -INFINITY;
-  r.tmax = INFINITY;
+  ray_clip(P, r);
+  return r;
+}
+
+// The ray of a stored (unit direction, zdot) record: bit for bit what make_ray returned when
+// the record was written (same divisions, same slab arithmetic), without the pixel -> direction
+// part.
+__device__ inline Ray ray_from_record(const NgpParams& P, const float4 rd) {
+  Ray r;
+  r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;
+  r.zdot = rd.w;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float lo = fmaxf(P.lo[a], 0.5f - half_s), hi = fminf(P.hi[a], 0.5f + half_s);
-    const float t0 = (lo - r.o[a]) * r.idir[a], t1 = (hi - r.o[a]) * r.idir[a];
-    r.tmin = fmaxf(r.tmin, fminf(t0, t1));
-    r.tmax = fminf(r.tmax, fmaxf(t0, t1));
+    r.o[a] = P.cam[4 * a + 3];
+    r.idir[a] = 1.0f / r.d[a];
   }
-  r.hit = r.tmax > fmaxf(r.tmin, 0.f);
+  ray_clip(P, r);
   return r;
 }
 
@@ -547,8 +568,7 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
   const RayState& S = Wk.st[round & 1];
   const int wh = P.W * P.H;
   for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
-    const int pix = (int)(S.rid[slot] / (unsigned)P.spp);
-    const Ray r = make_ray(P, pix % P.W, pix / P.W);
+    const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
     float t = S.t[slot];
     bool out = false;
     for (int k = 0; k < kK; ++k) {
@@ -715,8 +735,7 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
     bool alive = slot < n;
     const int sl = alive ? slot : 0;
     const unsigned rid = S.rid[sl];
-    const int pix = (int)(rid / (unsigned)P.spp);
-    const Ray r = make_ray(P, pix % P.W, pix / P.W);
+    const Ray r = ray_from_record(P, Wk.raydir[rid]);
     unsigned shB0[4], shB1[4];
     sh_fragments(r.d, shB0, shB1);
     float t = S.t[sl], T = S.T[sl];
