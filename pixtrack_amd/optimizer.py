@@ -15,6 +15,7 @@ the per-iteration log into ``logging_fn`` afterwards.  There is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import re
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -331,13 +332,14 @@ class PixTrackOptimizer:
             T_prev = T
 
 
-_PINNED: dict = {}
+_PINNED = threading.local()  # per thread: one tracker per thread is the supported concurrency
 
 
 def _pinned_record(n_floats: int) -> torch.Tensor:
     """Reusable pinned host buffers, two per size (a result may still be read while the next
     refinement is enqueued)."""
-    slot = _PINNED.setdefault(n_floats, [[], 0])
+    pool = _PINNED.__dict__.setdefault("pool", {})
+    slot = pool.setdefault(n_floats, [[], 0])
     if len(slot[0]) < 2:
         slot[0].append(torch.zeros(n_floats, dtype=torch.float32).pin_memory())
     slot[1] = (slot[1] + 1) % 2
@@ -347,6 +349,8 @@ def _pinned_record(n_floats: int) -> torch.Tensor:
 class PendingLM:
     """Result handle of an enqueued refinement; .result() waits for the kernel's event and reads
     the record the kernel wrote into pinned host memory."""
+
+    poll = True  # poll the completion word (single tracker per process); False: wait on the event
 
     def __init__(self, buf, has_log, n_levels, num_iters, keepalive, done):
         self.buf, self.has_log = buf, has_log
@@ -361,6 +365,8 @@ class PendingLM:
         # fallback for a kernel that never gets there (it then reports through `status`).
         flag = self.buf.numpy()
         spins = 0
+        if not PendingLM.poll:  # several trackers on threads: a Python spin would hold the GIL
+            self._done.synchronize()
         while flag[15] == 0.0:
             spins += 1
             if spins > 2_000_000 or (spins & 0x3FFF) == 0 and self._done.query():
