@@ -134,7 +134,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n_frames = args.warmup + args.steps
+    n_diag = min(20, args.steps)  # untimed diagnostic pass (per-stage HIP-event times)
+    n_timed_end = args.warmup + args.steps
+    n_frames = n_timed_end + n_diag
     unit = parallel.shard_units(ws, rank, ws)[0]  # one sequence per rank, seeds 1002, 1003, ...
     assets = make_tracking_assets(seed=1002 + unit, width=args.width, height=args.height, n_frames=n_frames)
     tracker = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets)
@@ -156,25 +158,34 @@ def main():
     start_pose = tracker.pose.numpy()
     tracker.testbed.stats_accum.zero_()
     n_renders0 = tracker.testbed.n_renders
-    timer.enabled = True
-    tracker.testbed.timing_enable(True)  # HIP events around every ngp_encode_kernel launch
+    # HIP events around the ngp_encode_kernel launches of every 4th render: live over the timed
+    # region, sampled so that the marker packets do not slow what they measure
+    tracker.testbed.timing_enable(4)
 
     if ws > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_frames):
+    for i in range(args.warmup, n_timed_end):
         tracker.run_single_frame((names[i], frames[i]))
     torch.cuda.synchronize()
     if ws > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    tracker.testbed.timing_enable(False)
+    tracker.testbed.timing_enable(0)
     enc_ms, enc_launches = tracker.testbed.timing_read()
     elapsed = parallel.max_over_ranks(elapsed, dev)
+    stats = tracker.testbed.stats_accum.cpu().tolist()
+    n_renders = tracker.testbed.n_renders - n_renders0
+    # per-stage times: a separate, untimed pass over the next frames of the same sequence (event
+    # pairs around every stage cost ~10 % of a frame, so they stay out of the timed region)
+    timer.enabled = True
+    for i in range(n_timed_end, n_frames):
+        tracker.run_single_frame((names[i], frames[i]))
+    torch.cuda.synchronize()
+    timer.enabled = False
 
-    records = parallel.pack_pose_records(tracker.pose_history, names[args.warmup:])
+    records = parallel.pack_pose_records(tracker.pose_history, names[args.warmup:n_timed_end])
     gathered = parallel.gather_pose_records(records.to(dev), dev)  # the one collective (RCCL)
     n_ok = int(sum(float(g[:, 12].sum()) for g in gathered))
     total_frames = sum(g.shape[0] for g in gathered)
@@ -182,18 +193,16 @@ def main():
     if rank != 0:
         return
     stage = timer.totals_ms()
-    stats = tracker.testbed.stats_accum.cpu().tolist()
-    n_renders = tracker.testbed.n_renders - n_renders0
-    nerf_ms, nerf_calls = stage.get("nerf_render", (0.0, 1))
     # dominant kernel: ngp_encode_kernel (level-major hash-grid gathers), kRounds launches per render.
     # ALGORITHMIC bytes per launch = composited samples per launch x 512 B; samples the
     # rounds evaluate past a ray's termination are waste and are not credited.
-    enc_avg_ms = enc_ms / max(enc_launches, 1)
-    samples_per_launch = stats[0] / max(enc_launches, 1)
+    enc_avg_ms = enc_ms / max(enc_launches, 1)          # over the timed (sampled) launches
+    launches_total = n_renders * 5  # kRounds = 5 encode launches per render
+    samples_per_launch = stats[0] / max(launches_total, 1)
     achieved = samples_per_launch * NERF_BYTES_PER_SAMPLE / (enc_avg_ms * 1e-3) / 1e9 if enc_avg_ms > 0 else 0.0
     # accuracy vs the synthetic ground truth over the timed frames (reported, not the metric)
     rot_err, tr_err = [], []
-    for i in range(args.warmup, n_frames):
+    for i in range(args.warmup, n_timed_end):
         ret = tracker.pose_history[names[i]]
         if ret.get("success"):
             Rr, tt = ret["T_refined"].numpy()
@@ -214,7 +223,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_unit": "MB per launch", "traffic_source": traffic_src,
                 "algorithmic_mb_per_launch": round(samples_per_launch * NERF_BYTES_PER_SAMPLE / 1e6, 2),
-                "avg_launch_ms": round(enc_avg_ms, 5), "launches": enc_launches,
+                "avg_launch_ms": round(enc_avg_ms, 5), "launches_timed": enc_launches, "launches": launches_total,
                 "samples_per_launch": round(samples_per_launch, 1), "bytes_per_sample": NERF_BYTES_PER_SAMPLE,
                 "samples_per_render": round(stats[0] / max(n_renders, 1), 1)}
     out = {
@@ -239,7 +248,8 @@ def main():
         "frames_total": total_frames,
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot_err)), 6) if rot_err else None,
         "mean_trans_err_vs_gt": round(float(np.mean(tr_err)), 6) if tr_err else None,
-        "stage_ms_per_frame": {k: round(v[0] / args.steps, 4) for k, v in stage.items()},
+        "stage_ms_per_frame": {k: round(v[0] / max(n_diag, 1), 4) for k, v in stage.items()},
+        "stage_ms_note": f"HIP-event times of a separate untimed pass over the next {n_diag} frames",
         "roofline": roofline,
     }
     if not args.no_cpu_baseline and ws == 1:

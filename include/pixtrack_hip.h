@@ -225,10 +225,12 @@ int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_
                         uint64_t* stats, void* stream);
 
 /* Live HIP-event timing of the renderer's dominant kernel (ngp_encode_kernel), for the
- * roofline line of bench.py.  While enabled, every encode launch is bracketed by an event
- * pair recorded on the render's own stream.  pxt_ngp_timing_read synchronises those events,
- * returns their summed duration (ms) and the launch count, and clears the list. */
-int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable);
+ * roofline line of bench.py.  every_nth > 0: the encode launches of every every_nth-th render
+ * are bracketed by an event pair recorded on the render's own stream (an event record is a
+ * marker packet between kernels, so sampling keeps the measurement from slowing what it
+ * measures); 0 disables.  pxt_ngp_timing_read synchronises those events, returns their summed
+ * duration (ms) and the number of timed launches, and clears the list. */
+int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t every_nth);
 int pxt_ngp_timing_read(pxt_ngp* ctx, float* total_ms_host, int32_t* n_launches_host);
 
 /* Network query at caller-given points, ngp coordinates + unit view directions (device

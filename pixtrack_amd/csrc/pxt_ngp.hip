@@ -711,9 +711,13 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
       }
     }
   }
-  if (P.stats) {
+  if (P.stats) {  // one atomic per workgroup: a single counter word sustains ~90 atomics/us
+    __shared__ unsigned long long s_cnt[4];
     for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
-    if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
+    if (lane == 0) s_cnt[wave] = n_samples;
+    __syncthreads();
+    const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x == 0 && tot) atomicAdd(P.stats + 0, tot);
   }
 }
 
@@ -874,8 +878,10 @@ struct pxt_ngp {
   void* scratch = nullptr;
   size_t scratch_rays = 0;
   pxt::NgpWork work;
-  bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  int timing = 0;        // > 0: HIP events around the encode launches of every timing-th render
+  long long renders = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;    // created once, reused
 };
 
 using namespace pxt;
@@ -1068,16 +1074,23 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   PXT_HIP_CHECK(hipMemsetAsync(Wk.counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), s));
   const int wide = 2048;
   hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, 0);
+  const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
   for (int r = 0; r < kRounds; ++r) {
     hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, s, P, Wk, r);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-      PXT_HIP_CHECK(hipEventCreate(&e0));
-      PXT_HIP_CHECK(hipEventCreate(&e1));
+    if (timed) {
+      if (ctx->pool.empty()) {
+        PXT_HIP_CHECK(hipEventCreate(&e0));
+        PXT_HIP_CHECK(hipEventCreate(&e1));
+      } else {
+        e0 = ctx->pool.back().first;
+        e1 = ctx->pool.back().second;
+        ctx->pool.pop_back();
+      }
       PXT_HIP_CHECK(hipEventRecord(e0, s));
     }
     hipLaunchKernelGGL(ngp_encode_kernel, dim3(4096), dim3(256), 0, s, P, Wk, r);
-    if (ctx->timing) {
+    if (timed) {
       PXT_HIP_CHECK(hipEventRecord(e1, s));
       ctx->events.emplace_back(e0, e1);
     }
@@ -1114,7 +1127,8 @@ extern "C" int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* v, float* o
 
 extern "C" int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable) {
   if (!ctx) return PXT_E_ARG;
-  ctx->timing = enable != 0;
+  ctx->timing = enable > 0 ? enable : 0;
+  ctx->renders = 0;
   return PXT_OK;
 }
 
@@ -1126,8 +1140,7 @@ extern "C" int pxt_ngp_timing_read(pxt_ngp* ctx, float* total_ms, int32_t* n_lau
     float ms = 0.f;
     PXT_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
     tot += ms;
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+    ctx->pool.push_back(ev);
   }
   *total_ms = tot;
   *n_launches = (int32_t)ctx->events.size();

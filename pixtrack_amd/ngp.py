@@ -387,8 +387,9 @@ class Testbed:
     def render(self, width: int, height: int, spp: int = 8, linear: bool = True) -> np.ndarray:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 
-    def timing_enable(self, enable: bool = True):
-        _lib.check(_lib.lib().pxt_ngp_timing_enable(self._ctx, int(enable)), "pxt_ngp_timing_enable")
+    def timing_enable(self, every_nth: int = 1):
+        """HIP events around the encode launches of every ``every_nth``-th render (0 / False: off)."""
+        _lib.check(_lib.lib().pxt_ngp_timing_enable(self._ctx, int(every_nth)), "pxt_ngp_timing_enable")
 
     def timing_read(self):
         """(total ms, launches) of ngp_encode_kernel since the last read (HIP events on the render stream)."""
