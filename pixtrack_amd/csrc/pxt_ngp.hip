@@ -65,6 +65,7 @@ struct NgpParams {
   float* out;
   float* out_depth;  // mode 2 only
   unsigned long long* stats;
+  long long enum_lo, enum_hi;  // the part of the ray enumeration this pipeline (slice) generates
 };
 
 __device__ inline float calc_dt(float t, float cone, float lo, float hi) {
@@ -480,7 +481,7 @@ template <bool FROM_INIT>
 __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
-  const long long n = FROM_INIT ? enum_total(P) : (long long)Wk.counters[round * kCtrStride];
+  const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
   const RayState& D = FROM_INIT ? Wk.st[0] : Wk.st[(round + 1) & 1];
   int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
         k[j] = false;
         t_start[j] = -1.f;
         rid_new[j] = 0u;
-        if (i < n && enum_ray(P, i, px, py, sp)) {
+        if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
           const int pix = py * P.W + px;
           if (pix != last_pix) {
             r = make_ray(P, px, py);
@@ -877,7 +878,9 @@ struct pxt_ngp {
   // scratch of the wavefront renderer, grown on demand (rays = W*H*spp)
   void* scratch = nullptr;
   size_t scratch_rays = 0;
-  pxt::NgpWork work;
+  pxt::NgpWork work[2];          // two independent pipelines over the two halves of the rays
+  hipStream_t side = nullptr;    // the second pipeline's stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int timing = 0;        // > 0: HIP events around the encode launches of every timing-th render
   long long renders = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
@@ -971,6 +974,9 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (ctx->wfrag) (void)hipFree(ctx->wfrag);
   if (ctx->occ) (void)hipFree(ctx->occ);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
   return PXT_OK;
 }
@@ -1002,6 +1008,9 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
 }
 
 // Carves the wavefront scratch for `rays` rays out of one allocation (grown on demand).
+// Scratch for a render of `rays` enumerated rays.  Per-pipeline buffers (live-ray state, samples,
+// features) are sized for half the rays each; the per-ray result buffers indexed by ray id
+// (finished passes, direction records) are shared.
 static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   if (ctx->scratch && ctx->scratch_rays >= rays) return PXT_OK;
   if (ctx->scratch) {
@@ -1011,39 +1020,44 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
     ctx->scratch = nullptr;
   }
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  const size_t samples = rays * kK;
+  const size_t half = (rays + 1) / 2 + kTile;  // a slice boundary is rounded to whole tiles
+  const size_t samples = half * kK;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
-  size_t o_rid[2], o_t[2], o_T[2], o_acc[2], o_accd[2];
-  for (int i = 0; i < 2; ++i) {
-    o_rid[i] = take(rays * 4); o_t[i] = take(rays * 4); o_T[i] = take(rays * 4); o_acc[i] = take(rays * 16);
-    o_accd[i] = take(rays * 4);
+  struct Offs {
+    size_t rid[2], t[2], T[2], acc[2], accd[2], cnt, spos, stt, feat, exh, keep;
+  } o[2];
+  for (int w = 0; w < 2; ++w) {
+    for (int i = 0; i < 2; ++i) {
+      o[w].rid[i] = take(half * 4); o[w].t[i] = take(half * 4); o[w].T[i] = take(half * 4);
+      o[w].acc[i] = take(half * 16); o[w].accd[i] = take(half * 4);
+    }
+    o[w].cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
+    o[w].spos = take(samples * 16); o[w].stt = take(samples * 4);
+    o[w].feat = take(samples * 4 * kMaxLevels); o[w].exh = take(half); o[w].keep = take(half);
   }
-  const size_t o_sppd = take(rays * 4);
-  const size_t o_cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
-  const size_t o_spos = take(samples * 16), o_stt = take(samples * 4);
-  const size_t o_feat = take(samples * 4 * kMaxLevels), o_exh = take(rays), o_spp = take(rays * 16);
-  const size_t o_keep = take(rays);
-  const size_t o_rdir = take(rays * 16);
+  const size_t o_sppd = take(rays * 4), o_spp = take(rays * 16), o_rdir = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
   if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
   char* b = (char*)ctx->scratch;
-  NgpWork& W = ctx->work;
-  for (int i = 0; i < 2; ++i) {
-    W.st[i].rid = (unsigned*)(b + o_rid[i]); W.st[i].t = (float*)(b + o_t[i]);
-    W.st[i].T = (float*)(b + o_T[i]); W.st[i].acc = (float4*)(b + o_acc[i]);
-    W.st[i].accd = (float*)(b + o_accd[i]);
+  for (int w = 0; w < 2; ++w) {
+    NgpWork& W = ctx->work[w];
+    for (int i = 0; i < 2; ++i) {
+      W.st[i].rid = (unsigned*)(b + o[w].rid[i]); W.st[i].t = (float*)(b + o[w].t[i]);
+      W.st[i].T = (float*)(b + o[w].T[i]); W.st[i].acc = (float4*)(b + o[w].acc[i]);
+      W.st[i].accd = (float*)(b + o[w].accd[i]);
+    }
+    W.counters = (int*)(b + o[w].cnt);
+    W.spos = (float4*)(b + o[w].spos);
+    W.st_t = (float*)(b + o[w].stt);
+    W.feat = (unsigned*)(b + o[w].feat);
+    W.exhausted = (uint8_t*)(b + o[w].exh);
+    W.keep = (uint8_t*)(b + o[w].keep);
+    W.sppbuf = (float4*)(b + o_spp);
+    W.sppbuf_d = (float*)(b + o_sppd);
+    W.raydir = (float4*)(b + o_rdir);
+    W.feat_stride = samples;
   }
-  W.counters = (int*)(b + o_cnt);
-  W.spos = (float4*)(b + o_spos);
-  W.st_t = (float*)(b + o_stt);
-  W.feat = (unsigned*)(b + o_feat);
-  W.exhausted = (uint8_t*)(b + o_exh);
-  W.sppbuf = (float4*)(b + o_spp);
-  W.sppbuf_d = (float*)(b + o_sppd);
-  W.keep = (uint8_t*)(b + o_keep);
-  W.raydir = (float4*)(b + o_rdir);
-  W.feat_stride = samples;
   ctx->scratch_rays = rays;
   return PXT_OK;
 }
@@ -1069,46 +1083,81 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   if (rays > 0x7fffffffull / kK) return PXT_E_ARG;
   int rc = ensure_scratch(ctx, rays);
   if (rc != PXT_OK) return rc;
-  const NgpWork& Wk = ctx->work;
-  hipStream_t s = (hipStream_t)stream;
-  PXT_HIP_CHECK(hipMemsetAsync(Wk.counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), s));
-  const int wide = 2048;
-  hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(1024), dim3(256), 0, s, P, Wk, 0);
+  hipStream_t s0 = (hipStream_t)stream;
+
+  // Two pipelines over the two halves of the ray enumeration, on the caller's stream and on a
+  // side stream.  Every ray is processed exactly as before (its result does not depend on which
+  // rays share its launches), but the chains overlap: the VALU-bound march of one half runs
+  // beside the L1-bound encode or the MFMA-bound shade of the other, and one half's launch
+  // tails are filled by the other's workgroups.  Small renders keep one pipeline.
+  const int n_pipe = rays >= ((size_t)1 << 19) ? 2 : 1;
+  if (n_pipe == 2 && !ctx->side) {
+    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  hipStream_t st[2] = {s0, n_pipe == 2 ? ctx->side : s0};
+  NgpParams Pp[2] = {P, P};
+  const long long total = (long long)rays;
+  const long long cut = n_pipe == 2 ? ((total / 2 + kTile - 1) / kTile) * kTile : total;
+  Pp[0].enum_lo = 0; Pp[0].enum_hi = cut;
+  Pp[1].enum_lo = cut; Pp[1].enum_hi = total;
+  if (n_pipe == 2) {
+    PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));          // the side stream starts after the
+    PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));  // caller's earlier work too
+  }
+  const int wide = 2048 / n_pipe, enc_grid = 4096 / n_pipe, cmp_grid = 1024 / n_pipe;
+  for (int w = 0; w < n_pipe; ++w) {
+    PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
+    hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
+  }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
   for (int r = 0; r < kRounds; ++r) {
-    hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, s, P, Wk, r);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed) {
-      if (ctx->pool.empty()) {
-        PXT_HIP_CHECK(hipEventCreate(&e0));
-        PXT_HIP_CHECK(hipEventCreate(&e1));
-      } else {
-        e0 = ctx->pool.back().first;
-        e1 = ctx->pool.back().second;
-        ctx->pool.pop_back();
+    for (int w = 0; w < n_pipe; ++w)
+      hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+    for (int w = 0; w < n_pipe; ++w) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timed) {
+        if (ctx->pool.empty()) {
+          PXT_HIP_CHECK(hipEventCreate(&e0));
+          PXT_HIP_CHECK(hipEventCreate(&e1));
+        } else {
+          e0 = ctx->pool.back().first;
+          e1 = ctx->pool.back().second;
+          ctx->pool.pop_back();
+        }
+        PXT_HIP_CHECK(hipEventRecord(e0, st[w]));
       }
-      PXT_HIP_CHECK(hipEventRecord(e0, s));
+      hipLaunchKernelGGL(ngp_encode_kernel, dim3(enc_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      if (timed) {
+        PXT_HIP_CHECK(hipEventRecord(e1, st[w]));
+        ctx->events.emplace_back(e0, e1);
+      }
     }
-    hipLaunchKernelGGL(ngp_encode_kernel, dim3(4096), dim3(256), 0, s, P, Wk, r);
-    if (timed) {
-      PXT_HIP_CHECK(hipEventRecord(e1, s));
-      ctx->events.emplace_back(e0, e1);
+    for (int w = 0; w < n_pipe; ++w) {
+      if (mode == 1)
+        hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      else if (mode == 2)
+        hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      else
+        hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
     }
-    if (mode == 1)
-      hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(wide), dim3(256), 0, s, P, Wk, r);
-    else if (mode == 2)
-      hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(wide), dim3(256), 0, s, P, Wk, r);
-    else
-      hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(wide), dim3(256), 0, s, P, Wk, r);
-    hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(1024), dim3(256), 0, s, P, Wk, r);
+    for (int w = 0; w < n_pipe; ++w)
+      hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
   }
-  if (mode == 1)
-    hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
-  else if (mode == 2)
-    hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
-  else
-    hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(1024), dim3(256), 0, s, P, Wk, kRounds);
-  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height * 8 + 255) / 256), dim3(256), 0, s, P, Wk);
+  for (int w = 0; w < n_pipe; ++w) {
+    if (mode == 1)
+      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
+    else if (mode == 2)
+      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
+    else
+      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
+  }
+  if (n_pipe == 2) {
+    PXT_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side));
+    PXT_HIP_CHECK(hipStreamWaitEvent(s0, ctx->ev_join, 0));
+  }
+  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height * 8 + 255) / 256), dim3(256), 0, s0, P, ctx->work[0]);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }
