@@ -133,6 +133,7 @@ def main():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    numa_node = parallel.bind_to_device_numa(local_rank)  # before any pinned allocation
 
     n_diag = min(20, args.steps)  # untimed diagnostic pass (per-stage HIP-event times)
     n_timed_end = args.warmup + args.steps
@@ -243,7 +244,8 @@ def main():
                                "1 sequence per GPU", "width": args.width, "height": args.height, "spp": 8,
                    "n_points_per_reference": int(tracker.localizer.refiner._points_of(tracker.reference_ids)[1].shape[0]),
                    "parallelism": f"{ws} independent sequence(s), 1 process/GPU, final RCCL all_gather of poses",
-                   "mask_and_reference_render_fused": bool(tracker._views_coincide())},
+                   "mask_and_reference_render_fused": bool(tracker._views_coincide()),
+                   "host_numa_node": numa_node},
         "tracked_ok": n_ok,
         "frames_total": total_frames,
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot_err)), 6) if rot_err else None,

@@ -75,3 +75,30 @@ def init_from_env(backend: str = "nccl"):
     if ws > 1 and not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
     return int(os.environ.get("RANK", "0")), ws, int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def bind_to_device_numa(device_index: int = 0):
+    """Pins this process to the CPUs of the NUMA node its GPU hangs off (one process per GPU on a
+    two-socket host: the per-frame host turnaround - launches, the pinned-memory completion word -
+    is 30 % slower from the far socket).  Returns the node, or None when the topology is not
+    exposed; never raises."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{int(getattr(p, 'pci_domain_id', 0)):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None

@@ -327,6 +327,10 @@ def main(argv=None):
     eval_path = args.out_dir
     loc_path = args.object_path / "pixtrack/aug_nerf_sfm"
     os.makedirs(eval_path, exist_ok=True)
+    if torch.cuda.is_available():
+        from ..parallel import bind_to_device_numa
+
+        bind_to_device_numa(0)
     tracker = PixLocPoseTrackerR9(object_path=str(args.object_path), data_path=str(data_path),
                                   eval_path=str(eval_path), loc_path=str(loc_path), debug=args.debug)
     tracker.run(args.query, max_frames=args.frames if args.frames is not None else np.inf)
