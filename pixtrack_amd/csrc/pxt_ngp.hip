@@ -878,9 +878,10 @@ struct pxt_ngp {
   // scratch of the wavefront renderer, grown on demand (rays = W*H*spp)
   void* scratch = nullptr;
   size_t scratch_rays = 0;
-  pxt::NgpWork work[2];          // two independent pipelines over the two halves of the rays
-  hipStream_t side = nullptr;    // the second pipeline's stream
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int kMaxPipes = 4;
+  pxt::NgpWork work[kMaxPipes];            // independent pipelines over equal slices of the rays
+  hipStream_t side[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};  // streams of pipelines 1..
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};
   int timing = 0;        // > 0: HIP events around the encode launches of every timing-th render
   long long renders = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
@@ -974,9 +975,11 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (ctx->wfrag) (void)hipFree(ctx->wfrag);
   if (ctx->occ) (void)hipFree(ctx->occ);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
+    if (ctx->side[w]) (void)hipStreamDestroy(ctx->side[w]);
+    if (ctx->ev_join[w]) (void)hipEventDestroy(ctx->ev_join[w]);
+  }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
   return PXT_OK;
 }
@@ -1020,14 +1023,15 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
     ctx->scratch = nullptr;
   }
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  const size_t half = (rays + 1) / 2 + kTile;  // a slice boundary is rounded to whole tiles
+  const int kP = pxt_ngp::kMaxPipes;
+  const size_t half = (rays + 1) / 2 + kTile;  // the largest slice (two pipelines), rounded to whole tiles
   const size_t samples = half * kK;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
   struct Offs {
     size_t rid[2], t[2], T[2], acc[2], accd[2], cnt, spos, stt, feat, exh, keep;
-  } o[2];
-  for (int w = 0; w < 2; ++w) {
+  } o[pxt_ngp::kMaxPipes];
+  for (int w = 0; w < kP; ++w) {
     for (int i = 0; i < 2; ++i) {
       o[w].rid[i] = take(half * 4); o[w].t[i] = take(half * 4); o[w].T[i] = take(half * 4);
       o[w].acc[i] = take(half * 16); o[w].accd[i] = take(half * 4);
@@ -1040,7 +1044,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
   hipError_t e = hipMalloc(&ctx->scratch, off);
   if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
   char* b = (char*)ctx->scratch;
-  for (int w = 0; w < 2; ++w) {
+  for (int w = 0; w < kP; ++w) {
     NgpWork& W = ctx->work[w];
     for (int i = 0; i < 2; ++i) {
       W.st[i].rid = (unsigned*)(b + o[w].rid[i]); W.st[i].t = (float*)(b + o[w].t[i]);
@@ -1090,21 +1094,28 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // rays share its launches), but the chains overlap: the VALU-bound march of one half runs
   // beside the L1-bound encode or the MFMA-bound shade of the other, and one half's launch
   // tails are filled by the other's workgroups.  Small renders keep one pipeline.
-  const int n_pipe = rays >= ((size_t)1 << 19) ? 2 : 1;
-  if (n_pipe == 2 && !ctx->side) {
-    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  static const int env_pipes = [] { const char* e = getenv("PXT_NGP_PIPES"); return e ? atoi(e) : 2; }();
+  const int n_pipe = rays >= ((size_t)1 << 19) ? std::min(std::max(env_pipes, 1), pxt_ngp::kMaxPipes) : 1;
+  if (n_pipe > 1 && !ctx->ev_fork) {
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
+      PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side[w], hipStreamNonBlocking));
+      PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join[w], hipEventDisableTiming));
+    }
   }
-  hipStream_t st[2] = {s0, n_pipe == 2 ? ctx->side : s0};
-  NgpParams Pp[2] = {P, P};
+  hipStream_t st[pxt_ngp::kMaxPipes];
+  NgpParams Pp[pxt_ngp::kMaxPipes];
   const long long total = (long long)rays;
-  const long long cut = n_pipe == 2 ? ((total / 2 + kTile - 1) / kTile) * kTile : total;
-  Pp[0].enum_lo = 0; Pp[0].enum_hi = cut;
-  Pp[1].enum_lo = cut; Pp[1].enum_hi = total;
-  if (n_pipe == 2) {
-    PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));          // the side stream starts after the
-    PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));  // caller's earlier work too
+  const long long per = n_pipe > 1 ? ((total / n_pipe + kTile - 1) / kTile) * kTile : total;
+  for (int w = 0; w < n_pipe; ++w) {
+    st[w] = w == 0 ? s0 : ctx->side[w];
+    Pp[w] = P;
+    Pp[w].enum_lo = std::min(total, per * w);
+    Pp[w].enum_hi = (w == n_pipe - 1) ? total : std::min(total, per * (w + 1));
+  }
+  if (n_pipe > 1) {
+    PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));  // the side streams start after the caller's earlier work
+    for (int w = 1; w < n_pipe; ++w) PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side[w], ctx->ev_fork, 0));
   }
   const int wide = 2048 / n_pipe, enc_grid = 4096 / n_pipe, cmp_grid = 1024 / n_pipe;
   for (int w = 0; w < n_pipe; ++w) {
@@ -1153,9 +1164,9 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     else
       hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
   }
-  if (n_pipe == 2) {
-    PXT_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side));
-    PXT_HIP_CHECK(hipStreamWaitEvent(s0, ctx->ev_join, 0));
+  for (int w = 1; w < n_pipe; ++w) {
+    PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));
+    PXT_HIP_CHECK(hipStreamWaitEvent(s0, ctx->ev_join[w], 0));
   }
   hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height * 8 + 255) / 256), dim3(256), 0, s0, P, ctx->work[0]);
   PXT_HIP_CHECK(hipGetLastError());
