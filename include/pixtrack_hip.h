@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (3), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (4), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -223,6 +223,13 @@ int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
  * (pixloc_tracker_r9.py:224,227); when those two cameras coincide the tracker uses this. */
 int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba, float* out_depth_rgba,
                         uint64_t* stats, void* stream);
+
+/* A render of >= 2^19 rays runs as n pipelines over equal slices of the rays, on the caller's
+ * stream and n-1 internal side streams joined before the final resolve: the image is bit for bit
+ * the same, the kernel chains overlap (the VALU-bound march of one slice beside the L1-bound
+ * encode or MFMA-bound shade of another).  n = 0 restores the default (2, or $PXT_NGP_PIPES);
+ * n = 1 serialises the render on the caller's stream (isolated per-kernel timing); n <= 4. */
+int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n);
 
 /* Live HIP-event timing of the renderer's dominant kernel (ngp_encode_kernel), for the
  * roofline line of bench.py.  every_nth > 0: the encode launches of every every_nth-th render

@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class PxtError(RuntimeError):
@@ -131,6 +131,7 @@ PROTOTYPES = {
     "pxt_ngp_destroy": (C.c_int, [_VP]),
     "pxt_ngp_render": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP]),
     "pxt_ngp_render_both": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP, _VP]),
+    "pxt_ngp_set_pipelines": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_enable": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_read": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),
     "pxt_ngp_query": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),

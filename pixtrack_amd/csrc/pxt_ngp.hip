@@ -882,6 +882,7 @@ struct pxt_ngp {
   pxt::NgpWork work[kMaxPipes];            // independent pipelines over equal slices of the rays
   hipStream_t side[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};  // streams of pipelines 1..
   hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};
+  int pipelines = 0;     // 0: default (PXT_NGP_PIPES or 2); else the number of ray slices rendered side by side
   int timing = 0;        // > 0: HIP events around the encode launches of every timing-th render
   long long renders = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
@@ -1095,7 +1096,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // beside the L1-bound encode or the MFMA-bound shade of the other, and one half's launch
   // tails are filled by the other's workgroups.  Small renders keep one pipeline.
   static const int env_pipes = [] { const char* e = getenv("PXT_NGP_PIPES"); return e ? atoi(e) : 2; }();
-  const int n_pipe = rays >= ((size_t)1 << 19) ? std::min(std::max(env_pipes, 1), pxt_ngp::kMaxPipes) : 1;
+  const int want_pipes = ctx->pipelines > 0 ? ctx->pipelines : env_pipes;
+  const int n_pipe = rays >= ((size_t)1 << 19) ? std::min(std::max(want_pipes, 1), pxt_ngp::kMaxPipes) : 1;
   if (n_pipe > 1 && !ctx->ev_fork) {
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
@@ -1183,6 +1185,12 @@ extern "C" int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* v, float* o
                                    uint64_t* stats, void* stream) {
   if (!out_depth_rgba) return PXT_E_ARG;
   return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream);
+}
+
+extern "C" int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n) {
+  if (!ctx || n < 0 || n > pxt_ngp::kMaxPipes) return PXT_E_ARG;
+  ctx->pipelines = n;
+  return PXT_OK;
 }
 
 extern "C" int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable) {

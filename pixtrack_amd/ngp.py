@@ -387,6 +387,10 @@ class Testbed:
     def render(self, width: int, height: int, spp: int = 8, linear: bool = True) -> np.ndarray:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 
+    def set_pipelines(self, n: int = 0):
+        """Number of ray slices a large render processes side by side (0: default of 2)."""
+        _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, int(n)), "pxt_ngp_set_pipelines")
+
     def timing_enable(self, every_nth: int = 1):
         """HIP events around the encode launches of every ``every_nth``-th render (0 / False: off)."""
         _lib.check(_lib.lib().pxt_ngp_timing_enable(self._ctx, int(every_nth)), "pxt_ngp_timing_enable")
