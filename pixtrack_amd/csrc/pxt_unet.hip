@@ -470,6 +470,8 @@ struct pxt_unet {
   const float* head_b[pxt::kNumHeads];
   void* dev_blob = nullptr;
   int64_t n_bytes = 0;
+  hipStream_t side = nullptr;          // the coarse heads run here, beside the decoder
+  hipEvent_t ev_enc4 = nullptr, ev_dec1 = nullptr, ev_side = nullptr;
   pxt::UnetLayer conv[pxt::kNumConv];
   pxt::UnetLayer head[pxt::kNumHeads];
 };
@@ -670,6 +672,10 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (!ctx) return PXT_E_ARG;
   if (ctx->dev_blob) (void)hipFree(ctx->dev_blob);
   if (ctx->dev_head) (void)hipFree(ctx->dev_head);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->ev_enc4) (void)hipEventDestroy(ctx->ev_enc4);
+  if (ctx->ev_dec1) (void)hipEventDestroy(ctx->ev_dec1);
+  if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
   delete ctx;
   return PXT_OK;
 }
@@ -705,6 +711,36 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   auto buf = [&](size_t off) { return (half_t*)(ws + off); };
   static const int block_first[5] = {0, 2, 4, 7, 10};
   static const int block_n[5] = {2, 2, 3, 3, 3};
+  if (!ctx->side) {
+    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_enc4, hipEventDisableTiming));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_dec1, hipEventDisableTiming));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+  }
+  // 1x1 heads at output scales 0, 2, 4 (per image: separate output tensors and normalisation
+  // flags).  The two coarse ones are small, latency-bound launches whose inputs (enc4, dec1) exist
+  // long before the decoder finishes: they run on a side stream beside the decoder's convolutions.
+  const half_t* pre[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // fine -> coarse: dec3, dec2, dec1, dec0, enc4
+  auto launch_head = [&](int k, hipStream_t hs) {
+    static const int head_src[3] = {0, 2, 4};
+    const UnetLayer& Lh = ctx->head[k];
+    const int i = head_src[k];
+    const int hh = (i == 4) ? P.h[4] : P.dh[3 - i], ww = (i == 4) ? P.w[4] : P.dw[3 - i];
+    const long long npix = (long long)hh * ww;
+    const long long waves = (npix + 31) / 32;
+    // small maps: one wave per workgroup so the few waves spread over as many CUs
+    const int tpb = waves < 1024 ? 64 : 256;
+    const unsigned blocks = (unsigned)((waves * 64 + tpb - 1) / tpb);
+    for (int im = 0; im < B; ++im) {
+      const half_t* src = pre[i] + (size_t)im * npix * Lh.cin;
+      if (Lh.cout + 1 <= 64)
+        hipLaunchKernelGGL(head_mfma_kernel<2>, dim3(blocks), dim3(tpb), 0, hs, src, npix, Lh.cin, ctx->head_w[k],
+                           ctx->head_b[k], Lh.cout, normalize[im], out_maps[3 * im + k], out_cstride[k]);
+      else
+        hipLaunchKernelGGL(head_mfma_kernel<5>, dim3(blocks), dim3(tpb), 0, hs, src, npix, Lh.cin, ctx->head_w[k],
+                           ctx->head_b[k], Lh.cout, normalize[im], out_maps[3 * im + k], out_cstride[k]);
+    }
+  };
 
   const half_t* skip[5];
   const half_t* cur = nullptr;
@@ -747,8 +783,10 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     cur = x;
   }
   // decoder
-  const half_t* pre[5];  // fine -> coarse: dec3, dec2, dec1, dec0, enc4
   pre[4] = skip[4];
+  PXT_HIP_CHECK(hipEventRecord(ctx->ev_enc4, s));
+  PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_enc4, 0));
+  launch_head(2, ctx->side);
   const half_t* prev = skip[4];
   int ph = P.h[4], pw = P.w[4], pc = ctx->conv[12].cout;
   for (int d = 0; d < 4; ++d) {
@@ -763,28 +801,17 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
     pre[3 - d] = o;
-  }
-  // heads at output scales 0, 2, 4 (per image: separate output tensors and normalisation flags)
-  static const int head_src[3] = {0, 2, 4};
-  for (int k = 0; k < 3; ++k) {
-    const UnetLayer& Lh = ctx->head[k];
-    const int i = head_src[k];
-    const int hh = (i == 4) ? P.h[4] : P.dh[3 - i], ww = (i == 4) ? P.w[4] : P.dw[3 - i];
-    const long long npix = (long long)hh * ww;
-    const long long waves = (npix + 31) / 32;
-    // small maps: one wave per workgroup so the few waves spread over as many CUs
-    const int tpb = waves < 1024 ? 64 : 256;
-    const unsigned blocks = (unsigned)((waves * 64 + tpb - 1) / tpb);
-    for (int im = 0; im < B; ++im) {
-      const half_t* src = pre[i] + (size_t)im * npix * Lh.cin;
-      if (Lh.cout + 1 <= 64)
-        hipLaunchKernelGGL(head_mfma_kernel<2>, dim3(blocks), dim3(tpb), 0, s, src, npix, Lh.cin, ctx->head_w[k],
-                           ctx->head_b[k], Lh.cout, normalize[im], out_maps[3 * im + k], out_cstride[k]);
-      else
-        hipLaunchKernelGGL(head_mfma_kernel<5>, dim3(blocks), dim3(tpb), 0, s, src, npix, Lh.cin, ctx->head_w[k],
-                           ctx->head_b[k], Lh.cout, normalize[im], out_maps[3 * im + k], out_cstride[k]);
+    if (d == 1) {  // dec1 feeds the stride-4 head
+      PXT_HIP_CHECK(hipEventRecord(ctx->ev_dec1, s));
+      PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_dec1, 0));
+      launch_head(1, ctx->side);
     }
   }
+  // (the heads were launched above: the two coarse ones on the side stream as soon as their input
+  // existed, the fine one here)
+  launch_head(0, s);
+  PXT_HIP_CHECK(hipEventRecord(ctx->ev_side, ctx->side));
+  PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_side, 0));
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }
