@@ -10,6 +10,12 @@ every rank tracks its OWN independently seeded sequence (frames of one video are
 dependent), no communication in the loop, one RCCL all_gather of the pose
 records at the end -> "weak" scaling.  A step = one tracked frame; query frames are resident
 in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+The timed loop carries only the roofline's instrumentation (HIP events around the dominant
+kernel's launches of every 4th render, one sample-count atomic per workgroup); per-stage times
+and the dominant kernel's isolated timing come from a separate untimed pass over the next 20
+frames.  The per-frame cost varies along the synthetic orbit (more samples per render as the
+object turns), so `value` depends on K: ~410 frames/s at the default K = 60, ~350 at K = 200.
 """
 from __future__ import annotations
 
