@@ -7,7 +7,7 @@ convolution, and the pyramid comes back as the HWC records the LM kernel reads.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch

@@ -6,7 +6,6 @@ from __future__ import annotations
 from collections import defaultdict
 from typing import Dict, List, Optional
 
-import numpy as np
 
 from .utils.colmap import read_model
 

@@ -14,7 +14,7 @@ import ctypes as C
 import math
 from dataclasses import dataclass
 from enum import IntEnum
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -17,7 +17,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 import re
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np

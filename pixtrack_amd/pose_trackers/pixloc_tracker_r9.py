@@ -21,7 +21,6 @@ import ast
 import os
 import pickle as pkl
 from pathlib import Path
-from typing import Optional
 
 import numpy as np
 import torch

@@ -28,7 +28,7 @@ from . import _lib
 from .feature_extractor import PixTrackFeatureExtractor
 from .geometry import Camera, Pose
 from .model3d import Model3D
-from .optimizer import LevelPack, PixTrackOptimizer, cstride_for
+from .optimizer import LevelPack, PixTrackOptimizer
 from .unet import OUTPUT_DIMS, UNet
 from .utils.conf import Conf, merge
 

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import struct
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch

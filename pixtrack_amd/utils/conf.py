@@ -5,7 +5,7 @@ this keeps the same keys, `conf.a.b` access, in-place mutation
 from __future__ import annotations
 
 import copy
-from typing import Any, Dict, Mapping
+from typing import Any, Mapping
 
 
 class Conf(dict):

@@ -5,7 +5,6 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np, torch
 from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
 from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
-from pixtrack_amd.utils.io import ArrayIterator
 from pixtrack_amd.utils.pose_utils import geodesic_distance_for_rotations
 
 def main():

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from pixtrack_amd import _lib
-from pixtrack_amd.geometry import Camera, Pose
+from pixtrack_amd.geometry import Pose
 from pixtrack_amd.ngp import RenderMode, Testbed
 from pixtrack_amd.optimizer import LevelPack, PixTrackOptimizer, cstride_for
 from pixtrack_amd.synthetic import PREMIER_PROTEIN_AABB, look_at_pose, make_lm_scene, make_synthetic_nerf
