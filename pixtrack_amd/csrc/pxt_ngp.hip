@@ -567,7 +567,6 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
 __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
   const int n = Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
-  const int wh = P.W * P.H;
   for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
     const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
     float t = S.t[slot];
@@ -627,7 +626,6 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   const RayState& S = Wk.st[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
-  const int wh = P.W * P.H;
   unsigned long long n_samples = 0;
   const int n_groups = (n + 7) / 8;
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
@@ -731,7 +729,6 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
   const int n = Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wh = P.W * P.H;
   const float half_s = P.aabb_scale * 0.5f;
   const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
   unsigned long long n_samples = 0;

@@ -14,7 +14,8 @@ from .. import _lib
 def get_nerf_image_device(testbed, nerf_pose, camera, depth: bool = False, alpha_thresh: float = 0.0,
                           spp: int = 8):
     """Renders at ``camera``'s size with fov from fx (cx, cy, fy ignored: reference quirk
-    Appendix D.5).  Returns the float32 RGBA frame [H,W,4] left on the device."""
+    Appendix D.5).  Returns the float32 RGBA frame [H,W,4] left on the device; ``alpha_thresh``
+    is applied by ``rgba_to_u8`` (kept in the signature for parity with get_nerf_image)."""
     width, height = camera.size
     width, height = int(width), int(height)
     fl_x = float(camera.f[0])
