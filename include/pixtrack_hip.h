@@ -6,7 +6,7 @@
  * instant-ngp's Testbed through pyngp).  Each entry point below replaces ONE of the
  * Python-level interfaces that path goes through; the citation names the reference
  * line where pixtrack crosses that interface.  The Python host side
- * (pixtrack_amd/*.py) binds these with ctypes and keeps the reference's own
+ * (the pixtrack_amd package) binds these with ctypes and keeps the reference's own
  * class/method names on top (INTEGRATION.md shows the stub a maintainer would add).
  *
  * Conventions
