@@ -173,12 +173,15 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    frame_t = []
     for i in range(args.warmup, n_timed_end):
         tracker.run_single_frame((names[i], frames[i]))
+        frame_t.append(time.perf_counter())  # host-side frame boundaries (each frame ends on its LM result)
     torch.cuda.synchronize()
     if ws > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    frame_ms = np.diff(np.array([t0] + frame_t)) * 1e3
     tracker.testbed.timing_enable(0)
     enc_ms, enc_launches = tracker.testbed.timing_read()
     elapsed = parallel.max_over_ranks(elapsed, dev)
@@ -276,6 +279,8 @@ def main():
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot_err)), 6) if rot_err else None,
         "mean_trans_err_vs_gt": round(float(np.mean(tr_err)), 6) if tr_err else None,
         "stage_ms_per_frame": {k: round(v[0] / max(n_diag, 1), 4) for k, v in stage.items()},
+        "frame_ms": {"p50": round(float(np.percentile(frame_ms, 50)), 4), "p90": round(float(np.percentile(frame_ms, 90)), 4),
+                     "max": round(float(frame_ms.max()), 4), "argmax": int(frame_ms.argmax())},
         "stage_ms_note": f"HIP-event times of a separate untimed pass over the next {n_diag} frames",
         "roofline": roofline,
     }

@@ -1116,7 +1116,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));  // the side streams start after the caller's earlier work
     for (int w = 1; w < n_pipe; ++w) PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side[w], ctx->ev_fork, 0));
   }
-  const int wide = 2048 / n_pipe, enc_grid = 4096 / n_pipe, cmp_grid = 1024 / n_pipe;
+  const int wide = 2048, enc_grid = 4096, cmp_grid = 1024;  // grid-stride kernels: full grids measured best
   for (int w = 0; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
     hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
