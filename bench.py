@@ -169,6 +169,13 @@ def main():
     # region, sampled so that the marker packets do not slow what they measure
     tracker.testbed.timing_enable(4)
 
+    # the frame loop allocates a few hundred small Python objects per frame; a generation-2
+    # collection in the middle of it is a 10 ms stall of the host that feeds the GPU
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     if ws > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -181,6 +188,7 @@ def main():
     if ws > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     frame_ms = np.diff(np.array([t0] + frame_t)) * 1e3
     tracker.testbed.timing_enable(0)
     enc_ms, enc_launches = tracker.testbed.timing_read()

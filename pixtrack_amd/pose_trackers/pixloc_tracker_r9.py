@@ -101,6 +101,7 @@ class PixLocPoseTrackerR9(PoseTracker):
             aabb = ast.literal_eval(os.environ["OBJ_AABB"])
             snapshot = str(Path(object_path) / "pixtrack/instant-ngp/snapshots/weights.msgpack")
         self.testbed = initialize_ingp(snapshot, aabb, device=self.device)
+        self.localizer.refiner.warm_reference_points()  # static per-reference tables, off the frame path
         self.dynamic_id = None
         self.hits = 0
         self.misses = 0

@@ -120,6 +120,12 @@ class PoseTrackerRefiner:
             self._p3d_cache[key] = (p3dids, torch.from_numpy(xyz).to(self.device))
         return self._p3d_cache[key]
 
+    def warm_reference_points(self, dbids: Optional[Sequence[int]] = None) -> None:
+        """Builds the per-reference point tables (static data) up front, so that a switch of the
+        reference image during tracking does not stall a frame on a Python loop over its points."""
+        for dbid in (dbids if dbids is not None else list(self.model3d.dbs)):
+            self._points_of([int(dbid)])
+
     # ---- dense features ----------------------------------------------------------
     def dense_feature_extraction(self, image, name: str, image_scale: int = 1, mask=None, normalize=False):
         """-> (HWC maps [h,w,cstride] x3 with the confidence as channel C, scales)."""
