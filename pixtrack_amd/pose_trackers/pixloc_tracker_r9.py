@@ -333,7 +333,15 @@ def main(argv=None):
         bind_to_device_numa(0)
     tracker = PixLocPoseTrackerR9(object_path=str(args.object_path), data_path=str(data_path),
                                   eval_path=str(eval_path), loc_path=str(loc_path), debug=args.debug)
-    tracker.run(args.query, max_frames=args.frames if args.frames is not None else np.inf)
+    import gc
+
+    gc.collect()
+    gc.freeze()   # the assets stay; a generation-2 collection inside the frame loop is a 10 ms
+    gc.disable()  # stall of the host that feeds the GPU
+    try:
+        tracker.run(args.query, max_frames=args.frames if args.frames is not None else np.inf)
+    finally:
+        gc.enable()
     tracker.save_poses(args.pixloc_pickles)
     print("Cache hits: %d, misses: %d" % (tracker.hits, tracker.misses))
     _dump(tracker.pose_tracker_history, os.path.join(tracker.eval_path, "trackers.pkl"), args.pixloc_pickles)
