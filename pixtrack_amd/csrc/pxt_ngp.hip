@@ -127,14 +127,16 @@ __device__ inline void sh4_eval(float x, float y, float z, float* o) {
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
-// ReLU + fp16 pack of 8 consecutive accumulator rows -> one B fragment.
+// ReLU + fp16 pack of 8 consecutive accumulator rows -> one B fragment.  The ReLU runs on the
+// packed halves (fp16 rounding is monotone and sign preserving, so max(fp16(x), 0) = fp16(max(x, 0))
+// up to the sign of a zero, which an MFMA operand does not see): 4 v_pk_max_f16 instead of 8 v_max_f32.
 __device__ inline half8 relu_pack8(const f32x16& a, int base, bool relu) {
   half8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float v = a[base + j];
-    if (relu) v = fmaxf(v, 0.f);
-    r[j] = (half_t)v;
+  for (int j = 0; j < 8; ++j) r[j] = (half_t)a[base + j];
+  if (relu) {
+    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    r = __builtin_elementwise_max(r, z);
   }
   return r;
 }
@@ -210,14 +212,16 @@ __device__ inline void ngp_mlp_block(const half8* s_w, int lane, half8 x0, half8
     a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC1 + 2 * rb + 1) * 64 + lane], shb, a, 0, 0, 0);
     c1[rb] = a;
   }
+  half8 c1p[4];  // packed once, used by both output row blocks
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c1p[q] = relu_pack8(c1[q >> 1], 8 * (q & 1), true);
   f32x16 c2[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     f32x16 a = {0};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC2 + 4 * rb + q) * 64 + lane],
-                                                 relu_pack8(c1[q >> 1], 8 * (q & 1), true), a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_32x32x16_f16(s_w[(kFragC2 + 4 * rb + q) * 64 + lane], c1p[q], a, 0, 0, 0);
     c2[rb] = a;
   }
   f32x16 cout = {0};
