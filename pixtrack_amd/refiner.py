@@ -28,7 +28,7 @@ from . import _lib
 from .feature_extractor import PixTrackFeatureExtractor
 from .geometry import Camera, Pose
 from .model3d import Model3D
-from .optimizer import LevelPack, PixTrackOptimizer
+from .optimizer import LevelPack, PixTrackOptimizer, cstride_for
 from .unet import OUTPUT_DIMS, UNet
 from .utils.conf import Conf, merge
 
@@ -181,6 +181,83 @@ class PoseTrackerRefiner:
             features[str(image_scale)] = self.interp_sparse_observations(maps, scales, dbids[0], p3dids, pose, p3d)
         return features
 
+    # ---- pre-extracted reference features (reference :175-198) ---------------------------
+    # File layout of the reference's reader: group[str(ref_id)][str(scale)]["p3dids"] (int ids) and
+    # group[str(ref_id)][str(scale)][str(level)]["p3did_to_feat"] ([n, C_level + 1]: descriptor then
+    # confidence, row i belongs to p3dids[i]).  The reference tree has a reader but no writer; both
+    # directions live here.  Containers: `reference_features.h5` when h5py is importable (it is not
+    # in this image), else `reference_features.npz` with the same hierarchy as "/"-joined keys.
+    def _feature_cache_paths(self):
+        from pathlib import Path
+
+        dumps = Path(self.paths.get("dumps", "."))
+        return dumps / "reference_features.h5", dumps / "reference_features.npz"
+
+    def read_features(self, ref_id) -> Dict[str, SparseReferenceFeatures]:
+        h5_path, npz_path = self._feature_cache_paths()
+        multiscales = self.conf.multiscale or [1]
+        arrays = {}
+        if h5_path.exists():
+            try:
+                import h5py
+            except ImportError as e:
+                raise _lib.PxtError(f"{h5_path} needs h5py, which this environment lacks; convert it to "
+                                    f"{npz_path.name} (same keys, '/'-joined)") from e
+            with h5py.File(str(h5_path), "r") as f:
+                for scale in multiscales:
+                    g = f[str(ref_id)][str(scale)]
+                    arrays[f"{scale}/p3dids"] = np.array(g["p3dids"])
+                    for level in (k for k in g.keys() if k != "p3dids"):
+                        arrays[f"{scale}/{level}/p3did_to_feat"] = np.array(g[level]["p3did_to_feat"])
+        elif npz_path.exists():
+            with np.load(npz_path) as z:
+                pre = f"{ref_id}/"
+                arrays = {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
+        else:
+            raise FileNotFoundError(f"no reference feature cache at {h5_path} or {npz_path}")
+        out = {}
+        for scale in multiscales:
+            p3dids = [int(x) for x in arrays[f"{scale}/p3dids"].tolist()]
+            packed = []
+            for level, c in enumerate(OUTPUT_DIMS):
+                feat = torch.from_numpy(np.asarray(arrays[f"{scale}/{level}/p3did_to_feat"], np.float32))
+                assert feat.shape == (len(p3dids), c + 1), (feat.shape, len(p3dids), c)
+                rec = torch.zeros(len(p3dids), cstride_for(c))
+                d = feat[:, :c]
+                rec[:, :c] = d / d.norm(dim=1, keepdim=True).clamp_min(1e-12)  # A.4: L2-normalised reference
+                rec[:, c] = feat[:, c]
+                packed.append(rec.to(self.device))
+            xyz = np.array([self.model3d.points3D[p].xyz for p in p3dids], np.float32).reshape(-1, 3)
+            valid = torch.ones(len(p3dids), dtype=torch.uint8, device=self.device)
+            out[str(scale)] = SparseReferenceFeatures(packed, valid, p3dids, torch.from_numpy(xyz).to(self.device),
+                                                      OUTPUT_DIMS)
+        return out
+
+    def write_features(self, features_by_ref: Dict, path=None) -> str:
+        """Writes {ref_id: {str(scale): SparseReferenceFeatures}} (e.g. what extract_reference_features
+        returns) in the layout read_features reads; only points valid on every level are stored.
+        Descriptors are stored as held here (L2-normalised; the reader normalises again)."""
+        h5_path, npz_path = self._feature_cache_paths()
+        arrays = {}
+        for ref_id, per_scale in features_by_ref.items():
+            for scale, ref in per_scale.items():
+                keep = ref.valid.cpu().bool()
+                ids = [p for p, k in zip(ref.p3dids_all, keep.tolist()) if k]
+                arrays[f"{ref_id}/{scale}/p3dids"] = np.asarray(ids, np.int64)
+                for level, c in enumerate(ref.dims):
+                    arrays[f"{ref_id}/{scale}/{level}/p3did_to_feat"] = ref.packed[level].cpu()[keep][:, : c + 1].numpy()
+        try:
+            import h5py
+        except ImportError:
+            target = str(path or npz_path)
+            np.savez(target, **arrays)
+            return target if target.endswith(".npz") else target + ".npz"
+        target = str(path or h5_path)
+        with h5py.File(target, "w") as f:
+            for k, v in arrays.items():
+                f.create_dataset(k, data=v)
+        return target
+
     # ---- refinement ------------------------------------------------------------------
     def refine(self, qname: str, qcamera: Camera, pose_init: Pose, dbids: List[int], loc=None,
                image_query=None, pose: Optional[Pose] = None, reference_images=None, dynamic_id=None) -> Dict:
@@ -200,8 +277,16 @@ class PoseTrackerRefiner:
         if reference_images is not None:
             raise NotImplementedError("raw reference images per query (r6/r8 mode) are out of scope")
         if dynamic_id is None:
-            raise NotImplementedError("reference_features.h5 (static references) is a 'next' row (SURVEY 8f)")
-        features_dict = self.features_dicts[dynamic_id]["features"]
+            # static references (the r5/r7 trackers' mode, reference :243-248): pre-extracted sparse
+            # features of the reference image, read once from the cache file and kept
+            ref_id = dbids[0]
+            if ref_id in self.features_dicts:
+                features_dict = self.features_dicts[ref_id]
+            else:
+                features_dict = self.read_features(ref_id)
+            self.features_dicts[ref_id] = features_dict
+        else:
+            features_dict = self.features_dicts[dynamic_id]["features"]
         self.last_lm = []
         ret = {"success": False, "T_init": T_init}
         for image_scale in multiscales:

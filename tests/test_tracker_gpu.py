@@ -192,3 +192,40 @@ def test_frames_larger_than_the_extractor_limit(device):
         assert geodesic_distance_for_rotations(R, Rg) < 2e-2 and np.linalg.norm(t - tg) < 2e-2
     maps = tr.localizer.refiner.last_lm[0]
     assert maps.iters[0] >= 1 and not maps.failed
+
+
+def test_static_reference_feature_cache_round_trip(device, tmp_path):
+    """pre-extracted reference features (the r5/r7 trackers' mode).  Features
+    written with write_features and read back through read_features drive the same refinement as
+    the dynamic reference they were taken from."""
+    assets = make_tracking_assets(seed=1031, width=128, height=96, n_frames=3, n_points=3000)
+    tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+    tr.spp = 2
+    frames = render_query_frames(assets, tr.testbed)
+    tr.run_single_frame(("000000.png", frames[0]))
+    tr.run_single_frame(("000001.png", frames[1]))
+    refiner = tr.localizer.refiner
+    ref_id = tr.reference_ids[0]
+    dyn = refiner.features_dicts[tr.dynamic_id]["features"]
+    ret_dyn = tr.pose_history["000001.png"]
+    # write under the refiner's dumps directory, drop every in-memory copy, refine again statically
+    refiner.paths["dumps"] = tmp_path
+    written = refiner.write_features({ref_id: dyn})
+    assert written.endswith((".npz", ".h5")) and (tmp_path / "reference_features.npz").exists() or written.endswith(".h5")
+    refiner.features_dicts.pop(ref_id, None)
+    static = refiner.read_features(ref_id)
+    keep = dyn["1"].valid.cpu().bool()
+    assert static["1"]["p3dids"] == [p for p, k in zip(dyn["1"].p3dids_all, keep.tolist()) if k]
+    for level in range(3):
+        a, b = static["1"].packed[level].cpu(), dyn["1"].packed[level].cpu()[keep]
+        assert torch.allclose(a, b, atol=1e-6)
+    refiner.query_mask = None
+    # same start pose, same (unmasked) query through both paths
+    T0 = ret_dyn["T_init"]
+    ret_a = refiner.refine_query_pose("q", tr.camera, T0, [ref_id], [1], image_query=frames[1], dynamic_id=tr.dynamic_id)
+    ret_b = refiner.refine_query_pose("q", tr.camera, T0, [ref_id], [1], image_query=frames[1], dynamic_id=None)
+    assert ret_a["success"] and ret_b["success"]
+    Ra, ta = ret_a["T_refined"].numpy()
+    Rb, tb = ret_b["T_refined"].numpy()
+    assert geodesic_distance_for_rotations(Ra, Rb) < 1e-5 and np.linalg.norm(ta - tb) < 1e-5
+    assert ref_id in refiner.features_dicts  # cached after the first static read
