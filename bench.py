@@ -133,12 +133,21 @@ def main():
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
     from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
 
-    rank, ws, local_rank = parallel.init_from_env("nccl")
+    # RCCL ("nccl") is the backend of a real multi-GPU run.  PXT_DIST_BACKEND=gloo exists to
+    # rehearse the multi-rank control flow (barriers, max-over-ranks, pose gather) on a box with
+    # fewer GPUs than ranks: the ranks then share devices and the collectives run on host tensors.
+    backend = os.environ.get("PXT_DIST_BACKEND", "nccl")
+    rank, ws, local_rank = parallel.init_from_env(backend)
     assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback for the product path)")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and ws > n_dev:
+        raise SystemExit(f"{ws} ranks but {n_dev} visible GPUs: RCCL needs one GPU per rank")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     numa_node = parallel.bind_to_device_numa(local_rank)  # before any pinned allocation
 
     n_diag = min(20, args.steps)  # untimed diagnostic pass (per-stage HIP-event times)
@@ -192,7 +201,7 @@ def main():
     frame_ms = np.diff(np.array([t0] + frame_t)) * 1e3
     tracker.testbed.timing_enable(0)
     enc_ms, enc_launches = tracker.testbed.timing_read()
-    elapsed = parallel.max_over_ranks(elapsed, dev)
+    elapsed = parallel.max_over_ranks(elapsed, coll_dev)
     stats = tracker.testbed.stats_accum.cpu().tolist()
     n_renders = tracker.testbed.n_renders - n_renders0
     # per-stage times: a separate, untimed pass over the next frames of the same sequence (event
@@ -212,7 +221,7 @@ def main():
     iso_samples = tracker.testbed.stats_accum.cpu().tolist()[0]
 
     records = parallel.pack_pose_records(tracker.pose_history, names[args.warmup:n_timed_end])
-    gathered = parallel.gather_pose_records(records.to(dev), dev)  # the one collective (RCCL)
+    gathered = parallel.gather_pose_records(records.to(coll_dev), coll_dev)  # the one collective (RCCL)
     n_ok = int(sum(float(g[:, 12].sum()) for g in gathered))
     total_frames = sum(g.shape[0] for g in gathered)
 
