@@ -85,7 +85,7 @@ def depth_mask(depth_rgba: np.ndarray) -> np.ndarray:
 
 def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndarray, ref_id: int,
                 multiscale=(1,), use_mask: bool = True, lm_conf: Optional[LO.LMConf] = None,
-                timings: Optional[Dict[str, float]] = None, spp: int = 8):
+                timings: Optional[Dict[str, float]] = None, spp: int = 8, keep: Optional[Dict] = None):
     """One frame from pose (R, t): returns dict(success, R, t, cost, mask).  ``query_image``
     float32 HWC 0..255.  Follows refine(): mask -> dynamic reference -> per scale
     {UNet(ref) -> sparse sample, UNet(query) -> LM over 3 levels coarse->fine}."""
@@ -105,6 +105,8 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
         t0 = time.perf_counter()
         depth = NO.render(ngp, nerf_view(snapshot, nerf2sfm, aabb, R, t, qcam, 1, spp))
         mask = depth_mask(depth)
+        if keep is not None:
+            keep["depth_rgba"] = depth
         img = img * mask[..., None].astype(np.float32)
         tick("nerf_depth", t0)
     # dynamic reference render with SfM camera 1 scaled by reference_scale 0.5
@@ -114,6 +116,8 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
     t0 = time.perf_counter()
     ref_rgba = NO.render(ngp, nerf_view(snapshot, nerf2sfm, aabb, R, t, ref_cam, 0, spp))
     ref_img = to_u8(ref_rgba).astype(np.float32)
+    if keep is not None:
+        keep["ref_rgba"] = ref_rgba
     tick("nerf_ref", t0)
     # points observed by the reference image with track length >= 3
     im = model3d.dbs[ref_id]

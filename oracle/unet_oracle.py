@@ -88,7 +88,7 @@ def extractor_call(weights, image_hwc: np.ndarray, scale_image: int = 1, resize_
         s = target / max(h, w)
         h_new, w_new = int(round(h * s)), int(round(w * s))
         img = cv2_resize_linear(img, w_new, h_new)
-        scale_resize = (w_new / w, h_new / h)
+        scale_resize = (s, s)  # pixloc resize(): the int/max branch returns the unrounded factor (its TODO)
     x = torch.from_numpy(img).permute(2, 0, 1) / 255.0
     feats, confs = unet_forward(weights, x)
     scales = [(scale_resize[0] / s, scale_resize[1] / s) for s in (1, 4, 16)]

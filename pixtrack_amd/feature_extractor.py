@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ops import ops
 from .unet import OUTPUT_DIMS
 from .utils.conf import merge
 
@@ -40,8 +41,10 @@ class PixTrackFeatureExtractor:
             if max(h, w) > target or self.conf.resize_by == "max_force":
                 s = target / max(h, w)
                 h_new, w_new = int(round(h * s)), int(round(w * s))
-                scale_resize = (w_new / w, h_new / h)
-                return h_new, w_new, scale_resize
+                # pixloc's resize() returns the UNROUNDED factor for the int/max branch (its own
+                # TODO says it should recompute from the rounded size; it does not), and the level
+                # cameras are scaled with what it returns (feature_extractor.py:45,56-57)
+                return h_new, w_new, (s, s)
         return h, w, scale_resize
 
     def _to_device_hwc(self, image) -> torch.Tensor:
@@ -98,8 +101,7 @@ class PixTrackFeatureExtractor:
                 mask = None
             src = img.float().contiguous()
             dst = torch.empty(h_new, w_new, 3, device=self.device, dtype=torch.float32)
-            _lib.check(_lib.lib().pxt_resize_linear(src.data_ptr(), H, W, 3, dst.data_ptr(), h_new, w_new,
-                                                    _lib.stream_ptr(self.device)), "pxt_resize_linear")
+            ops.resize_linear(src, dst)
             img = dst
         maps = self.model.forward_packed(img, mask, normalize=normalize)
         scales = [(scale_resize[0] / s, scale_resize[1] / s) for s in self.model.scales]

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ops import ops
 
 N_MLP_PARAMS = 64 * 32 + 16 * 64 + 64 * 32 + 64 * 64 + 16 * 64
 MLP_SHAPES = [("d1", 64, 32), ("d2", 16, 64), ("c1", 64, 32), ("c2", 64, 64), ("c3", 16, 64)]
@@ -209,15 +210,40 @@ def from_instant_ngp(d: Dict) -> NerfSnapshot:
     k1 = 0.0
     meta = ds.get("metadata") or []
     if meta and isinstance(meta[0], dict):
-        cd = meta[0].get("camera_distortion") or meta[0].get("lens") or {}
-        prm = cd.get("params") or [0.0]
-        k1 = float(prm[0]) if int(cd.get("mode", 1)) == 1 else 0.0  # 1 = Iso (radial k1, k2, p1, p2)
+        k1 = _training_lens_k1(meta[0])
     return NerfSnapshot(
         grid=params[_MLP_PARAMS:].reshape(-1, F).copy(), mlp=params[:_MLP_PARAMS].copy(),
         occupancy=occupancy_from_density_grid(density), n_levels=n_levels, n_features=F, log2_hashmap=log2_T,
         base_res=base, per_level_scale=pls, cascades=expect_c, aabb_scale=aabb_scale,
         cone_angle=0.0 if aabb_scale <= 1.0 else 1.0 / 256.0, scale=float(ds.get("scale", 0.33)),
         offset=float(offset[0]), k1=k1)
+
+
+def _training_lens_k1(meta0: Dict) -> float:
+    """Radial k1 of the training lens from metadata[0].  Two encodings are accepted, because the
+    layout cannot be checked against instant-ngp here (its source is not in the reference tree):
+    ``{"mode": m, "params": [k1, k2, p1, p2, ...]}`` and named keys (``k1`` / ``k2`` / ``p1`` / ``p2``;
+    ``ftheta_*`` marks a lens this renderer does not model).  A lens record that is present but
+    unreadable raises instead of silently rendering without distortion."""
+    cd = meta0.get("camera_distortion")
+    if cd is None:
+        cd = meta0.get("lens")
+    if cd is None:
+        return 0.0
+    if not isinstance(cd, dict):
+        raise _lib.PxtError(f"snapshot lens record of type {type(cd).__name__} is not understood")
+    if any(str(k).startswith("ftheta") for k in cd) or str(cd.get("mode", "")).lower() in ("ftheta", "2", "fisheye"):
+        raise _lib.PxtError("the snapshot was trained with an f-theta / fisheye lens, which this renderer does not model")
+    if "k1" in cd:
+        return float(cd["k1"])
+    if "params" in cd:
+        prm = list(cd["params"]) or [0.0]
+        mode = cd.get("mode", 1)
+        undistorted = mode in (0, "0", "Perspective", "perspective", None) and not any(float(x) != 0.0 for x in prm)
+        return 0.0 if undistorted else float(prm[0])
+    if not cd:
+        return 0.0
+    raise _lib.PxtError(f"snapshot lens record has none of the known keys (k1 / params): {sorted(map(str, cd))}")
 
 
 def to_instant_ngp(snap: NerfSnapshot) -> Dict:
@@ -334,18 +360,18 @@ class Testbed:
         assert self._snap is not None, "load_snapshot first"
         self._cam_ngp = nerf_matrix_to_ngp(np.asarray(nerf_c2w_3x4), self._snap.scale, self._snap.offset)
 
-    def _view(self, width: int, height: int, spp: int) -> _lib.NgpView:
-        v = _lib.NgpView()
-        v.cam[:] = [float(x) for x in np.asarray(self._cam_ngp, np.float32).reshape(-1)]
+    def _view(self) -> list:
+        """The 25-float view record of torch.ops.pixtrack.ngp_render (ops.VIEW_FLOATS): camera 3x4,
+        focal, k1, render box min / max, background RGBA, minimum transmittance."""
+        return ([float(x) for x in np.asarray(self._cam_ngp, np.float32).reshape(-1)]
+                + [0.0, float(self._snap.k1) if self.nerf.render_with_camera_distortion else 0.0]
+                + [float(x) for x in self.render_aabb.min] + [float(x) for x in self.render_aabb.max]
+                + [float(x) for x in self.background_color] + [float(self.nerf.rendering_min_transmittance)])
+
+    def _view_for(self, width: int, height: int) -> list:
+        v = self._view()
         res = width if self.fov_axis == 0 else height
-        v.focal = float(np.float32(0.5 * res / math.tan(0.5 * math.radians(self.fov))))
-        v.k1 = float(self._snap.k1) if self.nerf.render_with_camera_distortion else 0.0
-        v.aabb_min[:] = [float(x) for x in self.render_aabb.min]
-        v.aabb_max[:] = [float(x) for x in self.render_aabb.max]
-        v.background[:] = [float(x) for x in self.background_color]
-        v.min_transmittance = float(self.nerf.rendering_min_transmittance)
-        v.width, v.height, v.spp = int(width), int(height), int(spp)
-        v.mode = int(self.render_mode)
+        v[12] = float(np.float32(0.5 * res / math.tan(0.5 * math.radians(self.fov))))
         return v
 
     def render_device(self, width: int, height: int, spp: int = 8, linear: bool = True,
@@ -359,10 +385,8 @@ class Testbed:
         stats = self.stats_accum  # running totals across launches when set (bench)
         if collect_stats:
             stats = torch.zeros(4, dtype=torch.int64, device=self.device)
-        v = self._view(width, height, spp)
-        _lib.check(
-            _lib.lib().pxt_ngp_render(self._ctx, C.byref(v), out.data_ptr(), _lib.dptr(stats),
-                                      _lib.stream_ptr(self.device)), "pxt_ngp_render")
+        ops.ngp_render(self._ctx_int(), self._view_for(width, height), int(width), int(height), int(spp),
+                       int(self.render_mode), out, stats)
         if collect_stats:
             self._stats = stats
         self.n_renders += 1
@@ -376,13 +400,13 @@ class Testbed:
             raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
         rgba = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
         depth = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
-        v = self._view(width, height, spp)
-        _lib.check(
-            _lib.lib().pxt_ngp_render_both(self._ctx, C.byref(v), rgba.data_ptr(), depth.data_ptr(),
-                                           _lib.dptr(self.stats_accum), _lib.stream_ptr(self.device)),
-            "pxt_ngp_render_both")
+        ops.ngp_render_both(self._ctx_int(), self._view_for(width, height), int(width), int(height), int(spp),
+                            rgba, depth, self.stats_accum)
         self.n_renders += 1
         return rgba, depth
+
+    def _ctx_int(self) -> int:
+        return int(self._ctx.value) if hasattr(self._ctx, "value") else int(self._ctx)
 
     def render(self, width: int, height: int, spp: int = 8, linear: bool = True) -> np.ndarray:
         return self.render_device(width, height, spp, linear).cpu().numpy()

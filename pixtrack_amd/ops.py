@@ -1,0 +1,262 @@
+"""``torch.ops.pixtrack.*``: the C-ABI entry points of libpixtrack_hip.so (include/pixtrack_hip.h)
+registered as ``torch.library`` custom ops on the ROCm device (dispatch key CUDA == HIP on a
+ROCm build of torch).  This is the seam SURVEY.md 8(b) / BASELINE north_star ask for: Python host
+code hands ``torch.Tensor``s to the ops, the op bodies are the only place where ctypes touches the
+hot path (pointers, sizes, the current HIP stream).
+
+Reference call sites the ops stand in for:
+  lm_refine            pixloc BaseRefiner.refine_pose_using_features -> opt.run per level
+                       (pixtrack/localization/pixloc_pose_refiners.py:255-262)
+  sample_sparse        PoseTrackerRefiner.interp_sparse_observations (:327-368, interpolator :351)
+  unet_forward_batch   self.model({"image": ...}) (pixtrack/localization/feature_extractor.py:48)
+  ngp_render[_both]    testbed.render(w, h, spp, True) (pixtrack/visualization/run_vis_on_poses.py:51)
+  depth_mask           get_mask morphology (pixtrack/pose_trackers/pixloc_tracker_r9.py:207-214)
+  rgba_to_u8           get_nerf_image's alpha threshold / *255 / uint8 (run_vis_on_poses.py:52-54)
+  resize_linear        pixloc resize(image, size, max, "linear") (feature_extractor.py:45)
+
+All ops are out-variants (they write into tensors the caller allocated and mutate nothing else), so
+the caller decides buffer reuse.  Context handles (``pxt_unet*`` / ``pxt_ngp*``) travel as ints.
+There is no CPU implementation: the ops are registered for the CUDA(HIP) key only, so a call with
+CPU tensors fails in the dispatcher, and a missing library raises ``PxtError`` at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+_NS = "pixtrack"
+_DEF = torch.library.Library(_NS, "DEF")
+
+SCHEMAS = {
+    "lm_refine": (
+        "(Tensor p3d, Tensor? point_mask, Tensor[] fmaps, Tensor[] frefs, int[] channels, float[] cameras, "
+        "int[] ndist, float[] lambdas, float[] T_init, int num_iters, int pad, int loss, float loss_alpha, "
+        "float loss_scale, float grad_stop, float dt_stop, float dR_stop, int min_valid, int n_workgroups, "
+        "Tensor(a!) record, Tensor(b!) workspace, bool want_log) -> ()"),
+    "sample_sparse": (
+        "(Tensor p3d, float[] T, Tensor[] fmaps, int[] channels, float[] cameras, int[] ndist, int pad, "
+        "bool normalize, Tensor(a!)[] outs, Tensor(b!) valid) -> ()"),
+    "unet_forward_batch": (
+        "(int ctx, Tensor[] images, Tensor?[] masks, bool[] normalize, Tensor(a!)[] outs, Tensor(b!) workspace) -> ()"),
+    "ngp_render": (
+        "(int ctx, float[] view, int width, int height, int spp, int mode, Tensor(a!) out, Tensor(b!)? stats) -> ()"),
+    "ngp_render_both": (
+        "(int ctx, float[] view, int width, int height, int spp, Tensor(a!) rgba, Tensor(b!) depth, "
+        "Tensor(c!)? stats) -> ()"),
+    "depth_mask": "(Tensor depth_rgba, int n_erode, int n_dilate, Tensor(a!) mask, Tensor(b!) scratch) -> ()",
+    "rgba_to_u8": "(Tensor rgba, float alpha_thresh, Tensor(a!) out) -> ()",
+    "resize_linear": "(Tensor src, Tensor(a!) dst) -> ()",
+    "conv3x3_nhwc_f16": "(Tensor x, Tensor weight, Tensor bias, bool relu, Tensor(a!) out) -> ()",
+}
+for _name, _schema in SCHEMAS.items():
+    _DEF.define(_name + _schema)
+
+VIEW_FLOATS = 12 + 2 + 3 + 3 + 4 + 1  # cam 3x4, focal, k1, aabb_min, aabb_max, background, min_transmittance
+
+
+def _stream(t: torch.Tensor) -> int:
+    return int(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.PxtError(f"{what} must be a contiguous float32 tensor (got {t.dtype}, contiguous={t.is_contiguous()})")
+    return t
+
+
+# ------------------------------------------------------------------------------------------- LM
+def _lm_refine(p3d, point_mask, fmaps, frefs, channels, cameras, ndist, lambdas, T_init, num_iters, pad, loss,
+               loss_alpha, loss_scale, grad_stop, dt_stop, dR_stop, min_valid, n_workgroups, record, workspace,
+               want_log):
+    L = _lib.lib()
+    n_levels = len(fmaps)
+    if not (1 <= n_levels <= _lib.PXT_MAX_LEVELS) or len(frefs) != n_levels or len(channels) != n_levels:
+        raise _lib.PxtError(f"lm_refine: {n_levels} levels (1..{_lib.PXT_MAX_LEVELS}), {len(frefs)} frefs, {len(channels)} channels")
+    if len(cameras) != 10 * n_levels or len(lambdas) != 6 * n_levels or len(ndist) != n_levels or len(T_init) != 12:
+        raise _lib.PxtError("lm_refine: cameras need 10, lambdas 6 floats per level, T_init 12 floats")
+    _f32c(p3d, "p3d")
+    n = int(p3d.shape[0])
+    arr = (_lib.LmLevel * n_levels)()
+    for i in range(n_levels):
+        fm, fr = _f32c(fmaps[i], "fmap"), _f32c(frefs[i], "fref")
+        h, w, cs = fm.shape
+        if tuple(fr.shape) != (n, cs):
+            raise _lib.PxtError(f"lm_refine: fref of level {i} is {tuple(fr.shape)}, expected {(n, cs)}")
+        arr[i].fmap, arr[i].fref = fm.data_ptr(), fr.data_ptr()
+        arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, int(channels[i]), cs
+        arr[i].cam[:] = cameras[10 * i:10 * i + 10]
+        arr[i].ndist = int(ndist[i])
+        arr[i].lambda_[:] = lambdas[6 * i:6 * i + 6]
+    conf = _lib.LmConf()
+    conf.num_iters, conf.pad, conf.loss = int(num_iters), int(pad), int(loss)
+    conf.loss_alpha, conf.loss_scale = float(loss_alpha), float(loss_scale)
+    conf.grad_stop, conf.dt_stop, conf.dR_stop = float(grad_stop), float(dt_stop), float(dR_stop)
+    conf.min_valid, conf.n_workgroups = int(min_valid), int(n_workgroups)
+    nh = 16 + _lib.PXT_MAX_LEVELS
+    need = nh + (n_levels * int(num_iters) * _lib.PXT_LM_LOG_STRIDE if want_log else 0)
+    if record.dtype != torch.float32 or record.numel() < need or not record.is_contiguous():
+        raise _lib.PxtError(f"lm_refine: record needs {need} contiguous float32 values")
+    if not (record.is_cuda or record.is_pinned()):
+        raise _lib.PxtError("lm_refine: record must be device memory or pinned host memory")
+    if point_mask is not None and (point_mask.dtype != torch.uint8 or not point_mask.is_contiguous()):
+        raise _lib.PxtError("lm_refine: point_mask must be contiguous uint8")
+    base = record.data_ptr()
+    T0 = (C.c_float * 12)(*[float(x) for x in T_init])
+    _lib.check(
+        L.pxt_lm_refine(p3d.data_ptr(), _lib.dptr(point_mask), n, arr, n_levels, T0, C.byref(conf), base,
+                        base + 4 * nh if want_log else None, workspace.data_ptr(), _stream(p3d)),
+        "pxt_lm_refine")
+
+
+# ------------------------------------------------------------------------------------ sampling
+def _sample_sparse(p3d, T, fmaps, channels, cameras, ndist, pad, normalize, outs, valid):
+    L = _lib.lib()
+    n_levels = len(fmaps)
+    if len(outs) != n_levels or len(cameras) != 10 * n_levels or len(T) != 12:
+        raise _lib.PxtError("sample_sparse: one out tensor and 10 camera floats per level, T of 12 floats")
+    _f32c(p3d, "p3d")
+    n = int(p3d.shape[0])
+    arr = (_lib.SampleLevel * n_levels)()
+    for i in range(n_levels):
+        fm, out = _f32c(fmaps[i], "fmap"), _f32c(outs[i], "out")
+        h, w, cs = fm.shape
+        if tuple(out.shape) != (n, cs):
+            raise _lib.PxtError(f"sample_sparse: out of level {i} is {tuple(out.shape)}, expected {(n, cs)}")
+        arr[i].fmap, arr[i].out = fm.data_ptr(), out.data_ptr()
+        arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, int(channels[i]), cs
+        arr[i].cam[:] = cameras[10 * i:10 * i + 10]
+        arr[i].ndist = int(ndist[i])
+    if valid.dtype != torch.uint8 or valid.numel() != n:
+        raise _lib.PxtError("sample_sparse: valid must be uint8 [n_points]")
+    T12 = (C.c_float * 12)(*[float(x) for x in T])
+    _lib.check(L.pxt_sample_sparse(p3d.data_ptr(), n, T12, arr, n_levels, int(pad), int(bool(normalize)),
+                                   valid.data_ptr(), _stream(p3d)), "pxt_sample_sparse")
+
+
+# ---------------------------------------------------------------------------------------- UNet
+def _unet_forward_batch(ctx, images, masks, normalize, outs, workspace):
+    L = _lib.lib()
+    n = len(images)
+    if n == 0 or len(masks) != n or len(normalize) != n or len(outs) != 3 * n:
+        raise _lib.PxtError("unet_forward_batch: per image one mask slot, one normalize flag and three output maps")
+    H, W = int(images[0].shape[0]), int(images[0].shape[1])
+    for im, mk in zip(images, masks):
+        if im.dim() != 3 or im.shape[2] != 3 or not im.is_contiguous() or im.dtype not in (torch.float32, torch.uint8):
+            raise _lib.PxtError("unet_forward_batch: images are contiguous HWC, 3 channels, float32 or uint8")
+        if (int(im.shape[0]), int(im.shape[1])) != (H, W):
+            raise _lib.PxtError("unet_forward_batch: a batch holds images of one size")
+        if mk is not None and (mk.dtype != torch.uint8 or tuple(mk.shape) != (H, W) or not mk.is_contiguous()):
+            raise _lib.PxtError("unet_forward_batch: masks are contiguous uint8 [H, W]")
+    need = int(L.pxt_unet_workspace_bytes_batch(ctx, n, H, W))
+    if need <= 0:
+        raise _lib.PxtError(f"image {H}x{W} (batch {n}) is not supported by the 4-level encoder")
+    if workspace.numel() * workspace.element_size() < need:
+        raise _lib.PxtError(f"unet_forward_batch: workspace holds {workspace.numel()} bytes, {need} needed")
+    for o in outs:
+        _f32c(o, "out map")
+    imgs = (C.c_void_p * n)(*[im.data_ptr() for im in images])
+    is_u8 = (C.c_int32 * n)(*[int(im.dtype == torch.uint8) for im in images])
+    mks = (C.c_void_p * n)(*[_lib.dptr(m) for m in masks])
+    norm = (C.c_int32 * n)(*[int(bool(x)) for x in normalize])
+    ptrs = (C.c_void_p * (3 * n))(*[o.data_ptr() for o in outs])
+    cs = (C.c_int32 * 3)(*[int(o.shape[2]) for o in outs[:3]])
+    _lib.check(L.pxt_unet_forward_batch(ctx, n, imgs, is_u8, mks, H, W, ptrs, cs, norm, workspace.data_ptr(),
+                                        _stream(images[0])), "pxt_unet_forward_batch")
+
+
+def _conv3x3(x, weight, bias, relu, out):
+    H, W, Cin = (int(s) for s in x.shape)
+    Cout = int(weight.shape[0])
+    _lib.check(_lib.lib().pxt_conv3x3_nhwc_f16(x.data_ptr(), H, W, Cin, weight.data_ptr(), bias.data_ptr(), Cout,
+                                               int(bool(relu)), out.data_ptr(), _stream(x)), "pxt_conv3x3_nhwc_f16")
+
+
+# ---------------------------------------------------------------------------------------- NeRF
+def _view(view: Sequence[float], width, height, spp, mode) -> "_lib.NgpView":
+    if len(view) != VIEW_FLOATS:
+        raise _lib.PxtError(f"ngp view record has {len(view)} floats, expected {VIEW_FLOATS}")
+    v = _lib.NgpView()
+    v.cam[:] = view[0:12]
+    v.focal, v.k1 = view[12], view[13]
+    v.aabb_min[:] = view[14:17]
+    v.aabb_max[:] = view[17:20]
+    v.background[:] = view[20:24]
+    v.min_transmittance = view[24]
+    v.width, v.height, v.spp, v.mode = int(width), int(height), int(spp), int(mode)
+    return v
+
+
+def _check_frame(t: torch.Tensor, width, height, what):
+    _f32c(t, what)
+    if tuple(t.shape) != (height, width, 4):
+        raise _lib.PxtError(f"{what} must be [{height}, {width}, 4] (got {tuple(t.shape)})")
+
+
+def _ngp_render(ctx, view, width, height, spp, mode, out, stats):
+    _check_frame(out, width, height, "out")
+    v = _view(view, width, height, spp, mode)
+    _lib.check(_lib.lib().pxt_ngp_render(ctx, C.byref(v), out.data_ptr(), _lib.dptr(stats), _stream(out)),
+               "pxt_ngp_render")
+
+
+def _ngp_render_both(ctx, view, width, height, spp, rgba, depth, stats):
+    _check_frame(rgba, width, height, "rgba")
+    _check_frame(depth, width, height, "depth")
+    v = _view(view, width, height, spp, 0)
+    _lib.check(_lib.lib().pxt_ngp_render_both(ctx, C.byref(v), rgba.data_ptr(), depth.data_ptr(), _lib.dptr(stats),
+                                              _stream(rgba)), "pxt_ngp_render_both")
+
+
+# ----------------------------------------------------------------------------------- image ops
+def _depth_mask(depth_rgba, n_erode, n_dilate, mask, scratch):
+    _f32c(depth_rgba, "depth_rgba")
+    H, W = int(depth_rgba.shape[0]), int(depth_rgba.shape[1])
+    if mask.dtype != torch.uint8 or tuple(mask.shape) != (H, W) or scratch.numel() < 2 * H * W:
+        raise _lib.PxtError("depth_mask: mask is uint8 [H, W], scratch holds 2*H*W bytes")
+    _lib.check(_lib.lib().pxt_depth_mask(depth_rgba.data_ptr(), H, W, int(n_erode), int(n_dilate), mask.data_ptr(),
+                                         scratch.data_ptr(), _stream(depth_rgba)), "pxt_depth_mask")
+
+
+def _rgba_to_u8(rgba, alpha_thresh, out):
+    _f32c(rgba, "rgba")
+    H, W = int(rgba.shape[0]), int(rgba.shape[1])
+    if out.dtype != torch.uint8 or tuple(out.shape) != (H, W, 3):
+        raise _lib.PxtError("rgba_to_u8: out is uint8 [H, W, 3]")
+    _lib.check(_lib.lib().pxt_rgba_to_u8(rgba.data_ptr(), H, W, float(alpha_thresh), out.data_ptr(), _stream(rgba)),
+               "pxt_rgba_to_u8")
+
+
+def _resize_linear(src, dst):
+    _f32c(src, "src")
+    _f32c(dst, "dst")
+    H, W, Cc = (int(s) for s in src.shape)
+    Ho, Wo, Co = (int(s) for s in dst.shape)
+    if Co != Cc:
+        raise _lib.PxtError("resize_linear: channel counts differ")
+    _lib.check(_lib.lib().pxt_resize_linear(src.data_ptr(), H, W, Cc, dst.data_ptr(), Ho, Wo, _stream(src)),
+               "pxt_resize_linear")
+
+
+_IMPLS = {
+    "lm_refine": _lm_refine,
+    "sample_sparse": _sample_sparse,
+    "unet_forward_batch": _unet_forward_batch,
+    "conv3x3_nhwc_f16": _conv3x3,
+    "ngp_render": _ngp_render,
+    "ngp_render_both": _ngp_render_both,
+    "depth_mask": _depth_mask,
+    "rgba_to_u8": _rgba_to_u8,
+    "resize_linear": _resize_linear,
+}
+for _name, _fn in _IMPLS.items():
+    _DEF.impl(_name, _fn, "CUDA")  # CUDA dispatch key == HIP device on torch-ROCm; nothing for CPU
+
+ops = getattr(torch.ops, _NS)
+
+
+def op_names() -> List[str]:
+    return sorted(SCHEMAS)

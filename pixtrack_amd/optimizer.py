@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ops import ops
 from .geometry import Camera, Pose
 from .utils.conf import Conf, merge
 
@@ -96,12 +97,13 @@ class Interpolator:
         fmap[..., :Cc] = tensor.permute(1, 2, 0)
         # treat ALL Cc channels as "descriptor" channels of a (Cc4 = round4) record
         obs, valid = sample_sparse_points2d(fmap, Cc, pts.to(tensor.device, torch.float32), self.pad)
-        return obs, valid, torch.zeros(pts.shape[0], Cc, 2, device=tensor.device)
+        # third output (pixloc: gradients, None unless asked for): gradients exist only inside the
+        # fused LM kernel; asking for them raises above rather than returning made-up values
+        return obs, valid, None
 
 
 def sample_sparse_points2d(fmap: torch.Tensor, Cc: int, pts: torch.Tensor, pad: int):
     """Bilinear sample an HWC map at pixel coordinates through pxt_sample_sparse."""
-    L = _lib.lib()
     h, w, cs = fmap.shape
     N = pts.shape[0]
     # round the descriptor width down to a multiple of 4 is not possible in general, so
@@ -112,19 +114,11 @@ def sample_sparse_points2d(fmap: torch.Tensor, Cc: int, pts: torch.Tensor, pad: 
         fm[..., :cs] = fmap
         fmap, cs = fm, C4 + 4
     p3d = torch.cat([pts, torch.ones(N, 1, device=pts.device)], -1).contiguous()
-    T = _lib.host_pose12([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0])
     out = torch.empty(N, cs, device=pts.device, dtype=torch.float32)
     valid = torch.empty(N, device=pts.device, dtype=torch.uint8)
-    lv = _lib.SampleLevel()
-    lv.fmap, lv.out = fmap.data_ptr(), out.data_ptr()
-    lv.h, lv.w, lv.C, lv.cstride = h, w, C4, cs
-    lv.cam[:] = [w, h, 1, 1, 0, 0, 0, 0, 0, 0]
-    lv.ndist = 0
-    _lib.check(
-        L.pxt_sample_sparse(p3d.data_ptr(), N, T, C.byref(lv), 1, pad, 0,
-                            valid.data_ptr(), _lib.stream_ptr(pts.device)),
-        "pxt_sample_sparse",
-    )
+    # identity pose and a unit camera: (x, y, 1) projects to pixel (x, y)
+    ops.sample_sparse(p3d, [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0, 0, 0, 0], [fmap], [C4],
+                      [float(w), float(h), 1.0, 1.0, 0, 0, 0, 0, 0, 0], [0], int(pad), False, [out], valid)
     return out[:, :Cc], valid.bool()
 
 
@@ -152,7 +146,12 @@ class PixTrackOptimizer:
         normalize_features=False,
         lambda_=0.0,
         interpolation=dict(mode="linear", pad=4),
-        pad=None,  # pixtrack passes optimizer.pad (pixloc_tracker_r9.py:48); honoured if set
+        # pixtrack passes a TOP-LEVEL optimizer.pad = 1 (pixloc_tracker_r9.py:48).  Decision (DESIGN.md
+        # section 4, pinned by tests/test_host_conf.py): it is honoured and becomes interpolation.pad,
+        # as pixloc's BaseModel.__init__ does for its own run_*.py configs ("pad" in conf and not
+        # in default_conf -> conf.interpolation = {pad: ...}; upstream recall, pixloc is not in the
+        # reference tree).  An explicit interpolation.pad wins when the top-level key is absent.
+        pad=None,
         grad_stop_criteria=1e-4,
         dt_stop_criteria=5e-3,
         dR_stop_criteria=5e-2,
@@ -169,7 +168,8 @@ class PixTrackOptimizer:
         self.interpolator = Interpolator(self.conf.interpolation.mode, int(pad))
         self.dampingnet = DampingNet(self.conf.damping)
         self.training = False
-        self.logging_fn: Optional[Callable] = None
+        self.logging_fn: Optional[Callable] = None        # per-iteration hook (pixloc protocol)
+        self.level_logging_fn: Optional[Callable] = None  # whole-level record (DebugTracker.record_level)
         self.device = device
         self._ws = None
         self._ws_dev = None
@@ -189,20 +189,25 @@ class PixTrackOptimizer:
     def state_dict(self):
         return {"dampingnet.const": self.dampingnet.const.clone()}
 
-    # ---- reference semantics kept for API parity ---------------------------
-    def early_stop(self, **args) -> bool:
-        """pixtrack_optimizer.py:5-18, verbatim semantics.  The kernel applies this same
-        rule on-device after every iteration; this method exists for callers/tests."""
-        stop = False
-        if not self.training and (args["i"] % 1) == 0:
-            T_delta, grad = args["T_delta"], args["grad"]
-            grad_norm = torch.norm(grad.detach(), dim=-1)
-            small_grad = grad_norm < self.conf.grad_stop_criteria
-            dR, dt = T_delta.magnitude()
-            small_step = (dt < self.conf.dt_stop_criteria) & (dR < self.conf.dR_stop_criteria)
-            if torch.all(small_step | small_grad):
-                stop = True
-        return stop
+    # ---- stop rule ------------------------------------------------------------
+    def early_stop(self, *, i=0, T_delta=None, grad=None, **_unused) -> bool:
+        """Host statement of the stop test ``lm_refine_kernel`` applies after EVERY update
+        (interface: pixtrack/optimizers/pixtrack_optimizer.py:5-18, which moves pixloc's
+        every-10th-iteration check to every iteration).  In inference mode a batch is finished
+        once each element either took a step below both step thresholds (translation norm and
+        rotation angle in degrees) or has a gradient norm below ``grad_stop_criteria``."""
+        if self.training:
+            return False
+        rot_deg, trans = T_delta.magnitude()
+        return self.converged(rot_deg, trans, torch.linalg.vector_norm(grad.detach(), dim=-1))
+
+    def converged(self, rot_deg, trans, grad_norm) -> bool:
+        """Same test on plain numbers / arrays, e.g. columns 2..4 of the kernel's iteration log
+        (include/pixtrack_hip.h): dR [deg], dt, ||g||."""
+        c = self.conf
+        tiny_step = (torch.as_tensor(trans) < c.dt_stop_criteria) & (torch.as_tensor(rot_deg) < c.dR_stop_criteria)
+        flat = torch.as_tensor(grad_norm) < c.grad_stop_criteria
+        return bool(torch.all(tiny_step | flat))
 
     def log(self, **args):
         if self.logging_fn is not None:
@@ -241,45 +246,32 @@ class PixTrackOptimizer:
     ) -> "PendingLM":
         """Enqueue the fused multi-level refinement (levels in EXECUTION order,
         coarse -> fine).  Returns a handle; ``.result()`` synchronises."""
-        L = _lib.lib()
         _lib.require_gpu(p3d, "p3d")
         dev = p3d.device
         n_levels = len(levels)
         assert 1 <= n_levels <= _lib.PXT_MAX_LEVELS
-        arr = (_lib.LmLevel * n_levels)()
-        keep = []
-        for i, lp in enumerate(levels):
-            assert lp.fmap.is_contiguous() and lp.fref.is_contiguous()
-            assert lp.fmap.dtype == torch.float32 and lp.fref.dtype == torch.float32
-            h, w, cs = lp.fmap.shape
-            assert lp.fref.shape == (p3d.shape[0], cs)
-            arr[i].fmap, arr[i].fref = lp.fmap.data_ptr(), lp.fref.data_ptr()
-            arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, lp.C, cs
-            cam10 = lp.camera.as10()
-            arr[i].cam[:] = cam10.tolist()
-            arr[i].ndist = int(lp.camera._data.shape[-1] - 6)
-            arr[i].lambda_[:] = lp.lambda_.float().tolist()
-            keep.append(lp)
-        T0 = _lib.host_pose12(T_init)
+        cams, lambdas, ndist = [], [], []
+        for lp in levels:
+            assert lp.fref.shape == (p3d.shape[0], lp.fmap.shape[2])
+            cams += lp.camera.as10().tolist()
+            ndist.append(int(lp.camera._data.shape[-1] - 6))
+            lambdas += lp.lambda_.float().tolist()
         # One buffer for the output record and the iteration log, in pinned host memory: the
         # kernel's (write-only) stores land on the host directly, so the frame's critical path
         # has no device->host copy to enqueue and wait for after the kernel - only the event.
+        nh = 16 + _lib.PXT_MAX_LEVELS
         n_log = n_levels * conf.num_iters * _lib.PXT_LM_LOG_STRIDE if want_log else 0
-        buf = _pinned_record(16 + _lib.PXT_MAX_LEVELS + n_log)
-        out = buf[: 16 + _lib.PXT_MAX_LEVELS]
-        out.zero_()
-        log = buf[16 + _lib.PXT_MAX_LEVELS:].view(n_levels, conf.num_iters, _lib.PXT_LM_LOG_STRIDE) if want_log else None
+        buf = _pinned_record(nh + n_log)
+        buf[:nh].zero_()
         p3d = p3d.to(torch.float32).contiguous()
         if mask is not None:
             mask = mask.to(dev, torch.uint8).contiguous()
-        _lib.check(
-            L.pxt_lm_refine(
-                p3d.data_ptr(), _lib.dptr(mask), p3d.shape[0], arr, n_levels, T0,
-                C.byref(conf), out.data_ptr(), _lib.dptr(log), workspace.data_ptr(),
-                _lib.stream_ptr(dev),
-            ),
-            "pxt_lm_refine",
-        )
+        T0 = T_init.as12().detach().cpu().reshape(-1).tolist() if hasattr(T_init, "as12") else [float(x) for x in T_init]
+        ops.lm_refine(p3d, mask, [lp.fmap for lp in levels], [lp.fref for lp in levels], [int(lp.C) for lp in levels],
+                      cams, ndist, lambdas, T0, conf.num_iters, conf.pad, conf.loss, conf.loss_alpha, conf.loss_scale,
+                      conf.grad_stop, conf.dt_stop, conf.dR_stop, conf.min_valid, conf.n_workgroups, buf, workspace,
+                      bool(want_log))
+        keep = list(levels)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
         return PendingLM(buf, want_log, n_levels, conf.num_iters, (p3d, mask, keep, workspace), done)
@@ -316,19 +308,21 @@ class PixTrackOptimizer:
     _run = run
 
     def replay_log(self, res: LMResult, level: int, T_init: Pose):
-        """Feed the recorded iterations of one level to ``logging_fn`` with the kwargs
-        DebugTracker.log_optim_iter reads (tracker.py:32-46)."""
+        """Hand the recorded iterations of one level to the attached tracker: in one call when it
+        takes whole-level records (DebugTracker.record_level), otherwise iteration by iteration
+        through ``logging_fn`` with the kwargs of pixloc's hook (tracker.py:32-46)."""
+        n = res.iters[level]
+        lg = res.log[level]
+        if self.level_logging_fn is not None:
+            self.level_logging_fn(T_init, lg[:n, 0].tolist(), lg[:n, 8:20], lg[:n, 3].tolist())
+            return
         if self.logging_fn is None:
             return
-        lg = res.log[level]
         T_prev = Pose(T_init.as12().detach().cpu().float())
-        for i in range(res.iters[level]):
+        for i in range(n):
             T = Pose(lg[i, 8:20].clone())
-            T_delta = T @ T_prev.inv()
-            self.logging_fn(
-                i=i, T_init=T_init, T=T, T_delta=T_delta,
-                cost=lg[i, 0:1].clone(), valid=torch.ones(1), n_valid=int(lg[i, 1]),
-            )
+            self.logging_fn(i=i, T_init=T_init, T=T, T_delta=T @ T_prev.inv(), cost=lg[i, 0:1].clone(),
+                            valid=torch.ones(1), n_valid=int(lg[i, 1]))
             T_prev = T
 
 
@@ -336,14 +330,15 @@ _PINNED = threading.local()  # per thread: one tracker per thread is the support
 
 
 def _pinned_record(n_floats: int) -> torch.Tensor:
-    """Reusable pinned host buffers, two per size (a result may still be read while the next
-    refinement is enqueued)."""
+    """Reusable pinned host buffers, a ring of two per size: the record of one refinement stays
+    readable while the next one is enqueued; it is recycled by the refinement after that."""
     pool = _PINNED.__dict__.setdefault("pool", {})
-    slot = pool.setdefault(n_floats, [[], 0])
-    if len(slot[0]) < 2:
-        slot[0].append(torch.zeros(n_floats, dtype=torch.float32).pin_memory())
-    slot[1] = (slot[1] + 1) % 2
-    return slot[0][min(slot[1], len(slot[0]) - 1)]
+    ring = pool.get(n_floats)
+    if ring is None:
+        ring = pool[n_floats] = [[torch.zeros(n_floats, dtype=torch.float32).pin_memory() for _ in range(2)], 0]
+    buf = ring[0][ring[1]]
+    ring[1] ^= 1
+    return buf
 
 
 class PendingLM:

@@ -27,6 +27,7 @@ import torch
 from scipy.spatial.transform import Rotation as R
 
 from .. import _lib
+from ..ops import ops
 from ..geometry import Camera as PixCamera, Pose
 from ..model3d import Model3D, extract_covisibility
 from ..refiner import Paths, PoseTrackerLocalizer
@@ -231,8 +232,7 @@ class PixLocPoseTrackerR9(PoseTracker):
         H, W = int(depth.shape[0]), int(depth.shape[1])
         mask = torch.empty(H, W, dtype=torch.uint8, device=self.device)
         tmp = torch.empty(2 * H * W, dtype=torch.uint8, device=self.device)
-        _lib.check(_lib.lib().pxt_depth_mask(depth.data_ptr(), H, W, 1, 5, mask.data_ptr(), tmp.data_ptr(),
-                                             _lib.stream_ptr(self.device)), "pxt_depth_mask")
+        ops.depth_mask(depth, 1, 5, mask, tmp)  # erode 5x5 once, dilate 5x5 five times (:211-213)
         return mask
 
     # ------------------------------------------------------------------ one frame

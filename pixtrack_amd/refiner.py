@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ops import ops
 from .feature_extractor import PixTrackFeatureExtractor
 from .geometry import Camera, Pose
 from .model3d import Model3D
@@ -147,23 +148,17 @@ class PoseTrackerRefiner:
         if p3d is None:
             p3d = torch.from_numpy(np.array([self.model3d.points3D[p].xyz for p in p3dids], np.float32)).to(self.device)
         n = int(p3d.shape[0])
-        L = _lib.lib()
-        arr = (_lib.SampleLevel * len(feature_maps))()
-        outs = []
-        for i, (fm, sc) in enumerate(zip(feature_maps, feature_scales)):
-            h, w, cs = fm.shape
-            out = torch.empty(n, cs, device=self.device, dtype=torch.float32)
-            outs.append(out)
+        outs, cams, ndist = [], [], []
+        for fm, sc in zip(feature_maps, feature_scales):
+            outs.append(torch.empty(n, fm.shape[2], device=self.device, dtype=torch.float32))
             cam_l = camera.scale(sc)
-            arr[i].fmap, arr[i].out = fm.data_ptr(), out.data_ptr()
-            arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, OUTPUT_DIMS[i], cs
-            arr[i].cam[:] = cam_l.as10().tolist()
-            arr[i].ndist = int(cam_l._data.shape[-1] - 6)
-        T12 = _lib.host_pose12(T_w2cam)
+            cams += cam_l.as10().tolist()
+            ndist.append(int(cam_l._data.shape[-1] - 6))
         valid = torch.empty(n, dtype=torch.uint8, device=self.device)
         pad = self.optimizer[0].interpolator.pad
-        _lib.check(L.pxt_sample_sparse(p3d.data_ptr(), n, T12, arr, len(feature_maps), int(pad), 1,
-                                       valid.data_ptr(), _lib.stream_ptr(self.device)), "pxt_sample_sparse")
+        T12 = T_w2cam.as12().detach().cpu().reshape(-1).tolist()
+        ops.sample_sparse(p3d, T12, list(feature_maps), list(OUTPUT_DIMS[:len(feature_maps)]), cams, ndist, int(pad),
+                          True, outs, valid)
         return SparseReferenceFeatures(outs, valid, list(p3dids), p3d, OUTPUT_DIMS)
 
     def extract_reference_features(self, dbids, pose: Optional[Pose] = None, reference_image=None):

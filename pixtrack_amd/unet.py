@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .ops import ops
 from .optimizer import cstride_for
 
 ENC_BLOCKS = [[(3, 64), (64, 64)], [(64, 128), (128, 128)], [(128, 256), (256, 256), (256, 256)],
@@ -263,17 +264,11 @@ class UNet:
     def forward_packed_batch(self, items) -> List[List[torch.Tensor]]:
         """items: [(image, mask or None, normalize)], images of one size -> per image the three
         maps of forward_packed, from ONE set of launches (pxt_unet_forward_batch)."""
-        L = _lib.lib()
         n = len(items)
         H, W = int(items[0][0].shape[0]), int(items[0][0].shape[1])
-        for image, mask, _ in items:
+        for image, _mask, _ in items:
             _lib.require_gpu(image, "image")
-            assert image.dim() == 3 and image.shape[2] == 3 and image.is_contiguous()
-            assert image.dtype in (torch.float32, torch.uint8)
-            assert (int(image.shape[0]), int(image.shape[1])) == (H, W), "a batch holds images of one size"
-            if mask is not None:
-                assert mask.dtype == torch.uint8 and mask.shape == (H, W) and mask.is_contiguous()
-        need = int(L.pxt_unet_workspace_bytes_batch(self._ctx, n, H, W))
+        need = int(_lib.lib().pxt_unet_workspace_bytes_batch(self._ctx, n, H, W))
         if need <= 0:
             raise _lib.PxtError(f"image {H}x{W} (batch {n}) is not supported by the 4-level encoder")
         if self._ws is None or self._ws.numel() < need:
@@ -281,17 +276,8 @@ class UNet:
         shapes = self.level_shapes(H, W)
         outs = [[torch.empty(h, w, cstride_for(c), device=self.device, dtype=torch.float32)
                  for (h, w), c in zip(shapes, OUTPUT_DIMS)] for _ in range(n)]
-        images = (C.c_void_p * n)(*[it[0].data_ptr() for it in items])
-        is_u8 = (C.c_int32 * n)(*[int(it[0].dtype == torch.uint8) for it in items])
-        masks = (C.c_void_p * n)(*[_lib.dptr(it[1]) for it in items])
-        norm = (C.c_int32 * n)(*[int(bool(it[2])) for it in items])
-        ptrs = (C.c_void_p * (3 * n))(*[o.data_ptr() for per in outs for o in per])
-        cs = (C.c_int32 * 3)(*[o.shape[2] for o in outs[0]])
-        _lib.check(
-            L.pxt_unet_forward_batch(self._ctx, n, images, is_u8, masks, H, W, ptrs, cs, norm,
-                                     self._ws.data_ptr(), _lib.stream_ptr(self.device)),
-            "pxt_unet_forward_batch",
-        )
+        ops.unet_forward_batch(int(self._ctx.value), [it[0] for it in items], [it[1] for it in items],
+                               [bool(it[2]) for it in items], [o for per in outs for o in per], self._ws)
         return outs
 
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, List[torch.Tensor]]:

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from ..ops import ops
 
 
 def get_nerf_image_device(testbed, nerf_pose, camera, depth: bool = False, alpha_thresh: float = 0.0,
@@ -36,8 +37,7 @@ def rgba_to_u8(rgba: torch.Tensor, alpha_thresh: float = 0.0) -> torch.Tensor:
     """``nerf_img[alpha < thresh] = 0; (nerf_img[:, :, :3] * 255).astype(uint8)`` on the device."""
     H, W = int(rgba.shape[0]), int(rgba.shape[1])
     out = torch.empty(H, W, 3, dtype=torch.uint8, device=rgba.device)
-    _lib.check(_lib.lib().pxt_rgba_to_u8(rgba.data_ptr(), H, W, float(alpha_thresh), out.data_ptr(),
-                                         _lib.stream_ptr(rgba.device)), "pxt_rgba_to_u8")
+    ops.rgba_to_u8(rgba, float(alpha_thresh), out)
     return out
 
 

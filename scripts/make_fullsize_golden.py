@@ -1,0 +1,100 @@
+"""Generates tests/golden/fullsize_640x480.npz: one STEADY-STATE tracked frame and one COLD-START
+frame of BASELINE configs[1] (640x480, spp 8) computed entirely by the CPU oracle
+(oracle/frame_oracle.py, oracle/ngp_oracle.py).  CPU only, a few minutes per render; the `-m gpu`
+tests (tests/test_fullsize_golden_gpu.py) compare the HIP path with these vectors on identical inputs.
+
+    python scripts/make_fullsize_golden.py            # writes the .npz (takes ~10-20 min on 8 cores)
+
+Everything is seeded: assets = make_tracking_assets(seed=1002), the query frames are ORACLE renders
+at the ground-truth poses (+ numpy default_rng noise, rounded to 8-bit levels), the start pose of the
+steady frame is the GT pose of frame 0 moved by a fixed small twist.  The fixture stores inputs
+(query frames as uint8, start poses, reference id) and expected outputs (final poses, costs, sample
+counts, mask bits, RGBA / depth renders as fp16).
+"""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+
+from oracle import frame_oracle as FO
+from oracle import ngp_oracle as NO
+from pixtrack_amd.synthetic import make_tracking_assets, perturb_pose
+
+OUT = ROOT / "tests" / "golden" / "fullsize_640x480.npz"
+SEED, W, H, SPP = 1002, 640, 480, 8
+
+
+def oracle_query(assets, ngp, R, t, sigma, rng):
+    qcam = FO.colmap_camera_to_pix(assets["query_camera"])
+    rgba, st = NO.render(ngp, FO.nerf_view(assets["snapshot"], assets["nerf2sfm"], assets["aabb"], R, t, qcam, 0, SPP),
+                         return_stats=True)
+    u8 = FO.to_u8(rgba).astype(np.float32)
+    img = np.clip(np.rint(u8 + rng.normal(size=u8.shape) * sigma), 0, 255).astype(np.uint8)
+    return img, st
+
+
+def main():
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    t_all = time.time()
+    assets = make_tracking_assets(seed=SEED, width=W, height=H, n_frames=3)
+    ngp = FO.ngp_model(assets["snapshot"])
+    rng = np.random.default_rng(SEED + 77)
+    gt = assets["gt_poses"]
+    out = {"seed": SEED, "width": W, "height": H, "spp": SPP}
+
+    # ---- cold start: frame 0 from the upright reference pose, scales [4, 1], no mask
+    t0 = time.time()
+    q0, st_q0 = oracle_query(assets, ngp, gt[0][0], gt[0][1], 12.0, rng)
+    print("query 0 rendered", round(time.time() - t0, 1), "s", st_q0, flush=True)
+    ref = assets["model3d"].dbs[1]
+    keep = {}
+    tm = {}
+    cold = FO.track_frame(assets, ref.qvec2rotmat(), ref.tvec, q0.astype(np.float32), 1, multiscale=(4, 1),
+                          use_mask=False, spp=SPP, keep=keep, timings=tm)
+    print("cold start", cold["success"], cold["cost"], cold["iters"], {k: round(v, 1) for k, v in tm.items()}, flush=True)
+    assert cold["success"]
+    out.update(cold_query=q0, cold_R0=ref.qvec2rotmat(), cold_t0=ref.tvec, cold_ref_id=1,
+               cold_R=cold["R"].numpy(), cold_t=cold["t"].numpy(), cold_cost=cold["cost"],
+               cold_iters=np.array(cold["iters"]), cold_ref_rgba=keep["ref_rgba"].astype(np.float16))
+
+    # ---- steady state: frame 1 from (GT pose of frame 0 + a fixed small twist), scale [1], masked
+    prng = np.random.default_rng(SEED + 78)
+    R0, t0_ = perturb_pose(gt[0][0], gt[0][1], prng, 0.15, 0.001, assets["center"])
+    t0 = time.time()
+    q1, st_q1 = oracle_query(assets, ngp, gt[1][0], gt[1][1], 2.0, rng)
+    print("query 1 rendered", round(time.time() - t0, 1), "s", st_q1, flush=True)
+    keep, tm = {}, {}
+    # the renders are repeated with stats to pin the sample sets
+    qcam = FO.colmap_camera_to_pix(assets["query_camera"])
+    steady = FO.track_frame(assets, R0, t0_, q1.astype(np.float32), 1, multiscale=(1,), use_mask=True, spp=SPP,
+                            keep=keep, timings=tm)
+    print("steady", steady["success"], steady["cost"], steady["iters"], {k: round(v, 1) for k, v in tm.items()}, flush=True)
+    assert steady["success"]
+    _, st_d = NO.render(ngp, FO.nerf_view(assets["snapshot"], assets["nerf2sfm"], assets["aabb"], R0, t0_, qcam, 1, 1),
+                        return_stats=True)  # spp 1: cheap; the sample set of pass 0 only
+    depth = keep["depth_rgba"]
+    # pixels whose `uint8(depth * 255) != 0` decision (run_vis_on_poses.py:53-54, wraps mod 256) sits
+    # within 0.05 grey levels of flipping: the only places where fp32 summation order may change a bit
+    m = np.mod(depth[..., 0].astype(np.float64) * 255.0, 256.0)
+    fragile = (m < 0.05) | (m > 255.95) | (np.abs(m - 1.0) < 0.05)
+    out.update(query=q1, R0=R0, t0=t0_, ref_id=1, R=steady["R"].numpy(), t=steady["t"].numpy(),
+               cost=steady["cost"], iters=np.array(steady["iters"]), n_points=steady["n_points"],
+               mask_bits=np.packbits(steady["mask"].astype(np.uint8)), mask_sum=int(steady["mask"].sum()),
+               ref_rgba=keep["ref_rgba"].astype(np.float16), depth=depth[..., 0].astype(np.float16),
+               depth_alpha=depth[..., 3].astype(np.float16),
+               depth_u8_nonzero_bits=np.packbits((FO.to_u8(depth)[..., 0] != 0).astype(np.uint8)),
+               depth_fragile_bits=np.packbits(fragile.astype(np.uint8)), depth_fragile_count=int(fragile.sum()),
+               spp1_samples=st_d["samples"], spp1_rays_hit=st_d["rays_hit"],
+               query_samples=st_q1["samples"], query_rays_hit=st_q1["rays_hit"],
+               gt_R=np.stack([g[0] for g in gt]), gt_t=np.stack([g[1] for g in gt]))
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, round(OUT.stat().st_size / 1e6, 2), "MB; total", round(time.time() - t_all, 1), "s")
+
+
+if __name__ == "__main__":
+    main()
