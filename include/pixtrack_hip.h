@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (4), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (5), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -177,6 +177,21 @@ int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* i
  * (Cout % 32 == 0), bias [Cout] float32, out [H][W][Cout] fp16; fused bias (+ReLU). */
 int pxt_conv3x3_nhwc_f16(const void* in, int32_t H, int32_t W, int32_t Cin, const void* weights,
                          const float* bias, int32_t Cout, int32_t relu, void* out, void* stream);
+
+/* The same layer with the taps already in the kernel's MFMA-fragment order (what pxt_unet_create
+ * prepares once for every layer of the pyramid), for profiling the convolution alone and for
+ * choosing tile configurations:
+ *   pxt_conv3x3_packed_bytes   bytes of the packed taps (= Cout*9*Cin*2), < 0 on bad dims
+ *   pxt_conv3x3_pack_weights   [Cout][3][3][Cin] fp16 (device) -> packed (device)
+ *   pxt_conv3x3_packed         in / out as above; pool_out (optional) [H/2][W/2][Cout] receives the
+ *                              2x2 max-pool of the output; cfg 0 = automatic, 1..6 = tile
+ *                              configuration (csrc/pxt_unet.hip kV2Cfgs); splits > 1 = split-K over
+ *                              the input-channel chunks with splitk_ws >= splits*H*W*Cout*4 bytes. */
+int64_t pxt_conv3x3_packed_bytes(int32_t Cin, int32_t Cout);
+int pxt_conv3x3_pack_weights(const void* weights, int32_t Cin, int32_t Cout, void* packed, void* stream);
+int pxt_conv3x3_packed(const void* in, int32_t H, int32_t W, int32_t Cin, const void* packed, const float* bias,
+                       int32_t Cout, int32_t relu, void* out, void* pool_out, int32_t cfg, int32_t splits,
+                       void* splitk_ws, int64_t splitk_ws_bytes, void* stream);
 
 /* -------------------------------------------------------------------------
  * instant-ngp style NeRF inference renderer.

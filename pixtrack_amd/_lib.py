@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class PxtError(RuntimeError):
@@ -127,6 +127,9 @@ PROTOTYPES = {
          C.POINTER(_I32), _VP, _VP],
     ),
     "pxt_conv3x3_nhwc_f16": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _I32, _I32, _VP, _VP]),
+    "pxt_conv3x3_packed_bytes": (_I64, [_I32, _I32]),
+    "pxt_conv3x3_pack_weights": (C.c_int, [_VP, _I32, _I32, _VP, _VP]),
+    "pxt_conv3x3_packed": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _I32, _I32, _VP, _I64, _VP]),
     "pxt_ngp_create": (C.c_int, [C.POINTER(NgpModel), _VP, _I64, _VP, _I64, _VP, _I64, C.POINTER(_VP)]),
     "pxt_ngp_destroy": (C.c_int, [_VP]),
     "pxt_ngp_render": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP]),

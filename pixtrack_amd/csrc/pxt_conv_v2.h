@@ -1,0 +1,394 @@
+// 3x3 convolution (pad 1), NHWC fp16 -> NHWC fp16, MFMA implicit GEMM -- second generation.
+// Included by pxt_unet.hip (needs half_t / half8 / half4 / f32x16 / UpSrc from there).
+//
+// What changed against the first kernel (measured there: the matrix pipe waited on the
+// global -> VGPR -> LDS staging of halo AND filter taps, two barriers per 32-channel chunk):
+//  * the filter taps never touch LDS.  They are pre-packed once (pxt_unet_create /
+//    pxt_conv3x3_pack_weights) in MFMA A-fragment order [chunk][tap][k-step][cout block][lane][8],
+//    so a wave fetches the fragment of one (tap, k-step) as ONE fully coalesced 1-KiB load straight
+//    into the operand registers, one step ahead of its use (they are L2 hits: every workgroup of a
+//    layer reads the same few hundred KiB);
+//  * LDS holds only the input halo, double buffered: the next chunk's halo is fetched at the start
+//    of a chunk and written into the other buffer in the middle of it -> ONE barrier per chunk;
+//  * halo pixels are 64-B records with the 16-B segment index XOR-swizzled by (column >> 2) & 3 on
+//    a row pitch that is a multiple of 256 B: each 16-lane group of a ds_read_b128 fragment read
+//    (16 consecutive columns) hits 16 distinct slots -> conflict free without padding;
+//  * a wave owns CW x PBW MFMA tiles (up to 64 output channels x 128 pixels): one A fragment feeds
+//    PBW MFMAs and one B fragment CW of them, which halves LDS and L1 traffic per MFMA;
+//  * the epilogue pairs half-waves with v_permlane32_swap so every lane stores 16 contiguous bytes,
+//    and can write the 2x2 max-pooled copy of its tile (the encoder's next input) as well.
+#pragma once
+
+#include <type_traits>
+
+namespace pxt {
+
+constexpr int kV2RowBytes = 1280;  // LDS pitch of a halo row: 20 pixel records (18 used) = 5 x 256 B
+constexpr int kV2Cols = 18;        // tile width 16 + 2
+
+struct ConvArgs {
+  const half_t* in;      // [n_img][H][W][Cin]  (UPCAT: the skip tensor [n_img][Hs][Ws][Cin - Cp])
+  int H, W, Cin;
+  const half_t* wpk;     // packed taps, see pack_conv_weights()
+  const float* bias;
+  int Cout, relu;
+  half_t* out;           // [n_img][H][W][Cout]
+  float* partial;        // split-K slabs [z][n_img][H][W][Cout] (gridDim.z > 1)
+  UpSrc up;
+  half_t* pool;          // optional [n_img][H/2][W/2][Cout]: 2x2 max-pool of `out` (gridDim.z == 1 only)
+};
+
+// Host-side mirror of the packed layout: element (cout, tap, cin) lives at
+//   ((((cin / 32) * 9 + tap) * 2 + s) * (Cout / 32) + cout / 32) * 512 + lane * 8 + j
+// with k = cin % 32, s = k / 16, lane = (cout % 32) + 32 * ((k % 16) / 8), j = k % 8.
+__host__ __device__ inline size_t packed_weight_index(int cout, int tap, int cin, int Cout) {
+  const int k = cin & 31, s = k >> 4, lane = (cout & 31) + 32 * ((k & 15) >> 3), j = k & 7;
+  return ((((size_t)(cin >> 5) * 9 + tap) * 2 + s) * (size_t)(Cout >> 5) + (cout >> 5)) * 512 + lane * 8 + j;
+}
+
+__global__ void pack_conv_weights_kernel(const half_t* __restrict__ w /* [Cout][9][Cin] */, int Cin, int Cout,
+                                         half_t* __restrict__ packed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Cout * 9 * Cin) return;
+  const int cin = (int)(i % Cin);
+  const int tap = (int)((i / Cin) % 9);
+  const int cout = (int)(i / ((long long)Cin * 9));
+  packed[packed_weight_index(cout, tap, cin, Cout)] = w[i];
+}
+
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+
+// Returns x through an empty asm: the compiler can no longer prove the value loop-invariant, so the
+// LDS address arithmetic derived from it is recomputed where it is used (a few VALU ops per chunk)
+// instead of being hoisted out of the chunk loop into ~30 long-lived registers.
+// Compile-time loop: the 18 (tap, k-step) steps of a chunk MUST be straight-line code (the register
+// rings are indexed by the step); `#pragma unroll` silently gave up on the largest variant.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ inline int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// 2x2 max over (row pair = lanes l, l ^ 16) x (column pair = lanes l, l ^ 1) of two packed fp16 pairs,
+// without touching LDS: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even
+// rows of another (a register swapped with its own copy leaves both row partners side by side), the
+// column partner comes through a DPP quad permutation.
+__device__ inline unsigned pool2x2_pk(unsigned v) {
+  auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  half2v a = __builtin_bit_cast(half2v, (unsigned)sw[0]), b = __builtin_bit_cast(half2v, (unsigned)sw[1]);
+  half2v m = __builtin_elementwise_max(a, b);
+  const unsigned mu = __builtin_bit_cast(unsigned, m);
+  const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)mu, (int)mu, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+  m = __builtin_elementwise_max(m, __builtin_bit_cast(half2v, nb));
+  return __builtin_bit_cast(unsigned, m);
+}
+
+// (launch bounds: the UPCAT variants ask for ONE wave per SIMD only so that the register allocator
+// does not spill -- with the 256-register cap it schedules itself into 51 spills, uncapped it needs
+// 228 registers, which still runs two waves per SIMD.)
+template <int CW, int PBW, int WC, int WP, bool UPCAT>
+__global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(const ConvArgs a) {
+  static_assert(WC * WP == 4, "four waves per workgroup");
+  constexpr int TH = 2 * PBW * WP, HR = TH + 2;
+  constexpr int BNC = 32 * CW * WC;
+  constexpr int kElems = HR * kV2Cols * 4;      // 16-B pieces of one halo chunk
+  constexpr int KH = (kElems + 255) / 256;      // pieces per thread
+  constexpr int NB = 2;                         // staged in two batches to bound the live registers
+  constexpr int KB = (KH + NB - 1) / NB;
+  constexpr int kBuf = HR * kV2RowBytes;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int tiles_x = (W + 15) >> 4;
+  const int tiles_per = tiles_x * ((H + TH - 1) / TH);
+  const int img = blockIdx.x / tiles_per, tile = blockIdx.x % tiles_per;
+  const int n_img = gridDim.x / tiles_per;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * 16;
+  const int co0 = blockIdx.y * BNC;
+  const int Cs = UPCAT ? Cin - a.up.Cp : Cin;
+  const int in_w = UPCAT ? a.up.Ws : W;
+  const half_t* in = a.in + (size_t)img * (UPCAT ? a.up.Hs : H) * in_w * Cs;
+  const half_t* prev = UPCAT ? a.up.prev + (size_t)img * a.up.Hp * a.up.Wp * a.up.Cp : nullptr;
+
+  f32x16 acc[CW][PBW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c)
+#pragma unroll
+    for (int p = 0; p < PBW; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
+
+  const int r31 = lane & 31, khalf = lane >> 5;
+  // B-fragment read offsets of this lane for the 3 horizontal taps x 2 k-steps; the vertical tap
+  // and the pixel block are immediates ((2 * pb + ky) rows).
+  int boff[3][2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int col = (r31 & 15) + kx;
+      boff[kx][s] = (2 * PBW * wp + (r31 >> 4)) * kV2RowBytes + col * 64 + (((2 * s + khalf) ^ ((col >> 2) & 3)) << 4);
+    }
+
+  // K range of this workgroup (split-K over gridDim.z)
+  const int n_chunks = Cin >> 5;
+  const int per_z = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int ch_begin = (int)blockIdx.z * per_z, ch_end = min(n_chunks, ch_begin + per_z);
+
+  // A fragments: packed [chunk][tap][s][cout block][lane][8]; this wave's CW blocks are adjacent
+  const size_t a_step = (size_t)(Cout >> 5) * 512;  // halves between consecutive (tap, s) steps
+  const half_t* aptr = a.wpk + ((size_t)ch_begin * 18) * a_step + (size_t)((co0 >> 5) + CW * wc) * 512 + lane * 8;
+
+  // ---- halo staging -------------------------------------------------------------------------
+  // Every staging load is UNCONDITIONAL (bounds-checked buffer loads that return zeros outside the
+  // image, clamped coordinates for the low-resolution patch): a load behind a lane-divergent branch
+  // makes hipcc's vmcnt bookkeeping conservative, and the filter-fragment waits then drain the halo
+  // loads right after they were issued.
+  half8 r_in[KB];
+  unsigned goff[KH];  // byte offset of this thread's pieces in `in` (2^31 = outside the image -> zeros)
+#pragma unroll
+  for (int k = 0; k < KH; ++k) {
+    const int i = tid + 256 * k;
+    const int pix = i >> 2, seg = i & 3;
+    const int gy = ty0 + pix / kV2Cols - 1, gx = tx0 + pix % kV2Cols - 1;
+    const bool ok = i < kElems && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    goff[k] = ok ? ((unsigned)(gy * in_w + gx) * (unsigned)Cs + (unsigned)(seg * 8)) * 2u : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)in, 0, (int)((size_t)(UPCAT ? a.up.Hs : H) * in_w * Cs * 2), 0x00020000);
+  const int cp0 = UPCAT ? a.up.Cp : 0;  // channels [0, cp0) of the conv input come from `prev`
+  auto halo_issue = [&](int c0, int batch) {
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const int k = batch * KB + kk;
+      if (k < KH)
+        r_in[kk] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 in_rsrc, (int)(goff[k] + (unsigned)((c0 - cp0) * 2)), 0, 0));
+    }
+  };
+  auto halo_write = [&](int buf, int batch) {
+    const int t_ = opaque(tid);
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      const int k = batch * KB + kk;
+      const int i = t_ + 256 * k;
+      const int pix = i >> 2, seg = i & 3;
+      const int hy = pix / kV2Cols, hx = pix % kV2Cols;
+      if (k < KH && i < kElems)
+        *(half8*)(smem + buf * kBuf + hy * kV2RowBytes + hx * 64 + ((seg ^ ((hx >> 2) & 3)) << 4)) = r_in[kk];
+    }
+  };
+
+  // UPCAT, channels below Cp: the low-resolution patch under this tile's halo ((TH/2 + 2) x 10 pixels
+  // of `prev`, one chunk) is copied raw into LDS, then every thread forms its halo pieces from it with
+  // the bilinear x2 weights (exactly 0, 1/4, 3/4; align_corners = False) -- LDS latency instead of
+  // four dependent global loads per piece, and each low-resolution pixel is fetched once.
+  constexpr int PH = TH / 2 + 2, PW = 10;
+  constexpr int kPatchElems = PH * PW * 4, KP = (kPatchElems + 255) / 256;
+  static_assert(!UPCAT || KP <= KB, "the patch pieces reuse the halo staging registers");
+  char* const patch = smem + 2 * kBuf;
+  unsigned poff[UPCAT ? KP : 1], up_src[UPCAT ? KH : 1];
+  if (UPCAT) {
+    const int py0 = (ty0 >> 1) - 1, px0 = (tx0 >> 1) - 1;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const int i = min(tid + 256 * kp, kPatchElems - 1);
+      const int pp = i >> 2, seg = i & 3;
+      const int sy = min(max(py0 + pp / PW, 0), a.up.Hp - 1), sx = min(max(px0 + pp % PW, 0), a.up.Wp - 1);
+      poff[kp] = (unsigned)(sy * a.up.Wp + sx) * (unsigned)a.up.Cp + (unsigned)(seg * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int i = tid + 256 * k;
+      const int pix = i >> 2, seg = i & 3;
+      const int gy = ty0 + pix / kV2Cols - 1, gx = tx0 + pix % kV2Cols - 1;
+      const bool ok = i < kElems && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float sy = fmaxf(((float)gy + 0.5f) * 0.5f - 0.5f, 0.f);
+      const float sx = fmaxf(((float)gx + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int y0 = min((int)sy, a.up.Hp - 1), x0 = min((int)sx, a.up.Wp - 1);
+      const int y1 = min(y0 + 1, a.up.Hp - 1), x1 = min(x0 + 1, a.up.Wp - 1);
+      const float ay = sy - (float)y0, ax = sx - (float)x0;  // exactly 0, 0.25 or 0.75 inside the image
+      const int pidx = ok ? (y0 - py0) * PW + (x0 - px0) : 0;
+      up_src[k] = ((unsigned)(pidx * 64 + seg * 16) << 8) | (ok ? 64u : 0u) | (x1 != x0 ? 1u : 0u) | (y1 != y0 ? 2u : 0u) |
+                  (ax == 0.25f ? 4u : ax == 0.75f ? 8u : 0u) | (ay == 0.25f ? 16u : ay == 0.75f ? 32u : 0u);
+    }
+  }
+  auto patch_issue = [&](int c0) {
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) r_in[kp] = *(const half8*)(prev + (poff[UPCAT ? kp : 0] + (unsigned)c0));
+  };
+  auto patch_write = [&]() {
+    const int t_ = opaque(tid);
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const int i = t_ + 256 * kp;
+      if (i < kPatchElems) *(half8*)(patch + i * 16) = r_in[kp];
+    }
+  };
+  auto patch_interp = [&](int buf) {
+    const int t_ = opaque(tid);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int i = t_ + 256 * k;
+      const int pix = i >> 2, seg = i & 3;
+      const int hy = pix / kV2Cols, hx = pix % kV2Cols;
+      const unsigned f = up_src[UPCAT ? k : 0];
+      const char* src = patch + (f >> 8);
+      const int dx = (f & 1u) ? 64 : 0, dy = (f & 2u) ? PW * 64 : 0;
+      const float ax = (f & 4u) ? 0.25f : (f & 8u) ? 0.75f : 0.f;
+      const float ay = (f & 16u) ? 0.25f : (f & 32u) ? 0.75f : 0.f;
+      const half8 p00 = *(const half8*)(src), p01 = *(const half8*)(src + dx);
+      const half8 p10 = *(const half8*)(src + dy), p11 = *(const half8*)(src + dy + dx);
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float top = (float)p00[j] * (1.f - ax) + (float)p01[j] * ax;
+        const float bot = (float)p10[j] * (1.f - ax) + (float)p11[j] * ax;
+        v[j] = (f & 64u) ? (half_t)(top * (1.f - ay) + bot * ay) : (half_t)0.f;
+      }
+      if (i < kElems)
+        *(half8*)(smem + buf * kBuf + hy * kV2RowBytes + hx * 64 + ((seg ^ ((hx >> 2) & 3)) << 4)) = v;
+      __builtin_amdgcn_sched_barrier(0);  // one piece's four taps live at a time (register budget)
+    }
+  };
+
+  if (ch_begin < ch_end) {  // first chunk: staged synchronously
+    if (UPCAT && ch_begin * 32 < cp0) {
+      patch_issue(ch_begin * 32);
+      patch_write();
+      __syncthreads();
+      patch_interp(0);
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        halo_issue(ch_begin * 32, b);
+        halo_write(0, b);
+      }
+    }
+  }
+
+  // Explicit software pipeline: filter fragments travel AR - 1 steps ahead of their use (an L2 hit
+  // is ~300-500 cycles under load, one step only 4-8 MFMAs), pixel fragments one step ahead (LDS).
+  // The rings are indexed with compile-time constants (18 steps per chunk, 18 % AR == 0).
+  constexpr int AR = 3;
+  half8 a_q[AR][CW], b_q[2][PBW];
+  const int n_steps = (ch_end - ch_begin) * 18;
+  if (n_steps > 0) {
+#pragma unroll
+    for (int d = 0; d < AR - 1; ++d)  // (a K range holds >= 18 steps)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) a_q[d][c] = *(const half8*)(aptr + (size_t)d * a_step + c * 512);
+  }
+  // address of the fragment AR - 1 steps ahead, clamped to the last one of this K range so that the
+  // prefetch needs no branch at the end
+  const half_t* const a_last = aptr + (size_t)max(n_steps - 1, 0) * a_step;
+  aptr += (size_t)(AR - 1) * a_step;
+
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const bool more = ch + 1 < ch_end;
+    const char* sbuf = smem + ((ch - ch_begin) & 1) * kBuf;
+    const int nbuf = ((ch - ch_begin) & 1) ^ 1;
+    __syncthreads();  // this chunk's halo is complete; everyone is done reading the other buffer
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) b_q[0][p] = *(const half8*)(sbuf + boff[0][0] + (2 * p) * kV2RowBytes);
+    static_for<0, 18>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      {
+        const half_t* ap = aptr < a_last ? aptr : a_last;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) a_q[(st + AR - 1) % AR][c] = *(const half8*)(ap + c * 512);
+      }
+      aptr += a_step;
+      if (more) {  // stage the next chunk's halo into the other buffer (workgroup-uniform branches)
+        const int c1 = (ch + 1) * 32;
+        if (UPCAT && c1 < cp0) {
+          if constexpr (st == 0) patch_issue(c1);
+          if constexpr (st == 5) { patch_write(); __syncthreads(); }
+          if constexpr (st == 7) patch_interp(nbuf);
+        } else {
+          if constexpr (st == 0) halo_issue(c1, 0);
+          if constexpr (st == 5) { halo_write(nbuf, 0); halo_issue(c1, 1); }
+          if constexpr (st == 11) halo_write(nbuf, 1);
+        }
+      }
+      if constexpr (st < 17) {
+        constexpr int tn = (st + 1) >> 1, sn = (st + 1) & 1;
+#pragma unroll
+        for (int p = 0; p < PBW; ++p)
+          b_q[(st + 1) & 1][p] = *(const half8*)(sbuf + boff[tn % 3][sn] + (2 * p + tn / 3) * kV2RowBytes);
+      }
+      // hipcc's scheduler otherwise sinks the prefetch loads down to their first use (shorter live
+      // ranges), which is exactly the latency this pipeline exists to hide: pin them above the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < PBW; ++p)
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_q[st % AR][c], b_q[st & 1][p], acc[c][p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+
+  // ---- epilogue: D[row = cout][col = pixel]; lane: col = lane & 31, rows (r&3) + 8*(r>>2) + 4*khalf
+  const int cw0 = co0 + 32 * CW * wc;
+  half_t* out = a.out + (size_t)img * H * W * Cout;
+#pragma unroll
+  for (int p = 0; p < PBW; ++p) {
+    const int gy = ty0 + 2 * PBW * wp + 2 * p + (r31 >> 4), gx = tx0 + (r31 & 15);
+    const bool inside = gy < H && gx < W;
+    if (gridDim.z > 1) {
+      if (!inside) continue;
+      float* pd = a.partial + ((((size_t)blockIdx.z * n_img + img) * H + gy) * W + gx) * Cout + cw0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(pd + 32 * c + 8 * g + 4 * khalf) =
+              make_float4(acc[c][p][4 * g + 0], acc[c][p][4 * g + 1], acc[c][p][4 * g + 2], acc[c][p][4 * g + 3]);
+      continue;
+    }
+    half_t* dst = out + ((size_t)gy * W + gx) * Cout + cw0;
+    half_t* pdst = nullptr;
+    const bool pool_lane = a.pool && (r31 & 17) == 0 && (gy >> 1) < (H >> 1) && (gx >> 1) < (W >> 1);
+    if (a.pool)
+      pdst = a.pool + (((size_t)img * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * Cout + cw0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        unsigned lo[2], hi[2];  // packed fp16 pairs of row groups g and g + 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 bv = *(const float4*)(a.bias + cw0 + 32 * c + 8 * (g + h) + 4 * khalf);
+          float v0 = acc[c][p][4 * (g + h) + 0] + bv.x, v1 = acc[c][p][4 * (g + h) + 1] + bv.y;
+          float v2 = acc[c][p][4 * (g + h) + 2] + bv.z, v3 = acc[c][p][4 * (g + h) + 3] + bv.w;
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          half4 o;
+          o[0] = (half_t)v0; o[1] = (half_t)v1; o[2] = (half_t)v2; o[3] = (half_t)v3;
+          if (a.pool) {  // wave-uniform branch
+            const uint2 m = make_uint2(pool2x2_pk(((const unsigned*)&o)[0]), pool2x2_pk(((const unsigned*)&o)[1]));
+            if (pool_lane) *(uint2*)(pdst + 32 * c + 8 * (g + h) + 4 * khalf) = m;
+          }
+          (h == 0 ? lo : hi)[0] = ((const unsigned*)&o)[0];
+          (h == 0 ? lo : hi)[1] = ((const unsigned*)&o)[1];
+        }
+        // lanes 0-31 (khalf 0) end up with channels 8g .. 8g+7, lanes 32-63 with 8(g+1) .. 8(g+1)+7
+        auto s0 = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
+        if (inside) *(uint4*)(dst + 32 * c + 8 * (g + khalf)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+  }
+}
+
+}  // namespace pxt

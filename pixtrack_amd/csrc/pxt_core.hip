@@ -11,7 +11,7 @@ void set_last_error(const char* what, hipError_t e) {
 }
 }  // namespace pxt
 
-extern "C" int pxt_version(void) { return 4; }
+extern "C" int pxt_version(void) { return 5; }
 extern "C" const char* pxt_last_error(void) { return pxt::g_last_error; }
 extern "C" int pxt_device_cus(int* n_cus) {
   if (!n_cus) return PXT_E_ARG;

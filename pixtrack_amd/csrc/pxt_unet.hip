@@ -10,10 +10,10 @@
 // The 3x3 convolutions are implicit GEMMs on v_mfma_f32_32x32x16_f16 with fp32
 // accumulation: rows = output channels (A operand = filter taps), columns = pixels
 // (B operand = the shifted input window), K = 9 * Cin walked as (Cin chunk of 32) x
-// (9 taps) x (2 k-steps of 16).  A workgroup owns a 16x16 pixel tile and 32*NT output
-// channels; the 18x18 halo of the current Cin chunk and the 9 filter taps of that
-// chunk are staged in LDS once and reused by all taps / all four waves.  Bias (or the
-// folded BatchNorm affine) and ReLU are fused into the epilogue.
+// (9 taps) x (2 k-steps of 16).  The kernel is in pxt_conv_v2.h: the input halo of a chunk is
+// double-buffered in LDS, the filter taps arrive pre-packed in fragment order straight from L2.
+// Bias (or the folded BatchNorm affine), ReLU and the encoder's 2x2 max-pool are fused into the
+// epilogue.
 #include "pxt_common.h"
 
 #include <algorithm>
@@ -102,19 +102,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// 3x3 convolution, pad 1, NHWC fp16 -> NHWC fp16, MFMA implicit GEMM.
+// 3x3 convolution, pad 1, NHWC fp16 -> NHWC fp16, MFMA implicit GEMM: pxt_conv_v2.h.
 // ---------------------------------------------------------------------------
-constexpr int kTH = 16, kTW = 16;        // output pixels per workgroup
-constexpr int kCK = 32;                  // input channels per staged chunk
-constexpr int kPix = 40;                 // padded halves per LDS pixel/filter row (80 B)
-constexpr int kHalo = (kTH + 2) * (kTW + 2);
-// LDS pitch of one halo row in halves: 768 (1536 B = 0 mod 256 B).  With the natural pitch
-// (18 px * 80 B = 1440 B) the two image rows a 16-lane ds_read_b128 group touches collide on
-// two 16-B slots (SQ_LDS_BANK_CONFLICT was 39 % of the LDS cycles); 1536 B makes them disjoint.
-constexpr int kRowPitch = 768;
-constexpr int kInHalves = (kTH + 2) * kRowPitch;
-constexpr int kHaloLoads = (kHalo * 4 + 255) / 256;  // 16-B staging loads per thread: halo
-
 // Decoder input cat([bilinear x2 upsample(prev) (align_corners=False), skip[:2Hp, :2Wp]]) formed
 // while staging (UPCAT): channels [0, Cp) of the conv input are interpolated from `prev`
 // [Hp][Wp][Cp], the rest come from `in` = skip [Hs][Ws][Cin - Cp].  Same fp32 lerp and fp16
@@ -124,214 +113,9 @@ struct UpSrc {
   int Hp, Wp, Cp, Hs, Ws;
 };
 
-template <int NT, bool UPCAT>  // output channels per workgroup = 32 * NT
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const half_t* __restrict__ in, int H,
-                                                           int W, int Cin,
-                                                           const half_t* __restrict__ wts,
-                                                           const float* __restrict__ bias,
-                                                           int Cout, int relu,
-                                                           half_t* __restrict__ out,
-                                                           float* __restrict__ partial, UpSrc up) {
-  // gridDim.z > 1: split-K over the Cin chunks; every z-slice writes its fp32 partial sums to
-  // partial[z][pixel][cout] and splitk_reduce_kernel finishes (fixed order: deterministic).
-  constexpr int BNC = 32 * NT;
-  extern __shared__ __attribute__((aligned(16))) half_t smem[];
-  half_t* s_in = smem;                  // [18 rows][kRowPitch], 18 pixels x kPix used per row
-  half_t* s_w = smem + kInHalves;       // [9][BNC][kPix]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  // blockIdx.x = image * tiles_per_image + tile: a batch is just more tiles (same weights, the
-  // halo is clipped per image)
-  const int tiles_x = (W + kTW - 1) / kTW;
-  const int tiles_per = tiles_x * ((H + kTH - 1) / kTH);
-  const int img = blockIdx.x / tiles_per, tile = blockIdx.x % tiles_per;
-  const int n_img = gridDim.x / tiles_per;
-  const int ty0 = (tile / tiles_x) * kTH, tx0 = (tile % tiles_x) * kTW;
-  const int co0 = blockIdx.y * BNC;
-  const int Cs = UPCAT ? Cin - up.Cp : Cin;       // channels held by `in`
-  const int in_w = UPCAT ? up.Ws : W;              // its row pitch in pixels
-  in += (size_t)img * (UPCAT ? up.Hs : H) * in_w * Cs;
-  const half_t* prev = UPCAT ? up.prev + (size_t)img * up.Hp * up.Wp * up.Cp : nullptr;
-  out += (size_t)img * H * W * Cout;
-
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int c = 0; c < NT; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][c][r] = 0.f;
-
-  // this lane's two pixels (one per 32-wide MFMA column block) inside the tile
-  const int r31 = lane & 31, khalf = lane >> 5;
-  int p_off[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int ty = 4 * wave + 2 * p + (r31 >> 4), tx = r31 & 15;
-    p_off[p] = ty * kRowPitch + tx * kPix + 8 * khalf;
-  }
-  const int w_off = r31 * kPix + 8 * khalf;
-
-  const int n_chunks = Cin / kCK;
-  const int per_z = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
-  const int c_begin = (int)blockIdx.z * per_z * kCK, c_end = min(Cin, c_begin + per_z * kCK);
-  // Software pipeline (global -> registers -> LDS): the loads of chunk c+1 are issued right
-  // after chunk c has been written to LDS and stay in flight under chunk c's 72 MFMAs.
-  constexpr int kWTotal = 9 * BNC * 4;
-  constexpr int kWLoads = (kWTotal + 255) / 256;
-  half8 r_in[kHaloLoads], r_w[kWLoads];
-  // Offsets are 32-bit element indices from wave-uniform bases (saddr loads): every map of the
-  // pyramid has < 2^31 elements per image.
-  // UPCAT: per staged halo element, the bilinear footprint is chunk-invariant.  It is kept as ONE
-  // offset + ONE flag word (x/y neighbour present, the weights are exactly 0, 1/4 or 3/4) so that
-  // the loop-invariant state costs 12 VGPRs rather than 36 (which would cost the second wave).
-  unsigned up_off[UPCAT ? kHaloLoads : 1], up_flg[UPCAT ? kHaloLoads : 1];
-  if (UPCAT) {
-#pragma unroll
-    for (int k = 0; k < kHaloLoads; ++k) {
-      const int i = tid + 256 * k;
-      const int pix = i >> 2, seg = i & 3;
-      const int hy = pix / (kTW + 2), hx = pix % (kTW + 2);
-      const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-      const bool ok = i < kHalo * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const float sy = fmaxf(((float)gy + 0.5f) * 0.5f - 0.5f, 0.f);
-      const float sx = fmaxf(((float)gx + 0.5f) * 0.5f - 0.5f, 0.f);
-      const int y0 = (int)sy, x0 = (int)sx;
-      const int y1 = min(y0 + 1, up.Hp - 1), x1 = min(x0 + 1, up.Wp - 1);
-      const float ay = sy - (float)y0, ax = sx - (float)x0;  // exactly 0, 0.25 or 0.75
-      up_off[k] = ok ? (unsigned)(y0 * up.Wp + x0) * (unsigned)up.Cp + (unsigned)(seg * 8) : 0u;
-      up_flg[k] = (ok ? 64u : 0u) | (x1 != x0 ? 1u : 0u) | (y1 != y0 ? 2u : 0u) |
-                  (ax == 0.25f ? 4u : ax == 0.75f ? 8u : 0u) | (ay == 0.25f ? 16u : ay == 0.75f ? 32u : 0u);
-    }
-  }
-  auto prefetch = [&](int c0) {
-    if (UPCAT && c0 < up.Cp) {
-      const unsigned step_x = (unsigned)up.Cp, step_y = (unsigned)(up.Wp * up.Cp);
-#pragma unroll
-      for (int k = 0; k < kHaloLoads; ++k) {
-        half8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-        const unsigned f = up_flg[k];
-        if (f & 64u) {
-          const unsigned o00 = up_off[k] + (unsigned)c0;
-          const unsigned dx = (f & 1u) ? step_x : 0u, dy = (f & 2u) ? step_y : 0u;
-          const float ax = (f & 4u) ? 0.25f : (f & 8u) ? 0.75f : 0.f;
-          const float ay = (f & 16u) ? 0.25f : (f & 32u) ? 0.75f : 0.f;
-          const half8 a = *(const half8*)(prev + o00);
-          const half8 b = *(const half8*)(prev + (o00 + dx));
-          const half8 d = *(const half8*)(prev + (o00 + dy));
-          const half8 e = *(const half8*)(prev + (o00 + dy + dx));
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float top = (float)a[j] * (1.f - ax) + (float)b[j] * ax;
-            const float bot = (float)d[j] * (1.f - ax) + (float)e[j] * ax;
-            v[j] = (half_t)(top * (1.f - ay) + bot * ay);
-          }
-        }
-        r_in[k] = v;
-        // one element's taps (4 x 16 B) in flight at a time keeps the kernel within 256 VGPRs
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      const unsigned cc = (unsigned)(c0 - (UPCAT ? up.Cp : 0));
-#pragma unroll
-      for (int k = 0; k < kHaloLoads; ++k) {
-        const int i = tid + 256 * k;
-        const int pix = i >> 2, seg = i & 3;
-        const int hy = pix / (kTW + 2), hx = pix % (kTW + 2);
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        half8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-        if (i < kHalo * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-          v = *(const half8*)(in + ((unsigned)(gy * in_w + gx) * (unsigned)Cs + cc + (unsigned)(seg * 8)));
-        r_in[k] = v;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kWLoads; ++k) {
-      const int i = tid + 256 * k;
-      const int row = i >> 2, seg = i & 3;
-      const int t = row / BNC, n = row % BNC;
-      if (i < kWTotal) r_w[k] = *(const half8*)(wts + ((size_t)(co0 + n) * 9 + t) * Cin + c0 + seg * 8);
-    }
-  };
-  if (c_begin < c_end) prefetch(c_begin);
-  for (int c0 = c_begin; c0 < c_end; c0 += kCK) {
-    __syncthreads();  // every wave is done reading the previous chunk
-#pragma unroll
-    for (int k = 0; k < kHaloLoads; ++k) {
-      const int i = tid + 256 * k;
-      const int pix = i >> 2, seg = i & 3;
-      if (i < kHalo * 4)
-        *(half8*)(s_in + (pix / (kTW + 2)) * kRowPitch + (pix % (kTW + 2)) * kPix + seg * 8) = r_in[k];
-    }
-#pragma unroll
-    for (int k = 0; k < kWLoads; ++k) {
-      const int i = tid + 256 * k;
-      if (i < kWTotal) *(half8*)(s_w + (i >> 2) * kPix + (i & 3) * 8) = r_w[k];
-    }
-    __syncthreads();
-    if (c0 + kCK < c_end) prefetch(c0 + kCK);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int tap_in = (t / 3) * kRowPitch + (t % 3) * kPix;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        half8 b[2], a[NT];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) b[p] = *(const half8*)(s_in + p_off[p] + tap_in + 16 * s);
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-          a[c] = *(const half8*)(s_w + (t * BNC + 32 * c) * kPix + w_off + 16 * s);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int c = 0; c < NT; ++c)
-            acc[p][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], b[p], acc[p][c], 0, 0, 0);
-      }
-    }
-  }
-
-  // epilogue: D[row = cout][col = pixel]; lane holds col = lane&31,
-  // rows (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int ty = 4 * wave + 2 * p + (r31 >> 4), tx = r31 & 15;
-    const int gy = ty0 + ty, gx = tx0 + tx;
-    if (gy >= H || gx >= W) continue;
-    half_t* dst = out + ((size_t)gy * W + gx) * Cout + co0;
-    if (gridDim.z > 1) {
-      float* pd = partial + ((((size_t)blockIdx.z * n_img + img) * H + gy) * W + gx) * Cout + co0;
-#pragma unroll
-      for (int c = 0; c < NT; ++c)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int co = 32 * c + 8 * g + 4 * khalf;
-          *(float4*)(pd + co) = make_float4(acc[p][c][4 * g + 0], acc[p][c][4 * g + 1], acc[p][c][4 * g + 2],
-                                            acc[p][c][4 * g + 3]);
-        }
-      continue;
-    }
-#pragma unroll
-    for (int c = 0; c < NT; ++c)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = 32 * c + 8 * g + 4 * khalf;
-        const float4 bv = *(const float4*)(bias + co0 + co);
-        float v0 = acc[p][c][4 * g + 0] + bv.x, v1 = acc[p][c][4 * g + 1] + bv.y,
-              v2 = acc[p][c][4 * g + 2] + bv.z, v3 = acc[p][c][4 * g + 3] + bv.w;
-        if (relu) {
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        }
-        half4 o;
-        o[0] = (half_t)v0; o[1] = (half_t)v1; o[2] = (half_t)v2; o[3] = (half_t)v3;
-        *(half4*)(dst + co) = o;
-      }
-  }
-}
+}  // namespace pxt
+#include "pxt_conv_v2.h"
+namespace pxt {
 
 // Split-K epilogue: out = relu(sum_z partial[z] + bias) -> fp16, 4 channels per thread.
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int splits, long long n4, int Cout,
@@ -469,6 +253,8 @@ struct pxt_unet {
   const pxt::half_t* head_w[pxt::kNumHeads];
   const float* head_b[pxt::kNumHeads];
   void* dev_blob = nullptr;
+  void* dev_packed = nullptr;          // conv taps in MFMA A-fragment order (pxt_conv_v2.h)
+  const pxt::half_t* conv_packed[pxt::kNumConv];
   int64_t n_bytes = 0;
   hipStream_t side = nullptr;          // the coarse heads run here, beside the decoder
   hipEvent_t ev_enc4 = nullptr, ev_dec1 = nullptr, ev_side = nullptr;
@@ -480,21 +266,57 @@ using namespace pxt;
 
 namespace {
 
-// Split-K factor: small maps leave most of the 256 CUs idle with (tiles x Cout blocks)
-// workgroups, so the Cin chunks are spread over gridDim.z until ~2 workgroups per CU exist.
-int choose_splits(int tiles, int nblocks, int n_chunks) {
-  const int wgs = tiles * nblocks;
-  if (wgs >= 384) return 1;
-  int splits = (512 + wgs - 1) / wgs;
+// ---- launch plan of one 3x3 layer ------------------------------------------------------------
+// Tile configurations of conv3x3_v2_kernel<CW, PBW, WC, WP>: a workgroup (4 waves, WC x WP) covers
+// TH = 2*PBW*WP rows x 16 columns of pixels and BNC = 32*CW*WC output channels.
+struct V2Cfg { int CW, PBW, WC, WP; };
+constexpr V2Cfg kV2Cfgs[7] = {{0, 0, 0, 0},
+                              {2, 4, 2, 2},   // 1: 16x16 px x 128 ch  (wave: 64 ch x 128 px)
+                              {2, 2, 1, 4},   // 2: 16x16 px x  64 ch  (wave: 64 ch x  64 px)
+                              {2, 4, 1, 4},   // 3: 32x16 px x  64 ch  (measured slower everywhere: not instantiated)
+                              {2, 2, 2, 2},   // 4:  8x16 px x 128 ch
+                              {1, 4, 1, 4},   // 5: 32x16 px x  32 ch  (not instantiated)
+                              {1, 2, 1, 4}};  // 6: 16x16 px x  32 ch
+inline int cfg_th(int cfg) { return 2 * kV2Cfgs[cfg].PBW * kV2Cfgs[cfg].WP; }
+inline int cfg_bnc(int cfg) { return 32 * kV2Cfgs[cfg].CW * kV2Cfgs[cfg].WC; }
+
+struct ConvPlan { int cfg, tiles, nb, splits; };
+
+// Split-K factor: only the smallest maps (conv5: 12 tiles per image pair) leave most of the 256 CUs
+// without a workgroup; measured on the 60x80 layers (160 workgroups) every split loses to no split.
+int choose_splits(int wgs, int n_chunks) {
+  if (wgs >= 128) return 1;
+  int splits = (256 + wgs - 1) / wgs;
   splits = std::min(splits, std::max(1, n_chunks / 4));
-  return std::max(1, std::min(splits, 32));
+  return std::max(1, std::min(splits, 16));
 }
 
-size_t splitk_bytes(int n_img, int H, int W, int cin, int cout) {
-  const int tiles = n_img * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
-  const int nb = (cout % 64 == 0) ? cout / 64 : cout / 32;
-  const int sp = choose_splits(tiles, nb, cin / kCK);
-  return sp > 1 ? (size_t)sp * n_img * H * W * cout * sizeof(float) : 0;
+ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split, int force_cfg = 0,
+                   int force_splits = 0) {
+  ConvPlan P;
+  auto wgs_of = [&](int cfg) {
+    const int th = cfg_th(cfg);
+    return n_img * ((H + th - 1) / th) * ((W + 15) / 16) * (cout / cfg_bnc(cfg));
+  };
+  int cfg = force_cfg;
+  if (cfg < 1 || cfg > 6 || cfg == 3 || cfg == 5 || cout % cfg_bnc(cfg) != 0) {
+    // measured per layer of the 640x480 pyramid (scripts/bench_conv.py --all-cfgs, profiles/r02_conv_cfgs.log):
+    // the 8-row x 128-channel tile wins while it yields >= 2 workgroups per CU, the 16-row one below
+    if (cout % 128 == 0) cfg = wgs_of(4) >= 512 ? 4 : 1;
+    else if (cout % 64 == 0) cfg = 2;
+    else cfg = 6;
+  }
+  P.cfg = cfg;
+  const int th = cfg_th(cfg);
+  P.tiles = n_img * ((H + th - 1) / th) * ((W + 15) / 16);
+  P.nb = cout / cfg_bnc(cfg);
+  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(P.tiles * P.nb, cin / 32)) : 1;
+  return P;
+}
+
+size_t splitk_bytes(int n_img, int H, int W, int cin, int cout, bool upcat = false) {
+  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, true, upcat ? (cout % 64 == 0 ? 2 : 6) : 0);
+  return cp.splits > 1 ? (size_t)cp.splits * n_img * H * W * cout * sizeof(float) : 0;
 }
 
 struct Plan {
@@ -536,59 +358,75 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
   for (int i = 1; i < 13; ++i)
     sk = std::max(sk, splitk_bytes(n_img, P.h[blk_of[i]], P.w[blk_of[i]], ctx->conv[i].cin, ctx->conv[i].cout));
   for (int d = 0; d < 4; ++d)
-    sk = std::max(sk, splitk_bytes(n_img, P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout));
+    sk = std::max(sk, splitk_bytes(n_img, P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout, true));
   P.splitk = take(sk + 256);
   P.total = off;
   return true;
 }
 
-void set_conv_lds_attr() {
-  // the conv kernels stage > 64 KiB of LDS (gfx950 has 160 KiB per CU)
-  static bool done = false;
-  if (done) return;
-  const int lds2 = (int)((kInHalves + 9 * 64 * kPix) * sizeof(half_t));
-  const int lds1 = (int)((kInHalves + 9 * 32 * kPix) * sizeof(half_t));
-  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-  (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-  done = true;
+template <int CW, int PBW, int WC, int WP, bool UPCAT>
+void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int lds = 2 * (2 * PBW * WP + 2) * kV2RowBytes + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0);
+  static bool attr_done = false;  // the double-buffered halo of the 32-row tiles exceeds the 64 KiB default
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT>), grid, dim3(256), lds, s, a);
 }
 
-int launch_conv(const UnetLayer& L, const half_t* in, int H, int W, half_t* out, hipStream_t s,
-                int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr) {
-  if (L.cin % kCK != 0 || L.cout % 32 != 0) return PXT_E_ARG;
-  if (up && (up->Cp % kCK != 0 || up->Cp >= L.cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
-    return PXT_E_ARG;
-  const UpSrc u = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
-  set_conv_lds_attr();
-  const int tiles = n_img * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
-  const bool wide = L.cout % 64 == 0;
-  const int nb = wide ? L.cout / 64 : L.cout / 32;
-  const int splits = partial ? choose_splits(tiles, nb, L.cin / kCK) : 1;
-  if (wide) {
-    const size_t lds = (size_t)(kInHalves + 9 * 64 * kPix) * sizeof(half_t);
-    if (up)
-      hipLaunchKernelGGL((conv3x3_mfma_kernel<2, true>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
-                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
-    else
-      hipLaunchKernelGGL((conv3x3_mfma_kernel<2, false>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
-                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
-  } else {
-    const size_t lds = (size_t)(kInHalves + 9 * 32 * kPix) * sizeof(half_t);
-    if (up)
-      hipLaunchKernelGGL((conv3x3_mfma_kernel<1, true>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
-                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
-    else
-      hipLaunchKernelGGL((conv3x3_mfma_kernel<1, false>), dim3(tiles, nb, splits), dim3(256), lds, s, in, H, W,
-                         L.cin, (const half_t*)L.w, L.b, L.cout, relu, out, partial, u);
+void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_t s) {
+  if (upcat) {
+    // decoder layers (bilinear x2 + concat formed in the staging): the 16x16-pixel tiles.  (Keep every
+    // variant free of scratch: one build whose 18-step loop was not unrolled indexed its offset table
+    // dynamically, 32 B of scratch per lane, and each launch - plus the head kernels on the side
+    // stream - then took milliseconds waiting for scratch set-up.)
+    if (cfg == 2) launch_v2<2, 2, 1, 4, true>(a, grid, s);
+    else launch_v2<1, 2, 1, 4, true>(a, grid, s);
+    return;
   }
-  if (splits > 1) {
-    const long long n4 = (long long)n_img * H * W * L.cout / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, splits,
-                       n4, L.cout, L.b, relu, out);
+  switch (cfg) {
+    case 1: launch_v2<2, 4, 2, 2, false>(a, grid, s); break;
+    case 2: launch_v2<2, 2, 1, 4, false>(a, grid, s); break;
+    case 4: launch_v2<2, 2, 2, 2, false>(a, grid, s); break;
+    default: launch_v2<1, 2, 1, 4, false>(a, grid, s); break;
+  }
+}
+
+// One 3x3 layer: `wpk` are the packed taps.  `pool_out` (optional) receives the 2x2 max-pool of the
+// output when the layer runs without split-K; returns (through *pooled) whether it was written.
+int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const half_t* in, int H, int W, half_t* out,
+                hipStream_t s, int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr,
+                half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0) {
+  if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
+  if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
+    return PXT_E_ARG;
+  if (up) force_cfg = cout % 64 == 0 ? 2 : 6;
+  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits);
+  ConvArgs a;
+  a.in = in; a.H = H; a.W = W; a.Cin = cin; a.wpk = wpk; a.bias = bias; a.Cout = cout; a.relu = relu;
+  a.out = out; a.partial = partial;
+  a.up = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
+  a.pool = cp.splits == 1 ? pool_out : nullptr;
+  if (pooled) *pooled = a.pool != nullptr;
+  const dim3 grid(cp.tiles, cp.nb, cp.splits);
+  launch_v2_cfg(cp.cfg, up != nullptr, a, grid, s);
+  if (cp.splits > 1) {
+    const long long n4 = (long long)n_img * H * W * cout / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, cp.splits,
+                       n4, cout, bias, relu, out);
   }
   return PXT_OK;
+}
+
+// Host-side packing of [Cout][3][3][Cin] fp16 taps into the kernel's fragment order.
+void pack_conv_weights_host(const half_t* w, int cin, int cout, half_t* packed) {
+  for (int co = 0; co < cout; ++co)
+    for (int t = 0; t < 9; ++t) {
+      const half_t* src = w + ((size_t)co * 9 + t) * cin;
+      for (int ci = 0; ci < cin; ++ci) packed[packed_weight_index(co, t, ci, cout)] = src[ci];
+    }
 }
 
 }  // namespace
@@ -631,10 +469,24 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
   }
   // architecture checks (VGG16-UNet wiring the forward pass assumes)
   bool ok = ctx->conv[0].cin == 3 && (ctx->conv[0].cout % 16) == 0;
-  for (int i = 1; i < n_conv; ++i) ok = ok && (ctx->conv[i].cin % kCK) == 0 && (ctx->conv[i].cout % 32) == 0;
+  for (int i = 1; i < n_conv; ++i) ok = ok && (ctx->conv[i].cin % 32) == 0 && (ctx->conv[i].cout % 32) == 0;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 8) == 0 && ctx->head[i].cout + 1 <= 192;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 16) == 0 && ctx->head[i].cout + 1 <= 160;
   if (!ok) { (void)hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
+  // 3x3 taps in the conv kernel's A-fragment order
+  {
+    size_t total = 0;
+    size_t offs[kNumConv];
+    for (int i = 1; i < n_conv; ++i) { offs[i] = total; total += (size_t)ctx->conv[i].cout * 9 * ctx->conv[i].cin; }
+    std::vector<half_t> hp(total);
+    for (int i = 1; i < n_conv; ++i)
+      pack_conv_weights_host((const half_t*)(p + table[4 * i]), ctx->conv[i].cin, ctx->conv[i].cout, hp.data() + offs[i]);
+    e = hipMalloc(&ctx->dev_packed, total * sizeof(half_t));
+    if (e == hipSuccess) e = hipMemcpy(ctx->dev_packed, hp.data(), total * sizeof(half_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_last_error("packed conv weights", e); pxt_unet_destroy(ctx); return PXT_E_HIP; }
+    ctx->conv_packed[0] = nullptr;
+    for (int i = 1; i < n_conv; ++i) ctx->conv_packed[i] = (const half_t*)ctx->dev_packed + offs[i];
+  }
   // heads: fp16 [32*NT][Cin] row-major weights (rows >= cout+1 zero) + fp32 padded bias
   {
     std::vector<char> hb;
@@ -672,6 +524,7 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (!ctx) return PXT_E_ARG;
   if (ctx->dev_blob) (void)hipFree(ctx->dev_blob);
   if (ctx->dev_head) (void)hipFree(ctx->dev_head);
+  if (ctx->dev_packed) (void)hipFree(ctx->dev_packed);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_enc4) (void)hipEventDestroy(ctx->ev_enc4);
   if (ctx->ev_dec1) (void)hipEventDestroy(ctx->ev_dec1);
@@ -744,6 +597,7 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
 
   const half_t* skip[5];
   const half_t* cur = nullptr;
+  bool pooled_by_conv = false;
   for (int b = 0; b < 5; ++b) {
     const int h = P.h[b], w = P.w[b];
     const half_t* x;
@@ -765,17 +619,24 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
       }
       x = o;
     } else {
-      const int cin = ctx->conv[block_first[b]].cin;
       half_t* o = buf(P.enc_pool[b]);
-      const long long n = (long long)B * h * w * (cin / 8);
-      hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cur, P.h[b - 1],
-                         P.w[b - 1], cin, o, h, w, B);
+      if (!pooled_by_conv) {
+        const int cin = ctx->conv[block_first[b]].cin;
+        const long long n = (long long)B * h * w * (cin / 8);
+        hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cur, P.h[b - 1],
+                           P.w[b - 1], cin, o, h, w, B);
+      }
       x = o;
     }
+    pooled_by_conv = false;
     for (int i = (b == 0 ? 1 : 0); i < block_n[b]; ++i) {
       const bool last = i == block_n[b] - 1;
+      const int li = block_first[b] + i;
       half_t* o = last ? buf(P.enc_out[b]) : buf(P.enc_tmp[b][i & 1]);
-      int rc = launch_conv(ctx->conv[block_first[b] + i], x, h, w, o, s, 1, (float*)(ws + P.splitk), B);
+      // the block's last conv also writes the next block's pooled input (epilogue fusion)
+      half_t* pool_to = (last && b < 4) ? buf(P.enc_pool[b + 1]) : nullptr;
+      int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
+                           1, (float*)(ws + P.splitk), B, nullptr, pool_to, pool_to ? &pooled_by_conv : nullptr);
       if (rc != PXT_OK) return rc;
       x = o;
     }
@@ -796,7 +657,8 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     if (cs <= 0) return PXT_E_ARG;
     const UpSrc up{prev, ph, pw, pc, P.h[sb], P.w[sb]};  // upsample + concat happen in the conv's staging
     half_t* o = buf(P.dec_out[d]);
-    int rc = launch_conv(L, skip[sb], P.dh[d], P.dw[d], o, s, 1, (float*)(ws + P.splitk), B, &up);
+    int rc = launch_conv(L.cin, L.cout, ctx->conv_packed[13 + d], L.b, skip[sb], P.dh[d], P.dw[d], o, s, 1,
+                         (float*)(ws + P.splitk), B, &up);
     if (rc != PXT_OK) return rc;
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
@@ -827,17 +689,55 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
                                 workspace, stream);
 }
 
+extern "C" int64_t pxt_conv3x3_packed_bytes(int32_t Cin, int32_t Cout) {
+  if (Cin < 32 || Cout < 32 || Cin % 32 != 0 || Cout % 32 != 0) return PXT_E_ARG;
+  return (int64_t)Cout * 9 * Cin * (int64_t)sizeof(half_t);
+}
+
+extern "C" int pxt_conv3x3_pack_weights(const void* weights, int32_t Cin, int32_t Cout, void* packed, void* stream) {
+  if (!weights || !packed || pxt_conv3x3_packed_bytes(Cin, Cout) <= 0) return PXT_E_ARG;
+  const long long n = (long long)Cout * 9 * Cin;
+  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)weights, Cin, Cout, (half_t*)packed);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_conv3x3_packed(const void* in, int32_t H, int32_t W, int32_t Cin, const void* packed,
+                                  const float* bias, int32_t Cout, int32_t relu, void* out, void* pool_out,
+                                  int32_t cfg, int32_t splits, void* splitk_ws, int64_t splitk_ws_bytes,
+                                  void* stream) {
+  if (!in || !packed || !bias || !out || H < 1 || W < 1) return PXT_E_ARG;
+  if (splits > 1 && (!splitk_ws || splitk_ws_bytes < (int64_t)splits * H * W * Cout * (int64_t)sizeof(float)))
+    return PXT_E_ARG;
+  if (cfg == 3 || cfg == 5 || (cfg >= 1 && cfg <= 6 && Cout % cfg_bnc(cfg) != 0)) return PXT_E_ARG;
+  int rc = launch_conv(Cin, Cout, (const half_t*)packed, bias, (const half_t*)in, H, W, (half_t*)out,
+                       (hipStream_t)stream, relu, splits > 1 ? (float*)splitk_ws : nullptr, 1, nullptr,
+                       (half_t*)pool_out, nullptr, cfg, splits > 1 ? splits : 0);
+  if (rc != PXT_OK) return rc;
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
 extern "C" int pxt_conv3x3_nhwc_f16(const void* in, int32_t H, int32_t W, int32_t Cin,
                                     const void* weights, const float* bias, int32_t Cout,
                                     int32_t relu, void* out, void* stream) {
   if (!in || !weights || !bias || !out || H < 1 || W < 1) return PXT_E_ARG;
-  UnetLayer L;
-  L.cin = Cin;
-  L.cout = Cout;
-  L.w = weights;
-  L.b = bias;
-  int rc = launch_conv(L, (const half_t*)in, H, W, (half_t*)out, (hipStream_t)stream, relu);
+  const int64_t bytes = pxt_conv3x3_packed_bytes(Cin, Cout);
+  if (bytes <= 0) return PXT_E_ARG;
+  // test / profiling entry: the taps are repacked on every call into a scratch that lives as long
+  // as the process (the pyramid packs once, at pxt_unet_create)
+  static void* scratch = nullptr;
+  static int64_t scratch_bytes = 0;
+  if (scratch_bytes < bytes) {
+    PXT_HIP_CHECK(hipDeviceSynchronize());
+    if (scratch) (void)hipFree(scratch);
+    scratch = nullptr;
+    scratch_bytes = 0;
+    PXT_HIP_CHECK(hipMalloc(&scratch, (size_t)bytes));
+    scratch_bytes = bytes;
+  }
+  int rc = pxt_conv3x3_pack_weights(weights, Cin, Cout, scratch, stream);
   if (rc != PXT_OK) return rc;
-  PXT_HIP_CHECK(hipGetLastError());
-  return PXT_OK;
+  return pxt_conv3x3_packed(in, H, W, Cin, scratch, bias, Cout, relu, out, nullptr, 0, 1, nullptr, 0, stream);
 }

@@ -44,7 +44,7 @@ def test_unet_rejects_images_it_cannot_encode(device):
     net = UNet(make_synthetic_unet_weights(1), device)
     with pytest.raises(_lib.PxtError):  # 8 px: the fourth pooling would have nothing left
         net.forward_packed(torch.zeros(8, 8, 3, device=device), None, False)
-    with pytest.raises(AssertionError):  # a batch holds one image size
+    with pytest.raises(_lib.PxtError):  # a batch holds one image size (checked by the op)
         net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False),
                                   (torch.zeros(32, 48, 3, device=device), None, False)])
     with pytest.raises(_lib.PxtError):  # PXT_UNET_MAX_BATCH

@@ -138,3 +138,49 @@ def test_unet_batch_matches_single_images_and_oracle(device, H, W):
         cos = F.cosine_similarity(both[1][k][..., :c].cpu(), f_ref, dim=-1)
         assert cos.min().item() > 0.9995, (k, cos.min().item())
         assert (both[1][k][..., c].cpu() - confs[k][0]).abs().max().item() < 5e-3
+
+
+def _packed_conv(device, x, w, b, relu, cfg=0, splits=1, pool=False):
+    """x [Cin,H,W] fp16, w [Cout,Cin,3,3] fp16 -> (out [Cout,H,W] float, pooled or None) through
+    pxt_conv3x3_pack_weights + pxt_conv3x3_packed with an explicit tile configuration."""
+    L = _lib.lib()
+    Cin, H, W = x.shape
+    Cout = w.shape[0]
+    xd = x.permute(1, 2, 0).contiguous().to(device)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(device)
+    bd = b.to(device)
+    packed = torch.empty(int(L.pxt_conv3x3_packed_bytes(Cin, Cout)), dtype=torch.uint8, device=device)
+    _lib.check(L.pxt_conv3x3_pack_weights(wd.data_ptr(), Cin, Cout, packed.data_ptr(), _lib.stream_ptr(device)), "pack")
+    out = torch.full((H, W, Cout), float("nan"), dtype=torch.float16, device=device)
+    pl = torch.full((H // 2, W // 2, Cout), float("nan"), dtype=torch.float16, device=device) if pool else None
+    ws = torch.empty(max(1, splits) * H * W * Cout * 4, dtype=torch.uint8, device=device) if splits > 1 else None
+    _lib.check(L.pxt_conv3x3_packed(xd.data_ptr(), H, W, Cin, packed.data_ptr(), bd.data_ptr(), Cout, relu, out.data_ptr(),
+                                    _lib.dptr(pl), cfg, splits, _lib.dptr(ws), ws.numel() if ws is not None else 0,
+                                    _lib.stream_ptr(device)), "conv packed")
+    torch.cuda.synchronize()
+    return out.float().cpu().permute(2, 0, 1), (pl.float().cpu().permute(2, 0, 1) if pool else None)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6])
+@pytest.mark.parametrize("H,W,Cin,Cout", [(37, 50, 64, 128), (64, 48, 96, 256), (9, 130, 32, 128)])
+def test_conv3x3_every_tile_configuration(device, cfg, H, W, Cin, Cout):
+    """All six workgroup tilings (16x16/32x16/8x16 pixels x 128/64/32 channels) give the same layer,
+    on ragged sizes (partial tiles in both directions), with and without the fused 2x2 max-pool and
+    with split-K."""
+    g = torch.Generator().manual_seed(cfg * 7919 + H * 1000 + W + Cin)
+    x = torch.randn(Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.float()[None], w.float(), b, padding=1)[0])
+    tol = 2e-3 * max(1.0, ref.abs().max().item())
+    got, pooled = _packed_conv(device, x, w, b, 1, cfg=cfg, pool=True)
+    assert torch.isfinite(got).all() and (got - ref).abs().max().item() < tol
+    # the pooled copy is the max-pool of the fp16 output itself: exact
+    want_pool = F.max_pool2d(got[None], 2)[0]
+    assert torch.isfinite(pooled).all() and torch.equal(pooled, want_pool)
+    got2, _ = _packed_conv(device, x, w, b, 1, cfg=cfg, splits=min(3, Cin // 32))
+    assert (got2 - ref).abs().max().item() < tol
+    # without ReLU / without pool: same numbers as the pooled run where positive
+    got3, _ = _packed_conv(device, x, w, b, 0, cfg=cfg)
+    ref3 = F.conv2d(x.float()[None], w.float(), b, padding=1)[0]
+    assert (got3 - ref3).abs().max().item() < tol
