@@ -37,15 +37,29 @@ constexpr int kNumHeads = 3;
 // A workgroup owns a 64 x 4 pixel strip: the normalised 66 x 6 x 3 input window is computed once
 // into LDS; then thread = pixel, all Cout channels, 16 at a time.  The filter index is
 // wave-uniform, so the 27 x Cout weights arrive as scalar loads (SGPR operands of the FMAs):
-// no LDS or vector-memory traffic for them at all.
+// no LDS or vector-memory traffic for them at all.  The results go through an XOR-swizzled LDS
+// tile so that the global stores are contiguous (a row of the strip is 64 px x Cout x 2 B in a
+// row): thread = pixel stores were 16-B pieces 2*Cout bytes apart and ran at 1.1 TB/s.
+// All images of a batch run in ONE launch (blockIdx.y = image; type and mask per image).
 constexpr int kFW = 64, kFH = 4;
-template <bool U8>
-__global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict__ image,
-                                                         const uint8_t* __restrict__ mask, int H,
-                                                         int W, const float* __restrict__ wts,
-                                                         const float* __restrict__ bias, int Cout,
+struct FirstImages {
+  const void* image[PXT_UNET_MAX_BATCH];
+  const uint8_t* mask[PXT_UNET_MAX_BATCH];
+  int is_u8[PXT_UNET_MAX_BATCH];
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_kernel(const FirstImages imgs, int H, int W,
+                                                         const float* __restrict__ wts,
+                                                         const float* __restrict__ bias,
                                                          half_t* __restrict__ out) {
   __shared__ float s_px[(kFH + 2) * (kFW + 2) * 3];
+  __shared__ __attribute__((aligned(16))) half_t s_out[kFH * kFW * COUT];
+  const int im = blockIdx.y;
+  const void* image = imgs.image[im];
+  const uint8_t* mask = imgs.mask[im];
+  const bool u8 = imgs.is_u8[im] != 0;
+  out += (size_t)im * H * W * COUT;
   const int tiles_x = (W + kFW - 1) / kFW;
   const int tx0 = (blockIdx.x % tiles_x) * kFW, ty0 = (blockIdx.x / tiles_x) * kFH;
   const float mean[3] = {0.485f, 0.456f, 0.406f};
@@ -61,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict_
       float v = 0.f;
       if (ok) {
         const size_t idx = ((size_t)yy * W + xx) * 3 + c;
-        float raw = U8 ? (float)((const uint8_t*)image)[idx] : ((const float*)image)[idx];
+        float raw = u8 ? (float)((const uint8_t*)image)[idx] : ((const float*)image)[idx];
         if (mask) raw *= m;
         v = (raw / 255.0f - mean[c]) * istd[c];
       }
@@ -70,7 +84,6 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict_
   }
   __syncthreads();
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const int x = tx0 + lx, y = ty0 + ly;
   float in[27];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
@@ -78,9 +91,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict_
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int c = 0; c < 3; ++c) in[(ky * 3 + kx) * 3 + c] = s_px[((ly + ky) * (kFW + 2) + lx + kx) * 3 + c];
-  if (x >= W || y >= H) return;
-  half_t* dst = out + ((size_t)y * W + x) * Cout;
-  for (int cg = 0; cg < Cout / 16; ++cg) {  // uniform: wts / bias below are scalar loads
+  // this pixel's record in the LDS tile: COUT halves = COUT/8 16-B pieces, piece index XOR-ed with
+  // the pixel's low bits (thread = pixel writes would otherwise all land on the same banks)
+  constexpr int kPieces = COUT / 8;
+  half_t* rec = s_out + (size_t)threadIdx.x * COUT;
+#pragma unroll 1
+  for (int cg = 0; cg < COUT / 16; ++cg) {  // uniform: wts / bias below are scalar loads
     const float* wg = wts + (size_t)cg * 16 * 27;
     float acc[16];
 #pragma unroll
@@ -96,8 +112,21 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const void* __restrict_
       o0[j] = (half_t)fmaxf(acc[j], 0.f);
       o1[j] = (half_t)fmaxf(acc[8 + j], 0.f);
     }
-    *(half8*)(dst + cg * 16) = o0;
-    *(half8*)(dst + cg * 16 + 8) = o1;
+    *(half8*)(rec + (((2 * cg) ^ (int)(threadIdx.x & (kPieces - 1))) << 3)) = o0;
+    *(half8*)(rec + (((2 * cg + 1) ^ (int)(threadIdx.x & (kPieces - 1))) << 3)) = o1;
+  }
+  __syncthreads();
+  // coalesced write-out: the strip's row `ry` is kFW * COUT contiguous halves in global memory
+#pragma unroll
+  for (int k = 0; k < kFH * kFW * kPieces / 256; ++k) {
+    const int q = threadIdx.x + 256 * k;       // 16-B piece of the tile, row-major [row][px][piece]
+    const int piece = q % kPieces, px = (q / kPieces) % kFW, ry = q / (kPieces * kFW);
+    const int x = tx0 + px, y = ty0 + ry;
+    if (x < W && y < H) {
+      const int t = ry * kFW + px;  // the thread that computed this pixel
+      *(half8*)(out + ((size_t)y * W + x) * COUT + piece * 8) =
+          *(const half8*)(s_out + (size_t)t * COUT + ((piece ^ (t & (kPieces - 1))) << 3));
+    }
   }
 }
 
@@ -284,15 +313,16 @@ struct ConvPlan { int cfg, tiles, nb, splits; };
 
 // Split-K factor: only the smallest maps (conv5: 12 tiles per image pair) leave most of the 256 CUs
 // without a workgroup; measured on the 60x80 layers (160 workgroups) every split loses to no split.
-int choose_splits(int wgs, int n_chunks) {
-  if (wgs >= 128) return 1;
+int choose_splits(int wgs, int n_chunks, bool upcat) {
+  // (the decoder's 64-channel tiles run one workgroup per CU at 160 workgroups: split those too)
+  if (wgs >= (upcat ? 256 : 128)) return 1;
   int splits = (256 + wgs - 1) / wgs;
   splits = std::min(splits, std::max(1, n_chunks / 4));
   return std::max(1, std::min(splits, 16));
 }
 
 ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split, int force_cfg = 0,
-                   int force_splits = 0) {
+                   int force_splits = 0, bool upcat = false) {
   ConvPlan P;
   auto wgs_of = [&](int cfg) {
     const int th = cfg_th(cfg);
@@ -310,12 +340,12 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   const int th = cfg_th(cfg);
   P.tiles = n_img * ((H + th - 1) / th) * ((W + 15) / 16);
   P.nb = cout / cfg_bnc(cfg);
-  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(P.tiles * P.nb, cin / 32)) : 1;
+  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(P.tiles * P.nb, cin / 32, upcat)) : 1;
   return P;
 }
 
 size_t splitk_bytes(int n_img, int H, int W, int cin, int cout, bool upcat = false) {
-  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, true, upcat ? (cout % 64 == 0 ? 2 : 6) : 0);
+  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, true, upcat ? (cout % 64 == 0 ? 2 : 6) : 0, 0, upcat);
   return cp.splits > 1 ? (size_t)cp.splits * n_img * H * W * cout * sizeof(float) : 0;
 }
 
@@ -403,7 +433,7 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
   if (up) force_cfg = cout % 64 == 0 ? 2 : 6;
-  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits);
+  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr);
   ConvArgs a;
   a.in = in; a.H = H; a.W = W; a.Cin = cin; a.wpk = wpk; a.bias = bias; a.Cout = cout; a.relu = relu;
   a.out = out; a.partial = partial;
@@ -468,7 +498,7 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
     if (wbytes != want_w || bbytes != want_b) { (void)hipFree(ctx->dev_blob); delete ctx; return PXT_E_ARG; }
   }
   // architecture checks (VGG16-UNet wiring the forward pass assumes)
-  bool ok = ctx->conv[0].cin == 3 && (ctx->conv[0].cout % 16) == 0;
+  bool ok = ctx->conv[0].cin == 3 && ctx->conv[0].cout == 64;
   for (int i = 1; i < n_conv; ++i) ok = ok && (ctx->conv[i].cin % 32) == 0 && (ctx->conv[i].cout % 32) == 0;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 8) == 0 && ctx->head[i].cout + 1 <= 192;
   for (int i = 0; i < n_heads; ++i) ok = ok && (ctx->head[i].cin % 16) == 0 && ctx->head[i].cout + 1 <= 160;
@@ -602,21 +632,18 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     const int h = P.h[b], w = P.w[b];
     const half_t* x;
     if (b == 0) {
-      // the images differ in type (u8 render / float frame) and mask: one launch each, all
-      // writing into the batched activation buffer
+      // the images differ in type (u8 render / float frame) and mask: ONE launch, blockIdx.y = image
       const UnetLayer& L0 = ctx->conv[0];
       const unsigned nblk = (unsigned)(((w + kFW - 1) / kFW) * ((h + kFH - 1) / kFH));
       half_t* o = buf(P.enc_tmp[0][0]);
+      FirstImages fi;
       for (int i = 0; i < B; ++i) {
-        half_t* oi = o + (size_t)i * h * w * L0.cout;
-        const uint8_t* m = masks ? masks[i] : nullptr;
-        if (image_is_u8[i])
-          hipLaunchKernelGGL(conv_first_kernel<true>, dim3(nblk), dim3(256), 0, s, images[i], m, h, w,
-                             (const float*)L0.w, L0.b, L0.cout, oi);
-        else
-          hipLaunchKernelGGL(conv_first_kernel<false>, dim3(nblk), dim3(256), 0, s, images[i], m, h, w,
-                             (const float*)L0.w, L0.b, L0.cout, oi);
+        fi.image[i] = images[i];
+        fi.mask[i] = masks ? masks[i] : nullptr;
+        fi.is_u8[i] = image_is_u8[i];
       }
+      if (L0.cout != 64) return PXT_E_ARG;
+      hipLaunchKernelGGL(conv_first_kernel<64>, dim3(nblk, B), dim3(256), 0, s, fi, h, w, (const float*)L0.w, L0.b, o);
       x = o;
     } else {
       half_t* o = buf(P.enc_pool[b]);
