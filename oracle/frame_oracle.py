@@ -38,8 +38,15 @@ def sfm_to_nerf_pose(nerf2sfm, cIw):
 
 
 def colmap_camera_to_pix(cam) -> torch.Tensor:
-    """pixloc Camera.from_colmap for SIMPLE_RADIAL: (w,h,f,f,cx-.5,cy-.5,k1,0)."""
-    f, cx, cy, k1 = [float(x) for x in cam["params"]]
+    """pixloc Camera.from_colmap: SIMPLE_RADIAL -> (w,h,f,f,cx-.5,cy-.5,k1,0); OPENCV (the YCB iterator's
+    camera, reference pixtrack/utils/io.py:60-66) -> (w,h,fx,fy,cx-.5,cy-.5,k1,k2,p1,p2), missing
+    distortion parameters read as zeros."""
+    p = [float(x) for x in cam["params"]]
+    if cam.get("model", "SIMPLE_RADIAL") == "OPENCV":
+        fx, fy, cx, cy = p[:4]
+        dist = (p[4:8] + [0.0] * 4)[:4]
+        return torch.tensor([cam["width"], cam["height"], fx, fy, cx - 0.5, cy - 0.5] + dist, dtype=torch.float32)
+    f, cx, cy, k1 = p
     return torch.tensor([cam["width"], cam["height"], f, f, cx - 0.5, cy - 0.5, k1, 0.0], dtype=torch.float32)
 
 
@@ -85,7 +92,8 @@ def depth_mask(depth_rgba: np.ndarray) -> np.ndarray:
 
 def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndarray, ref_id: int,
                 multiscale=(1,), use_mask: bool = True, lm_conf: Optional[LO.LMConf] = None,
-                timings: Optional[Dict[str, float]] = None, spp: int = 8, keep: Optional[Dict] = None):
+                timings: Optional[Dict[str, float]] = None, spp: int = 8, keep: Optional[Dict] = None,
+                reference_scale: float = 0.5, aabb=None, query_camera=None):
     """One frame from pose (R, t): returns dict(success, R, t, cost, mask).  ``query_image``
     float32 HWC 0..255.  Follows refine(): mask -> dynamic reference -> per scale
     {UNet(ref) -> sparse sample, UNet(query) -> LM over 3 levels coarse->fine}."""
@@ -95,10 +103,10 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
         tm[name] = tm.get(name, 0.0) + (time.perf_counter() - t0)
 
     lm_conf = lm_conf or LO.LMConf()
-    model3d, snapshot, nerf2sfm, aabb, weights = (assets["model3d"], assets["snapshot"], assets["nerf2sfm"],
-                                                  assets["aabb"], assets["weights"])
+    model3d, snapshot, nerf2sfm, weights = assets["model3d"], assets["snapshot"], assets["nerf2sfm"], assets["weights"]
+    aabb = assets["aabb"] if aabb is None else aabb  # (the YCB policy renders inside the SfM points' box)
     ngp = ngp_model(snapshot)
-    qcam = colmap_camera_to_pix(assets["query_camera"])
+    qcam = colmap_camera_to_pix(assets["query_camera"] if query_camera is None else query_camera)
     mask = None
     img = np.asarray(query_image, np.float32)
     if use_mask:
@@ -109,10 +117,10 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
             keep["depth_rgba"] = depth
         img = img * mask[..., None].astype(np.float32)
         tick("nerf_depth", t0)
-    # dynamic reference render with SfM camera 1 scaled by reference_scale 0.5
+    # dynamic reference render with SfM camera 1 scaled by reference_scale (r9: 0.5, YCB: 0.3)
     c1 = model3d.cameras[1]
     ref_cam_full = colmap_camera_to_pix(dict(width=c1.width, height=c1.height, params=c1.params))
-    ref_cam = LO.camera_scale(ref_cam_full, 0.5)
+    ref_cam = LO.camera_scale(ref_cam_full, reference_scale)
     t0 = time.perf_counter()
     ref_rgba = NO.render(ngp, nerf_view(snapshot, nerf2sfm, aabb, R, t, ref_cam, 0, spp))
     ref_img = to_u8(ref_rgba).astype(np.float32)
@@ -134,7 +142,7 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
         maps_ref = [torch.cat([f, c], 0) for f, c in zip(f_ref, c_ref)]
         tick("unet_ref", t0)
         t0 = time.perf_counter()
-        obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, 0.5, R_ref, t_ref, p3d, lm_conf.pad)
+        obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, reference_scale, R_ref, t_ref, p3d, lm_conf.pad)
         tick("sample", t0)
         t0 = time.perf_counter()
         f_q, sc_q, c_q = UO.extractor_call(weights, img, scale)

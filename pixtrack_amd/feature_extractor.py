@@ -52,7 +52,8 @@ class PixTrackFeatureExtractor:
             image = torch.from_numpy(np.ascontiguousarray(image))
         if image.dtype not in (torch.float32, torch.uint8):
             image = image.float()
-        return image.to(self.device).contiguous()
+        # frames handed over in pinned host memory (ImageIterator's role) are uploaded asynchronously
+        return image.to(self.device, non_blocking=True).contiguous()
 
     def stage(self, image, scale_image: int = 1, mask: Optional[torch.Tensor] = None,
               normalize: bool = False) -> None:

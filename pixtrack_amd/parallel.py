@@ -31,6 +31,45 @@ def shard_units(n_units: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_units, world_size))
 
 
+def shard_segments(n_frames: int, world_size: int, rank: int, segment_len: int = 0) -> List[tuple]:
+    """Contiguous frame segments [start, stop) of ONE video dealt round-robin to ranks (BASELINE
+    configs[4] "frames sharded over 8 GPUs").  Frames of a video depend on their predecessor
+    (pixloc_tracker_r9.py:216-229), so every segment head is a cold start: results at segment heads
+    differ from a sequential run - the benchmark says so next to its number.
+    ``segment_len`` 0 = one segment per rank."""
+    if n_frames <= 0:
+        return []
+    if segment_len <= 0:
+        segment_len = -(-n_frames // max(world_size, 1))
+    starts = list(range(0, n_frames, segment_len))
+    return [(s, min(n_frames, s + segment_len)) for i, s in enumerate(starts) if i % world_size == rank]
+
+
+def stitch_segments(gathered: Sequence[torch.Tensor], segments_per_rank: Sequence[Sequence[tuple]], n_frames: int):
+    """Per-rank record blocks (each rank's segments concatenated in order) -> one [n_frames, 14]
+    tensor in frame order."""
+    out = torch.zeros(n_frames, RECORD, dtype=torch.float64)
+    for recs, segs in zip(gathered, segments_per_rank):
+        k = 0
+        for (a, b) in segs:
+            out[a:b] = recs[k:k + (b - a)]
+            k += b - a
+    return out
+
+
+def load_object_configs() -> List[dict]:
+    """The per-object records of the reference's config/*.sh (values committed as data in
+    configs/objects.json); boxes are returned with min <= max per axis."""
+    import json
+    from pathlib import Path
+
+    objs = json.loads((Path(__file__).parent / "configs" / "objects.json").read_text())["objects"]
+    for o in objs:
+        lo, hi = o["OBJ_AABB"]
+        o["aabb"] = [[min(a, b) for a, b in zip(lo, hi)], [max(a, b) for a, b in zip(lo, hi)]]
+    return objs
+
+
 def pack_pose_records(history: dict, names: Sequence[str]) -> torch.Tensor:
     """[n_frames, 14] float64 from a tracker's pose_history."""
     out = torch.zeros(len(names), RECORD, dtype=torch.float64)

@@ -89,19 +89,16 @@ class PixLocPoseTrackerR9(PoseTracker):
         self.pose_tracker_history = {}
         self.cold_start = True
         self.pose = None
-        upright_ref_img = assets["upright_ref_img"] if assets is not None else os.environ["UPRIGHT_REF_IMG"]
-        self.reference_ids = [self.localizer.model3d.name2id[upright_ref_img]]
+        self.reference_ids = self._initial_reference_ids(assets)
         self.reference_scale = 0.5
         self.localizer.refiner.reference_scale = self.reference_scale
         if assets is not None:
             self.nerf2sfm = assets["nerf2sfm"]
-            aabb = assets["aabb"]
             snapshot = assets["snapshot"]
         else:
             self.nerf2sfm = load_nerf2sfm(str(Path(data_path) / "nerf2sfm.pkl"))
-            aabb = ast.literal_eval(os.environ["OBJ_AABB"])
             snapshot = str(Path(object_path) / "pixtrack/instant-ngp/snapshots/weights.msgpack")
-        self.testbed = initialize_ingp(snapshot, aabb, device=self.device)
+        self.testbed = initialize_ingp(snapshot, self._render_aabb(assets), device=self.device)
         self.localizer.refiner.warm_reference_points()  # static per-reference tables, off the frame path
         self.dynamic_id = None
         self.hits = 0
@@ -121,6 +118,17 @@ class PixLocPoseTrackerR9(PoseTracker):
         self._ref_cam_cache = None
         self._coincide_cache = None
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
+        self.steady_multiscale = [1]  # image scales of a tracked (non-cold-start) frame (:223)
+
+    # ------------------------------------------------------------------ per-variant set-up
+    def _initial_reference_ids(self, assets):
+        """r9: the upright reference image named by $UPRIGHT_REF_IMG (:77-78)."""
+        upright_ref_img = assets["upright_ref_img"] if assets is not None else os.environ["UPRIGHT_REF_IMG"]
+        return [self.localizer.model3d.name2id[upright_ref_img]]
+
+    def _render_aabb(self, assets):
+        """r9: the render box is $OBJ_AABB (:85-86)."""
+        return assets["aabb"] if assets is not None else ast.literal_eval(os.environ["OBJ_AABB"])
 
     # ------------------------------------------------------------------ relocalisation
     def relocalize(self, query):
@@ -131,6 +139,23 @@ class PixLocPoseTrackerR9(PoseTracker):
             ref_img = self.localizer.model3d.dbs[self.reference_ids[0]]
             self.pose = Pose.from_Rt(ref_img.qvec2rotmat(), ref_img.tvec)
         self.relocalization_count += 1
+
+    def start_segment(self, pose_init: Pose):
+        """Cold start of a frame SEGMENT that does not begin at the video's first frame (BASELINE
+        configs[4]: one video cut into per-GPU segments).  The reference has no such entry point - its
+        only cold start is the upright reference pose of frame 0 (:95-106) - so a segment head needs a
+        pose from outside (a relocaliser; the synthetic runs pass a perturbed ground truth).  What
+        follows is the reference's cold-start policy: image scales [4, 1], no mask, nearest reference
+        image by rotation, cost threshold frozen again from this segment's first frame."""
+        self.pose = pose_init
+        self.cold_start = True
+        self.success = True
+        self.cost_threshold = None
+        self.dynamic_id = None
+        self.cache_hit = False
+        R_qry = pose_init.numpy()[0]
+        dbs = self.localizer.model3d.dbs
+        self.reference_ids = sorted(dbs, key=lambda r: geodesic_distance_for_rotations(R_qry, dbs[r].qvec2rotmat()))[:1]
 
     def get_query_camera(self, query):
         """Camera of the query stream from the frame size (EXIF-less pycolmap heuristic)."""
@@ -245,7 +270,7 @@ class PixLocPoseTrackerR9(PoseTracker):
             self.relocalize(query)
             self.cold_start = False
         elif self.success:
-            refiner.conf.multiscale = [1]
+            refiner.conf.multiscale = list(self.steady_multiscale)
             refiner.query_mask = self.get_mask(self.pose)  # multiplied inside the first conv
 
         # The masked query is fully known here, before the reference render is encoded: announce

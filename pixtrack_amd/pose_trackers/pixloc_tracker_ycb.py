@@ -10,20 +10,29 @@ different host policy:
 * success = optimiser success AND t_err < 10 cm AND r_err < 10 deg, where the error is that
   of `self.pose` BEFORE this frame's update (:280-290, :297-303); `ret["gt_pose"]` is kept.
 
+* needs neither $UPRIGHT_REF_IMG nor $OBJ_AABB: the reference image comes from the GT pose, the
+  render box from the SfM points (`get_nerf_aabb_from_sfm`, :92).
+
 Frames are (path, image, gt_pose: Pose, gt_camera: Camera) tuples (reference
-pixtrack/utils/io.py:13-72 `YCBVideoIterator`).
+pixtrack/utils/io.py:13-72 `YCBVideoIterator`).  CLI (:306-345): --object_path P --query "7:10"
+--out_dir D [--frames N] [--debug]; the dataset root is $YCB_ROOT or --ycb_root (the reference
+hard-codes /data/ycb/).
 """
 from __future__ import annotations
 
+import argparse
 import os
+from pathlib import Path
 
 import numpy as np
 from scipy.spatial.transform import Rotation as R
 
 from ..geometry import Pose
 from ..tracker import DebugTracker
+from ..utils.ingp_utils import get_nerf_aabb_from_sfm
+from ..utils.io import YCBVideoIterator
 from ..utils.pose_utils import geodesic_distance_for_rotations
-from .pixloc_tracker_r9 import PixLocPoseTrackerR9
+from .pixloc_tracker_r9 import PixLocPoseTrackerR9, _dump
 
 
 class GTFrameIterator:
@@ -48,7 +57,10 @@ class GTFrameIterator:
 
 
 class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
-    def __init__(self, data_path, loc_path, eval_path, object_path, debug=False, device=None, assets=None):
+    def __init__(self, data_path, loc_path, eval_path, object_path, debug=False, device=None, assets=None,
+                 ycb_root=None):
+        self.object_path = object_path
+        self.ycb_root = Path(ycb_root or os.environ.get("YCB_ROOT", "/data/ycb/"))
         super().__init__(object_path, data_path, loc_path, eval_path, debug=int(debug), device=device, assets=assets)
         self.reference_scale = 0.3
         self.localizer.refiner.reference_scale = self.reference_scale
@@ -57,6 +69,13 @@ class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
         self.gt_pose = None
         self.gt_camera = None
         self.t_err = self.r_err = float("nan")
+
+    def _initial_reference_ids(self, assets):
+        return None  # chosen from the GT pose at the first relocalisation (:117-130)
+
+    def _render_aabb(self, assets):
+        """The YCB variant renders inside the box of the SfM points (:92), never $OBJ_AABB."""
+        return get_nerf_aabb_from_sfm(self.localizer.model3d, self.nerf2sfm)
 
     def relocalize(self, query_path):
         if self.cold_start:
@@ -122,6 +141,38 @@ class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
                                       f"relocalizations: {self.relocalization_count}")
 
     def get_query_frame_iterator(self, path, max_frames):
-        if isinstance(path, GTFrameIterator):
+        if isinstance(path, (GTFrameIterator, YCBVideoIterator)):
             return path
-        raise NotImplementedError("the ycbvideo dataset loader is not part of this build; pass a GTFrameIterator")
+        it = YCBVideoIterator(object_path=Path(self.object_path), expression=path, ycb_path=self.ycb_root)
+        if max_frames is not None and np.isfinite(max_frames):
+            it.frames = it.frames[: int(max_frames)]
+        return it
+
+
+def main(argv=None):
+    """Reference command line (pixloc_tracker_ycb.py:306-345)."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--object_path", type=Path)
+    parser.add_argument("--query", default="7:10")
+    parser.add_argument("--out_dir", default="ycb_7")
+    parser.add_argument("--frames", type=int, default=None)
+    parser.add_argument("--debug", action="store_true", default=False)
+    parser.add_argument("--ycb_root", default=None, help="YCB-Video root (default $YCB_ROOT or /data/ycb/)")
+    parser.add_argument("--pixloc_pickles", action="store_true")
+    args = parser.parse_args(argv)
+    obj_path = args.object_path
+    eval_path = Path(args.out_dir)
+    os.makedirs(eval_path, exist_ok=True)
+    tracker = PixLocPoseTrackerYCB(data_path=str(obj_path / "pixtrack/pixsfm/dataset"), eval_path=str(eval_path),
+                                   loc_path=str(obj_path / "pixtrack/aug_nerf_sfm"), object_path=obj_path,
+                                   debug=args.debug, ycb_root=args.ycb_root)
+    tracker.run(args.query, max_frames=args.frames)
+    print("Relocalization count: ", tracker.relocalization_count)
+    tracker.save_poses(args.pixloc_pickles)
+    print("Cache hits: %d, misses: %d" % (tracker.hits, tracker.misses))
+    _dump(tracker.pose_tracker_history, os.path.join(tracker.eval_path, "trackers.pkl"), args.pixloc_pickles)
+    print("Done")
+
+
+if __name__ == "__main__":
+    main()

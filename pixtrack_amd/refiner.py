@@ -75,6 +75,10 @@ class PoseTrackerRefiner:
     )
     default_config = dict(
         multiscale=None,
+        # optional {image_scale: [pyramid levels]}: restricts the levels optimised at an image scale.
+        # Not a reference feature: it exists for BASELINE configs[4]'s "4-level pyramid" stress
+        # workload ({4: [2], 1: [2, 1, 0]}: the 1/64 map of the downscaled image + the three native ones)
+        level_plan=None,
         filter_covisibility=False,
         do_pose_approximation=False,
         do_inlier_ranking=False,
@@ -291,7 +295,9 @@ class PoseTrackerRefiner:
             # Infrastructure errors (HIP, spin bound) raise PxtError out of here; only the
             # algorithmic failure becomes success=False (SURVEY 8b error convention; the
             # reference's bare `except:` at :259-265 would have hidden both).
-            ret = self.refine_pose_using_features(maps_q, scales_q, qcamera, T_init, ref)
+            plan = self.conf.level_plan
+            levels = None if not plan else plan.get(image_scale, plan.get(str(image_scale)))
+            ret = self.refine_pose_using_features(maps_q, scales_q, qcamera, T_init, ref, levels)
             if not ret["success"]:
                 logger.info(f"Optimization failed for query {qname}")
                 break
@@ -299,11 +305,12 @@ class PoseTrackerRefiner:
         return ret
 
     def refine_pose_using_features(self, features_query: List[torch.Tensor], scales_query, qcamera: Camera,
-                                   T_init: Pose, ref: SparseReferenceFeatures) -> Dict:
+                                   T_init: Pose, ref: SparseReferenceFeatures, levels=None) -> Dict:
         """pixloc BaseRefiner.refine_pose_using_features on packed buffers: coarse -> fine,
-        optimizer[level] per level, all levels in one kernel launch."""
+        optimizer[level] per level, all levels in one kernel launch.  ``levels`` (optional) keeps
+        only those pyramid levels (conf.level_plan)."""
         n_levels = len(features_query)
-        order = list(reversed(range(n_levels)))
+        order = [l for l in reversed(range(n_levels)) if levels is None or l in levels]
         packs = []
         for level in order:
             opt = self.optimizer[level] if isinstance(self.optimizer, (list, tuple)) else self.optimizer

@@ -413,7 +413,8 @@ def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, 
                 width=width, height=height)
 
 
-def render_query_frames(assets, testbed, noise_sigma: float = 2.0, seed: int = 5, first_frame_sigma: float = 12.0):
+def render_query_frames(assets, testbed, noise_sigma: float = 2.0, seed: int = 5, first_frame_sigma: float = 12.0,
+                        cold_start_indices=(0,)):
     """Query frames = NeRF renders at the GT poses (+ Gaussian noise, sigma in 8-bit levels),
     float32 HWC 0..255 device tensors, as ImageIterator would hand them over.  Setup only.
 
@@ -437,7 +438,8 @@ def render_query_frames(assets, testbed, noise_sigma: float = 2.0, seed: int = 5
         nerf_pose = sfm_to_nerf_pose(assets["nerf2sfm"], np.linalg.inv(wIc))
         u8 = rgba_to_u8(get_nerf_image_device(testbed, nerf_pose, cam), 0.0)
         img = u8.float()
-        sigma = first_frame_sigma if (len(frames) == 0 and first_frame_sigma is not None) else noise_sigma
+        # (``cold_start_indices``: positions in the returned list that a tracker will cold-start on)
+        sigma = first_frame_sigma if (len(frames) in cold_start_indices and first_frame_sigma is not None) else noise_sigma
         if sigma > 0:
             noise = torch.randn(img.shape, generator=g) * sigma
             img = (img + noise.to(img.device)).clamp_(0, 255).round_()

@@ -172,3 +172,61 @@ def test_single_pixel_and_ragged_renders(testbed):
     for (w, h, spp) in ((1, 1, 1), (3, 5, 5), (7, 2, 8)):
         out = testbed.render_device(w, h, spp, True)
         assert out.shape == (h, w, 4) and torch.isfinite(out).all()
+
+
+def test_three_concurrent_trackers_share_one_gpu(device):
+    """Several sequences on one GPU, one Python thread + one HIP stream each (scripts/bench_multiseq.py):
+    every tracker's persistent LM grid (64 workgroups, its own counters) must stay live beside the other
+    trackers' renders, UNets and LM grids - no PXT_E_TIMEOUT, every frame tracked, and each sequence's
+    poses equal to what it gets when it runs alone (streams only reorder independent work)."""
+    import threading
+
+    from pixtrack_amd import optimizer
+    from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+    from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
+
+    S, n = 3, 24
+    seqs = []
+    for k in range(S):
+        assets = make_tracking_assets(seed=1040 + k, width=320, height=240, n_frames=n, n_points=4000)
+        tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+        tr.spp = 4
+        seqs.append((assets, tr, render_query_frames(assets, tr.testbed), torch.cuda.Stream(device=device)))
+    torch.cuda.synchronize()
+    # reference: each sequence alone
+    alone = []
+    for assets, tr, frames, _ in seqs:
+        solo = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+        solo.spp = 4
+        for i, f in enumerate(frames):
+            solo.run_single_frame((f"{i:06d}.png", f))
+        alone.append([solo.pose_history[f"{i:06d}.png"]["T_refined"].numpy() for i in range(n)])
+    errors = []
+    old_poll = optimizer.PendingLM.poll
+    optimizer.PendingLM.poll = False  # several trackers on threads: wait on the event, do not spin under the GIL
+
+    def work(k):
+        try:
+            _, tr, frames, stream = seqs[k]
+            with torch.cuda.stream(stream):
+                for i, f in enumerate(frames):
+                    tr.run_single_frame((f"{i:06d}.png", f))
+                stream.synchronize()
+        except Exception as e:  # PxtError (in-kernel status / HIP error) would land here
+            errors.append((k, repr(e)))
+
+    try:
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+    finally:
+        optimizer.PendingLM.poll = old_poll
+    assert not errors, errors
+    for k, (assets, tr, frames, _) in enumerate(seqs):
+        for i in range(n):
+            ret = tr.pose_history[f"{i:06d}.png"]
+            assert ret["success"], (k, i)
+            R, t = ret["T_refined"].numpy()
+            assert np.allclose(R, alone[k][i][0], atol=1e-5) and np.allclose(t, alone[k][i][1], atol=1e-5), (k, i)

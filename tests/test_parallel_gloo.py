@@ -70,3 +70,57 @@ def test_two_rank_gloo_gather():
     assert shapes0 == shapes1 == [torch.Size([9, 14]), torch.Size([8, 14])]  # ragged: 3*3 and 2*4 frames
     assert sums0 == sums1 and abs(sums0[0] - own0) < 1e-9 and abs(sums0[1] - own1) < 1e-9
     assert t0 == t1 == 2.0
+
+
+def _seg_worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    n_frames = 11
+    segs_all = [parallel.shard_segments(n_frames, ws, r, 3) for r in range(ws)]
+    mine = [i for (a, b) in segs_all[rank] for i in range(a, b)]
+    hist = {}
+    for i in mine:  # frame i's record carries i, so the stitched video can be checked against the frame index
+        T = Pose(torch.full((12,), float(i), dtype=torch.float64))
+        hist[f"{i:06d}.png"] = {"success": True, "T_init": T, "T_refined": T, "cost": float(rank)}
+    rec = parallel.pack_pose_records(hist, [f"{i:06d}.png" for i in mine])
+    video = parallel.stitch_segments(parallel.gather_pose_records(rec), segs_all, n_frames)
+    q.put((rank, segs_all[rank], video[:, 0].tolist(), video[:, 13].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_segments_cover_the_video_once():
+    for n, ws, seg in [(100, 8, 0), (11, 2, 3), (5, 8, 0), (64, 4, 7)]:
+        allsegs = sum((parallel.shard_segments(n, ws, r, seg) for r in range(ws)), [])
+        frames = sorted(i for a, b in allsegs for i in range(a, b))
+        assert frames == list(range(n)), (n, ws, seg)
+    assert parallel.shard_segments(0, 4, 0) == []
+    assert parallel.shard_segments(100, 8, 0) == [(0, 13)] and parallel.shard_segments(100, 8, 7) == [(91, 100)]
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_segment_sharding_stitches_in_frame_order():
+    """BASELINE configs[4]: one video in contiguous per-rank segments, stitched by the final gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert res[0][1] == [(0, 3), (6, 9)] and res[1][1] == [(3, 6), (9, 11)]
+    for _, _, frame_ids, owner in res:
+        assert frame_ids == [float(i) for i in range(11)]
+        assert owner == [0.0] * 3 + [1.0] * 3 + [0.0] * 3 + [1.0] * 2
+
+
+def test_object_configs_match_the_reference_shell_files():
+    objs = parallel.load_object_configs()
+    assert len(objs) == 8 and {o["name"] for o in objs} >= {"premier_protein", "cracker_box", "gimble"}
+    pp = next(o for o in objs if o["name"] == "premier_protein")
+    assert pp["OBJ_AABB"] == [[0.359, -0.248, 0.047], [0.627, 0.223, 0.574]] and pp["UPRIGHT_REF_IMG"] == "mapping/IMG_2520.png"
+    for o in objs:  # boxes come out ordered even where the shell file has them swapped (motor_core)
+        assert all(a < b for a, b in zip(*o["aabb"]))

@@ -1,0 +1,110 @@
+"""BASELINE configs[2]: YCB policy at 640x480 on the unit-cube (cracker_box) object.
+(1) one frame, HIP vs the CPU oracle's fixture (tests/golden/ycb_640x480.npz, two-render path:
+mask camera != reference camera at reference_scale 0.3); (2) a short sequence from an on-disk
+YCB-Video-layout dataset through the reference's command line, ADD-S and the GetMetrics figures
+against the synthetic ground truth."""
+import pickle
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from pixtrack_amd import evaluation
+from pixtrack_amd.geometry import Camera, Pose
+from pixtrack_amd.pose_trackers import pixloc_tracker_ycb as ycb
+from pixtrack_amd.synthetic import CRACKER_BOX_AABB, make_tracking_assets, render_query_frames, surface_points, ngp_to_sfm_points
+from pixtrack_amd.utils.io import YCBVideoIterator, write_ycb_sequence
+from pixtrack_amd.utils.pose_utils import geodesic_distance_for_rotations
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden" / "ycb_640x480.npz"
+
+
+def _assets(seed, n_frames, **kw):
+    return make_tracking_assets(seed=seed, width=640, height=480, n_frames=n_frames, aabb=CRACKER_BOX_AABB,
+                                reference_scale=0.3, n_points=5600, **kw)
+
+
+def _camera(assets):
+    f = float(assets["query_camera"]["params"][0])
+    return Camera.from_colmap(dict(model="OPENCV", width=640, height=480, params=np.array([f, f, 319.5, 239.5])))
+
+
+def test_ycb_frame_matches_oracle_fixture(device):
+    g = np.load(GOLDEN)
+    assets = _assets(int(g["seed"]), 12)
+    assert np.array_equal(np.stack([p[0] for p in assets["gt_poses"]]), g["gt_R"])
+    tr = ycb.PixLocPoseTrackerYCB("", "", "/tmp", "003_cracker_box", debug=True, device=device, assets=assets)
+    # render box from the SfM points, not a config value (pixloc_tracker_ycb.py:92)
+    assert np.allclose(np.array([tr.testbed.render_aabb.min, tr.testbed.render_aabb.max]), g["aabb"], atol=1e-6)
+    assert tr.reference_scale == 0.3 and tr.reference_ids is None
+    cam = _camera(assets)
+    # frame 0 (cold start) initialises from the GT it is given: hand it the fixture's start pose
+    start = Pose.from_Rt(g["R0"], g["t0"])
+    query = torch.from_numpy(g["query"].astype(np.float32)).to(device)
+    ok = tr.refine(("000001-color.png", query, start, cam))
+    assert tr.reference_ids == [int(g["ref_id"])] and not tr._views_coincide()
+    ret = tr.pose_history["000001-color.png"]
+    assert ok and ret["success"]
+    R, t = ret["T_refined"].numpy()
+    assert geodesic_distance_for_rotations(R, g["R"]) < 1e-3 and np.linalg.norm(t - g["t"]) < 1e-3
+    assert ret["cost"] == pytest.approx(float(g["cost"]), rel=0.03)
+    mask = tr.localizer.refiner.query_mask.cpu().numpy()
+    want = np.unpackbits(g["mask_bits"])[: 640 * 480].reshape(480, 640)
+    assert int(mask.sum()) == int(g["mask_sum"]) and int((mask != want).sum()) == 0
+    rgba = tr.testbed  # reference render at the start pose: SfM camera 1 x 0.3
+    from pixtrack_amd.visualization.run_vis_on_poses import get_nerf_image_device
+
+    img = get_nerf_image_device(tr.testbed, tr._nerf_pose(start), tr._reference_camera(), spp=8).cpu().numpy()
+    d = np.abs(img - g["ref_rgba"].astype(np.float32))
+    assert d.max() < 1e-2 and d.mean() < 5e-4, (d.max(), d.mean())
+
+
+def test_ycb_cli_sequence_adds_and_metrics(device, tmp_path, monkeypatch, capsys):
+    from pixtrack_amd.synthetic import write_object_dir
+
+    n = 12
+    # The notebook's metric first aligns the two translation tracks (the `t` of world->camera poses) with
+    # a similarity fit.  A camera orbiting an object centred at the origin has a CONSTANT t, which makes
+    # that fit degenerate: give the synthetic track a translation component (4 % of the distance per frame).
+    assets = _assets(1022, n, step_deg=1.0, jitter_trans=0.04)
+    # frames = NeRF renders with the YCB camera (principal point 319.5/239.5 == the synthetic centre - 0.5)
+    probe = ycb.PixLocPoseTrackerYCB("", "", "/tmp", "003_cracker_box", device=device, assets=assets)
+    frames = render_query_frames(assets, probe.testbed, first_frame_sigma=None)
+    f = float(assets["query_camera"]["params"][0])
+    K = np.array([[f, 0, 312.26], [0, f, 241.3], [0, 0, 1.0]])  # the dataset's own principal point is ignored
+    root, obj = tmp_path / "ycb", tmp_path / "003_cracker_box"
+    write_ycb_sequence(root, 7, frames, assets["gt_poses"], K, class_id=2)
+    write_object_dir(assets, obj)
+    it = YCBVideoIterator(obj, "7/:3", root)
+    assert len(it) == 3
+    path, image, pose, cam = next(it)
+    assert str(path).endswith("0007/000001-color.png") and image.dtype == np.float32 and image.shape == (480, 640, 3)
+    assert np.allclose(pose.numpy()[0], assets["gt_poses"][0][0]) and np.allclose(cam.c.numpy(), [319.0, 239.0])
+    monkeypatch.delenv("UPRIGHT_REF_IMG", raising=False)
+    monkeypatch.delenv("OBJ_AABB", raising=False)  # the YCB variant needs neither
+    out = tmp_path / "out"
+    ycb.main(["--object_path", str(obj), "--query", "7", "--out_dir", str(out), "--ycb_root", str(root), "--debug"])
+    text = capsys.readouterr().out
+    assert "Relocalization count:  1" in text and text.rstrip().endswith("Done")
+    poses = pickle.loads((out / "poses.pkl").read_bytes())
+    assert len(poses) == n and all(r["success"] and "gt_pose" in r for r in poses.values())
+    # model points of the synthetic object in the SfM frame
+    verts = ngp_to_sfm_points(surface_points(np.random.default_rng(0), 2000, CRACKER_BOX_AABB)[0])
+    extent = float(np.linalg.norm(verts.max(0) - verts.min(0)))
+    adds = []
+    for r in poses.values():
+        adds.append(evaluation.adds_distance(evaluation.get_pose_mat_from_tensor(r["T_refined"]),
+                                             evaluation.get_pose_mat_from_tensor(r["gt_pose"]), verts))
+    assert max(adds) < 0.02 * extent, (max(adds), extent)  # ADD-S below 2 % of the object's diameter on every frame
+    # the notebook's GetMetrics runs on the CLI's poses.pkl.  Its similarity alignment of the translation
+    # tracks amplifies a 1e-3 pose error by (camera distance / spread of the track) - ~100x on this short
+    # synthetic orbit - so its thresholds are not asserted here (tests/test_formats.py pins the function);
+    # against itself the file is perfect
+    vh = np.concatenate([verts, np.ones((len(verts), 1))], 1)
+    m = evaluation.get_metrics(poses, vh, tr_threshold=5.0, rot_threshold=5.0)
+    assert m["total_frames"] == n and 0.0 <= m["accuracy"] <= 1.0 and np.isfinite(m["average_error_vertices"])
+    perfect = {k: dict(v, T_refined=v["gt_pose"]) for k, v in poses.items()}
+    m0 = evaluation.get_metrics(perfect, vh, tr_threshold=5.0, rot_threshold=5.0)
+    assert m0["bad_count"] == 0 and m0["average_error_vertices"] < 1e-6
