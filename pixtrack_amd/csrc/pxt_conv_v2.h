@@ -16,7 +16,9 @@
 //  * a wave owns CW x PBW MFMA tiles (up to 64 output channels x 128 pixels): one A fragment feeds
 //    PBW MFMAs and one B fragment CW of them, which halves LDS and L1 traffic per MFMA;
 //  * the epilogue pairs half-waves with v_permlane32_swap so every lane stores 16 contiguous bytes,
-//    and can write the 2x2 max-pooled copy of its tile (the encoder's next input) as well.
+//    and can write the 2x2 max-pooled copy of its tile (the encoder's next input) as well.  (Plain
+//    stores: non-temporal and write-through (sc1) output stores were measured against them to shorten
+//    the end-of-kernel L2 write-back - both made the two-image pass 7 % slower, 1.04 vs 0.97 ms.)
 #pragma once
 
 #include <type_traits>
