@@ -205,3 +205,96 @@ def test_adds_is_zero_under_a_model_symmetry():
     assert evaluation.adds_distance(T1, T0, verts) < 1e-12
     T1[:3, 3] = [0.1, 0, 0]
     assert abs(evaluation.adds_distance(T1, T0, verts) - 0.1) < 1e-12
+
+
+def test_overlay_drawing_helpers():
+    """Host-side pieces of the overlay renderer (reference run_vis_on_poses.py:60-253): projection with the
+    centred pinhole, blend weights, axes / centre / text drawn where the pose puts them."""
+    from pixtrack_amd.geometry import Camera
+    from pixtrack_amd.visualization import run_vis_on_poses as V
+
+    cam = Camera.from_colmap(dict(model="SIMPLE_RADIAL", width=64, height=48, params=np.array([80.0, 32.0, 24.0, 0.0])))
+    K = V.pinhole_K(cam)
+    assert np.allclose(K, [[80, 0, 32], [0, 80, 24], [0, 0, 1]])
+    assert np.allclose(V.project_3d_to_2d(np.array([[0.0, 0.0, 2.0], [0.5, -0.25, 2.0]]), K), [[32, 24], [52, 14]])
+    q, n = np.full((48, 64, 3), 200, np.uint8), np.full((48, 64, 3), 100, np.uint8)
+    assert (V.blend_images(q, n) == 130).all()  # 0.3 * query + 0.7 * render
+    cIw = np.eye(4)
+    cIw[:3, 3] = [0.0, 0.0, -2.0]  # camera 2 units in front of the origin, looking along +z
+    img = V.add_pose_axes(np.zeros((48, 64, 3), np.uint8), cam, cIw, [0, 0, 0, 0], length=0.25, thickness=1)
+    assert tuple(img[24, 37]) == (0, 0, 255)   # +x axis: to the right of the centre, the reference's BGR (255,0,0)
+    assert tuple(img[19, 32]) == (0, 255, 0)   # -y axis: upwards
+    assert img[30:, :].sum() == 0
+    dot = V.add_object_center(np.zeros((48, 64, 3), np.uint8), cam, cIw, [0.0, 0.0, 0.0])
+    assert tuple(dot[24, 32]) == (255, 255, 255) and dot[:15].sum() == 0
+    txt = V.add_text_lines(np.zeros((48, 64, 3), np.uint8), ["Rotation error: 0.1000 degrees"], origin=(2, 2))
+    assert txt[..., 2].sum() > 0 and txt[..., 0].sum() == 0
+    inset = V.add_reference_image(np.zeros((48, 64, 3), np.uint8), np.full((40, 80, 3), 90, np.uint8), "mapping/0001.png")
+    assert (inset[0, :16] == 90).all() and (inset[20:, 20:] == 0).all()
+
+
+def test_reference_feature_cache_h5_branch_with_an_api_mock(tmp_path, monkeypatch):
+    """the `.h5` branch of read_features / write_features (reference
+    pixloc_pose_refiners.py:175-198).  h5py is not in this image, so the branch runs against a small
+    in-memory mock of the h5py calls it makes (File context manager, nested groups, create_dataset, keys):
+    this executes the hierarchy logic f[ref_id][scale]["p3dids"] / [level]["p3did_to_feat"]; real HDF5
+    I/O stays untested here."""
+    import sys
+    import types
+
+    store = {}
+
+    class Node(dict):
+        def create_dataset(self, key, data=None):
+            node = self
+            parts = key.split("/")
+            for p_ in parts[:-1]:
+                node = node.setdefault(p_, Node())
+            node[parts[-1]] = np.asarray(data)
+
+    class File(Node):
+        def __init__(self, path, mode="r"):
+            super().__init__()
+            self.path, self.mode = path, mode
+            if mode == "r":
+                self.update(store[path])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            if self.mode == "w":
+                store[self.path] = Node(self)
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    from pixtrack_amd import refiner as RF
+    from pixtrack_amd.unet import OUTPUT_DIMS
+
+    class P3D:
+        def __init__(self, xyz):
+            self.xyz = xyz
+
+    r = RF.PoseTrackerRefiner.__new__(RF.PoseTrackerRefiner)
+    r.paths = {"dumps": tmp_path}
+    r.conf = types.SimpleNamespace(multiscale=[1])
+    r.device = torch.device("cpu")
+    r.model3d = types.SimpleNamespace(points3D={i: P3D(np.array([i, 2 * i, 3 * i], float)) for i in range(7)})
+    rng = np.random.default_rng(0)
+    ids = [5, 1, 3, 6]
+    packed = []
+    for c in OUTPUT_DIMS:
+        rec = torch.zeros(len(ids), RF.cstride_for(c))
+        d = torch.from_numpy(rng.normal(size=(len(ids), c)).astype(np.float32))
+        rec[:, :c] = d / d.norm(dim=1, keepdim=True)
+        rec[:, c] = torch.from_numpy(rng.uniform(size=len(ids)).astype(np.float32))
+        packed.append(rec)
+    feats = RF.SparseReferenceFeatures(packed, torch.tensor([1, 1, 0, 1], dtype=torch.uint8), ids, torch.zeros(4, 3), OUTPUT_DIMS)
+    written = r.write_features({9: {"1": feats}})
+    assert written.endswith("reference_features.h5") and written in store
+    (tmp_path / "reference_features.h5").write_bytes(b"")  # the reader looks for the file's existence
+    back = r.read_features(9)["1"]
+    assert back.p3dids_all == [5, 1, 6]  # the invalid point was dropped by the writer
+    for lvl, c in enumerate(OUTPUT_DIMS):
+        assert torch.allclose(back.packed[lvl][:, : c + 1], packed[lvl][[0, 1, 3], : c + 1], atol=1e-6)
+    assert np.allclose(back.p3d.numpy(), [[5, 10, 15], [1, 2, 3], [6, 12, 18]])
