@@ -90,6 +90,16 @@ def depth_mask(depth_rgba: np.ndarray) -> np.ndarray:
     return m
 
 
+def fragile_depth_pixels(depth_rgba: np.ndarray, margin: float = 0.05) -> np.ndarray:
+    """Pixels whose `uint8(depth * 255) != 0` decision (get_mask; the uint8 cast wraps mod 256,
+    run_vis_on_poses.py:53-54) lies within ``margin`` grey levels of flipping: v = depth * 255 near 1 from
+    either side, or near a multiple of 256.  Exact zeros (rays that miss) and tiny values cannot flip.
+    Only at these pixels may fp32 summation order inside the MLPs change a mask bit."""
+    v = depth_rgba[..., 0].astype(np.float64) * 255.0
+    m = np.mod(v, 256.0)
+    return (np.abs(v - 1.0) < margin) | ((v > 128.0) & ((m < margin) | (m > 256.0 - margin) | (np.abs(m - 1.0) < margin)))
+
+
 def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndarray, ref_id: int,
                 multiscale=(1,), use_mask: bool = True, lm_conf: Optional[LO.LMConf] = None,
                 timings: Optional[Dict[str, float]] = None, spp: int = 8, keep: Optional[Dict] = None,

@@ -38,11 +38,7 @@ def oracle_query(assets, ngp, R, t, sigma, rng):
 
 
 def fragile_pixels(depth_rgba):
-    """`floor(v) mod 256 != 0` with v = depth * 255 flips where v crosses 1 (from below) or a multiple
-    of 256; exact zeros (rays that miss) and tiny positive values cannot flip."""
-    v = depth_rgba[..., 0].astype(np.float64) * 255.0
-    m = np.mod(v, 256.0)
-    return (np.abs(v - 1.0) < 0.05) | ((v > 128.0) & ((m < 0.05) | (m > 255.95) | (np.abs(m - 1.0) < 0.05)))
+    return FO.fragile_depth_pixels(depth_rgba)
 
 
 def refresh_fragile():

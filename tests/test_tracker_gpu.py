@@ -49,21 +49,40 @@ def test_masked_frame_matches_oracle(tracked):
     assets, tr, frames, states = tracked
     (R0, t0), ref_ids, _, ok = states[1]
     assert ok
-    want = FO.track_frame(assets, R0, t0, frames[1].cpu().numpy(), ref_ids[0], multiscale=(1,), use_mask=True, spp=2)
+    keep = {}
+    want = FO.track_frame(assets, R0, t0, frames[1].cpu().numpy(), ref_ids[0], multiscale=(1,), use_mask=True, spp=2,
+                          keep=keep)
     ret = tr.pose_history["000001.png"]
     R, t = ret["T_refined"].numpy()
     assert geodesic_distance_for_rotations(R, want["R"].numpy()) < 1e-3
     assert np.linalg.norm(t - want["t"].numpy()) < 1e-3
     assert ret["cost"] == pytest.approx(want["cost"], rel=0.03)
-    # the device mask equals the cv2-semantics mask of the oracle (a few edge pixels may flip
-    # where the composited depth sits within float noise of 1/255)
+    # The mask is byte work: bit-exact.  The only legitimate differences are pixels where the oracle's own
+    # depth sits within 0.05 grey levels of the `uint8 != 0` decision (FO.fragile_depth_pixels): check the
+    # decision bits before the morphology against that set, and demand an identical mask when none flipped.
+    from pixtrack_amd.geometry import Pose
+    from pixtrack_amd.visualization.run_vis_on_poses import get_nerf_image_device
+
+    pose = Pose.from_Rt(R0, t0)
+    depth = get_nerf_image_device(tr.testbed, tr._nerf_pose(pose), tr.camera, depth=True, spp=2).cpu().numpy()
+    nz = (FO.to_u8(depth)[..., 0] != 0)
+    want_nz = (FO.to_u8(keep["depth_rgba"])[..., 0] != 0)
+    flips = nz != want_nz
+    assert not (flips & ~FO.fragile_depth_pixels(keep["depth_rgba"])).any()
     tr.localizer.refiner.query_mask = None
     saved = tr.pose
-    from pixtrack_amd.geometry import Pose
-    tr.pose = Pose.from_Rt(R0, t0)
+    tr.pose = pose
     mask = tr.get_mask(tr.pose).cpu().numpy()
     tr.pose = saved
-    assert (mask != want["mask"]).mean() < 2e-3 and 0.02 < mask.mean() < 0.9
+    assert 0.02 < mask.mean() < 0.9
+    if not flips.any():
+        assert int((mask != want["mask"]).sum()) == 0
+    else:  # a fragile pixel flipped: the masks may differ only inside its 5x5-erode / 5x(5x5)-dilate footprint
+        ys, xs = np.nonzero(flips)
+        far = np.ones_like(mask, bool)
+        for y, x in zip(ys, xs):
+            far[max(0, y - 12):y + 13, max(0, x - 12):x + 13] = False
+        assert int(((mask != want["mask"]) & far).sum()) == 0
 
 
 def test_tracking_follows_ground_truth_and_history(tracked):
