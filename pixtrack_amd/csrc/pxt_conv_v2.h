@@ -28,6 +28,19 @@ namespace pxt {
 constexpr int kV2RowBytes = 1280;  // LDS pitch of a halo row: 20 pixel records (18 used) = 5 x 256 B
 constexpr int kV2Cols = 18;        // tile width 16 + 2
 
+// Optional fused epilogue of the LAST decoder layer (32 channels, one cout block per workgroup): the
+// fine 1x1 head (descriptor rows 0..31 on MFMA + the uncertainty row as a dot product), L2
+// normalisation, confidence = sigmoid(-x), float32 HWC record.  The layer's own fp16 output is then
+// never written: nothing else reads it.
+struct FusedHead {
+  const half8* wfrag;    // [2 k-steps][64 lanes]: head rows 0..31 with columns in accumulator-register order
+  const float* conf_w;   // [32] uncertainty-row weights (fp16-rounded), channel order
+  const float* bias;     // [33]
+  float* out[PXT_UNET_MAX_BATCH];
+  int normalize[PXT_UNET_MAX_BATCH];
+  int cstride, enabled;
+};
+
 struct ConvArgs {
   const half_t* in;      // [n_img][H][W][Cin]  (UPCAT: the skip tensor [n_img][Hs][Ws][Cin - Cp])
   int H, W, Cin;
@@ -38,6 +51,7 @@ struct ConvArgs {
   float* partial;        // split-K slabs [z][n_img][H][W][Cout] (gridDim.z > 1)
   UpSrc up;
   half_t* pool;          // optional [n_img][H/2][W/2][Cout]: 2x2 max-pool of `out` (gridDim.z == 1 only)
+  FusedHead head;        // head.enabled: Cout == 32, gridDim.z == 1
 };
 
 // Host-side mirror of the packed layout: element (cout, tap, cin) lives at
@@ -95,8 +109,13 @@ __device__ inline unsigned pool2x2_pk(unsigned v) {
 // (launch bounds: the UPCAT variants ask for ONE wave per SIMD only so that the register allocator
 // does not spill -- with the 256-register cap it schedules itself into 51 spills, uncapped it needs
 // 228 registers, which still runs two waves per SIMD.)
-template <int CW, int PBW, int WC, int WP, bool UPCAT>
-__global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(const ConvArgs a) {
+// AR = depth of the filter-fragment ring (fragments travel AR - 1 steps ahead).  3 covers an L2 hit
+// when two or three waves share a SIMD; the deep layers (60x80 and 30x40 maps: <= 1 workgroup per CU,
+// 2.4-4.7 MB of taps per layer that every workgroup streams once, cold) use 9 with one wave per SIMD:
+// their loop was bound by the miss latency of each new fragment, not by the matrix pipe.
+template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3>
+__global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const ConvArgs a) {
+  static_assert(18 % AR == 0, "the ring is indexed by the step modulo AR at compile time");
   static_assert(WC * WP == 4, "four waves per workgroup");
   constexpr int TH = 2 * PBW * WP, HR = TH + 2;
   constexpr int BNC = 32 * CW * WC;
@@ -283,7 +302,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(const ConvArgs a) {
   // Explicit software pipeline: filter fragments travel AR - 1 steps ahead of their use (an L2 hit
   // is ~300-500 cycles under load, one step only 4-8 MFMAs), pixel fragments one step ahead (LDS).
   // The rings are indexed with compile-time constants (18 steps per chunk, 18 % AR == 0).
-  constexpr int AR = 3;
   half8 a_q[AR][CW], b_q[2][PBW];
   const int n_steps = (ch_end - ch_begin) * 18;
   if (n_steps > 0) {
@@ -358,6 +376,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v2_kernel(const ConvArgs a) {
         for (int g = 0; g < 4; ++g)
           *(float4*)(pd + 32 * c + 8 * g + 4 * khalf) =
               make_float4(acc[c][p][4 * g + 0], acc[c][p][4 * g + 1], acc[c][p][4 * g + 2], acc[c][p][4 * g + 3]);
+      continue;
+    }
+    if (CW == 1 && a.head.enabled) {  // workgroup-uniform
+      // bias + ReLU + fp16: the 16 accumulator registers ARE the two B fragments of the head's GEMM
+      // (its weight columns were permuted to this register order when the context was created)
+      half8 hb[2];
+      float cdot = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const half_t hv = (half_t)fmaxf(acc[0][p][r] + a.bias[ch], 0.f);
+        hb[r >> 3][r & 7] = hv;
+        cdot += (float)hv * a.head.conf_w[ch];
+      }
+      f32x16 hd = {0};
+      hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.head.wfrag[lane], hb[0], hd, 0, 0, 0);
+      hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.head.wfrag[64 + lane], hb[1], hd, 0, 0, 0);
+      float ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hd[r] += a.head.bias[(r & 3) + 8 * (r >> 2) + 4 * khalf];
+        ss += hd[r] * hd[r];
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      cdot += __shfl_xor(cdot, 32, 64);
+      const float inv = a.head.normalize[img] ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+      if (inside) {
+        float* o = a.head.out[img] + ((size_t)gy * W + gx) * a.head.cstride;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(o + 8 * g + 4 * khalf) = make_float4(hd[4 * g] * inv, hd[4 * g + 1] * inv, hd[4 * g + 2] * inv, hd[4 * g + 3] * inv);
+        if (khalf == 0) *(float4*)(o + 32) = make_float4(1.f / (1.f + expf(cdot + a.head.bias[32])), 0.f, 0.f, 0.f);
+      }
       continue;
     }
     half_t* dst = out + ((size_t)gy * W + gx) * Cout + cw0;

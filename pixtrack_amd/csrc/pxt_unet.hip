@@ -83,37 +83,52 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstImages imgs,
     }
   }
   __syncthreads();
-  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  float in[27];
+  // One wave per strip row (64 pixels = two 32-pixel MFMA column blocks), all 64 output channels:
+  // exact-f32 matrix FMAs v_mfma_f32_32x32x2_f32, K = 27 taps padded to 28 = 14 instructions per
+  // 32x32 tile.  The result is bit for bit the k-ordered fmaf chain acc = fma(in_k, w_k, acc), k = 0..26,
+  // started from the bias - what the scalar loop of the first version computed at a quarter of the rate
+  // (its 27 x 64 weights had to stream through the SGPR file).
+  static_assert(COUT == 64, "two 32-row blocks");
+  const int lane = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int r31 = lane & 31, khalf = lane >> 5;
+  float wa[14][2];  // A operand: row = output channel 32 cb + r31, k = 2 kp + khalf
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int kp = 0; kp < 14; ++kp) {
+    const int k = 2 * kp + khalf;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) in[(ky * 3 + kx) * 3 + c] = s_px[((ly + ky) * (kFW + 2) + lx + kx) * 3 + c];
-  // this pixel's record in the LDS tile: COUT halves = COUT/8 16-B pieces, piece index XOR-ed with
-  // the pixel's low bits (thread = pixel writes would otherwise all land on the same banks)
+    for (int cb = 0; cb < 2; ++cb) wa[kp][cb] = k < 27 ? wts[(size_t)(32 * cb + r31) * 27 + k] : 0.f;
+  }
   constexpr int kPieces = COUT / 8;
-  half_t* rec = s_out + (size_t)threadIdx.x * COUT;
-#pragma unroll 1
-  for (int cg = 0; cg < COUT / 16; ++cg) {  // uniform: wts / bias below are scalar loads
-    const float* wg = wts + (size_t)cg * 16 * 27;
-    float acc[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
-    // same accumulation order as a k-major loop per output channel: acc_j += in_k * w_jk, k = 0..26
+  for (int pb = 0; pb < 2; ++pb) {
+    const int lx = 32 * pb + r31;
+    f32x16 acc[2];
 #pragma unroll
-    for (int k = 0; k < 27; ++k)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] += in[k] * wg[j * 27 + k];
-    half8 o0, o1;
+      for (int r = 0; r < 16; ++r) acc[cb][r] = bias[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * khalf];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o0[j] = (half_t)fmaxf(acc[j], 0.f);
-      o1[j] = (half_t)fmaxf(acc[8 + j], 0.f);
+    for (int kp = 0; kp < 14; ++kp) {
+      const int k = 2 * kp + khalf;  // (ky, kx, c) = (k / 9, (k / 3) % 3, k % 3)
+      const int kk = k < 27 ? k : 0;
+      const float bv = s_px[((ly + kk / 9) * (kFW + 2) + lx + (kk / 3) % 3) * 3 + kk % 3];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kp][cb], bv, acc[cb], 0, 0, 0);
     }
-    *(half8*)(rec + (((2 * cg) ^ (int)(threadIdx.x & (kPieces - 1))) << 3)) = o0;
-    *(half8*)(rec + (((2 * cg + 1) ^ (int)(threadIdx.x & (kPieces - 1))) << 3)) = o1;
+    // D[row = channel][col = pixel]: this lane holds pixel lx, channels (r&3) + 8 (r>>2) + 4 khalf of each block;
+    // ReLU, fp16, into the pixel's record of the XOR-swizzled LDS tile (16-B pieces of 8 channels)
+    const int t = ly * kFW + lx;
+    half_t* rec = s_out + (size_t)t * COUT;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf(acc[cb][4 * g + j], 0.f);
+        const int piece = 4 * cb + g;  // channels 32 cb + 8 g .. + 7; this lane owns the half 4 khalf .. + 3
+        *(half4*)(rec + ((piece ^ (t & (kPieces - 1))) << 3) + 4 * khalf) = o;
+      }
   }
   __syncthreads();
   // coalesced write-out: the strip's row `ry` is kFW * COUT contiguous halves in global memory
@@ -282,6 +297,7 @@ struct pxt_unet {
   const pxt::half_t* head_w[pxt::kNumHeads];
   const float* head_b[pxt::kNumHeads];
   void* dev_blob = nullptr;
+  void* dev_head0 = nullptr;           // fine head fused into the last decoder layer: frags | conf_w | bias
   void* dev_packed = nullptr;          // conv taps in MFMA A-fragment order (pxt_conv_v2.h)
   const pxt::half_t* conv_packed[pxt::kNumConv];
   int64_t n_bytes = 0;
@@ -394,16 +410,16 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
   return true;
 }
 
-template <int CW, int PBW, int WC, int WP, bool UPCAT>
+template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3>
 void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
   constexpr int lds = 2 * (2 * PBW * WP + 2) * kV2RowBytes + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0);
   static bool attr_done = false;  // the double-buffered halo of the 32-row tiles exceeds the 64 KiB default
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT>,
+    (void)hipFuncSetAttribute((const void*)conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>), grid, dim3(256), lds, s, a);
 }
 
 void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_t s) {
@@ -416,8 +432,13 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
     else launch_v2<1, 2, 1, 4, true>(a, grid, s);
     return;
   }
+  // <= 1 workgroup per CU: nothing hides a miss on the streamed taps but a deeper fragment ring
+  const bool deep = (long long)grid.x * grid.y * grid.z <= 256;
   switch (cfg) {
-    case 1: launch_v2<2, 4, 2, 2, false>(a, grid, s); break;
+    case 1:
+      if (deep) launch_v2<2, 4, 2, 2, false, 9>(a, grid, s);
+      else launch_v2<2, 4, 2, 2, false>(a, grid, s);
+      break;
     case 2: launch_v2<2, 2, 1, 4, false>(a, grid, s); break;
     case 4: launch_v2<2, 2, 2, 2, false>(a, grid, s); break;
     default: launch_v2<1, 2, 1, 4, false>(a, grid, s); break;
@@ -428,7 +449,8 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
 // output when the layer runs without split-K; returns (through *pooled) whether it was written.
 int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const half_t* in, int H, int W, half_t* out,
                 hipStream_t s, int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr,
-                half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0) {
+                half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0,
+                const FusedHead* head = nullptr) {
   if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
@@ -439,6 +461,12 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   a.out = out; a.partial = partial;
   a.up = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
   a.pool = cp.splits == 1 ? pool_out : nullptr;
+  std::memset(&a.head, 0, sizeof(a.head));
+  if (head) {
+    if (cout != 32 || cp.splits != 1 || cfg_bnc(cp.cfg) != 32) return PXT_E_ARG;
+    a.head = *head;
+    a.head.enabled = 1;
+  }
   if (pooled) *pooled = a.pool != nullptr;
   const dim3 grid(cp.tiles, cp.nb, cp.splits);
   launch_v2_cfg(cp.cfg, up != nullptr, a, grid, s);
@@ -546,6 +574,27 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
       ctx->head_b[i] = (const float*)((const char*)ctx->dev_head + offs_b[i]);
     }
   }
+  // fine head in the form the last decoder layer's epilogue consumes (pxt_conv_v2.h FusedHead)
+  if (ctx->head[0].cin == 32 && ctx->head[0].cout == 32 && ctx->conv[n_conv - 1].cout == 32) {
+    const float* Wsrc = (const float*)(p + table[4 * n_conv]);      // [cin 32][33]
+    const float* bsrc = (const float*)(p + table[4 * n_conv + 2]);  // [33]
+    std::vector<char> hb(2 * 64 * 8 * sizeof(half_t) + 32 * sizeof(float) + 36 * sizeof(float));
+    half_t* fr = (half_t*)hb.data();
+    float* cw = (float*)(hb.data() + 2 * 64 * 8 * sizeof(half_t));
+    float* bb = cw + 32;
+    for (int s2 = 0; s2 < 2; ++s2)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * s2 + j, kh = lane >> 5, row = lane & 31;
+          const int ch = (r & 3) + 8 * (r >> 2) + 4 * kh;  // channel held in accumulator register r
+          fr[((size_t)s2 * 64 + lane) * 8 + j] = (half_t)Wsrc[(size_t)ch * 33 + row];
+        }
+    for (int c = 0; c < 32; ++c) cw[c] = (float)(half_t)Wsrc[(size_t)c * 33 + 32];
+    for (int i = 0; i < 33; ++i) bb[i] = bsrc[i];
+    e = hipMalloc(&ctx->dev_head0, hb.size());
+    if (e == hipSuccess) e = hipMemcpy(ctx->dev_head0, hb.data(), hb.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_last_error("fused head", e); pxt_unet_destroy(ctx); return PXT_E_HIP; }
+  }
   *out_ctx = ctx;
   return PXT_OK;
 }
@@ -555,6 +604,7 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (ctx->dev_blob) (void)hipFree(ctx->dev_blob);
   if (ctx->dev_head) (void)hipFree(ctx->dev_head);
   if (ctx->dev_packed) (void)hipFree(ctx->dev_packed);
+  if (ctx->dev_head0) (void)hipFree(ctx->dev_head0);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->ev_enc4) (void)hipEventDestroy(ctx->ev_enc4);
   if (ctx->ev_dec1) (void)hipEventDestroy(ctx->ev_dec1);
@@ -676,6 +726,7 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_enc4, 0));
   launch_head(2, ctx->side);
   const half_t* prev = skip[4];
+  bool head0_fused = false;
   int ph = P.h[4], pw = P.w[4], pc = ctx->conv[12].cout;
   for (int d = 0; d < 4; ++d) {
     const UnetLayer& L = ctx->conv[13 + d];
@@ -684,8 +735,21 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     if (cs <= 0) return PXT_E_ARG;
     const UpSrc up{prev, ph, pw, pc, P.h[sb], P.w[sb]};  // upsample + concat happen in the conv's staging
     half_t* o = buf(P.dec_out[d]);
+    FusedHead fh;
+    const bool fuse_head = d == 3 && ctx->dev_head0 != nullptr && out_cstride[0] >= 36;
+    if (fuse_head) {  // the fine head runs in this layer's epilogue; its own output is not materialised
+      const char* hb = (const char*)ctx->dev_head0;
+      fh.wfrag = (const half8*)hb;
+      fh.conf_w = (const float*)(hb + 2 * 64 * 8 * sizeof(half_t));
+      fh.bias = fh.conf_w + 32;
+      for (int im = 0; im < B; ++im) { fh.out[im] = out_maps[3 * im]; fh.normalize[im] = normalize[im]; }
+      fh.cstride = out_cstride[0];
+      fh.enabled = 1;
+      head0_fused = true;
+    }
     int rc = launch_conv(L.cin, L.cout, ctx->conv_packed[13 + d], L.b, skip[sb], P.dh[d], P.dw[d], o, s, 1,
-                         (float*)(ws + P.splitk), B, &up);
+                         fuse_head ? nullptr : (float*)(ws + P.splitk), B, &up, nullptr, nullptr, 0, 0,
+                         fuse_head ? &fh : nullptr);
     if (rc != PXT_OK) return rc;
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
@@ -698,7 +762,7 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   }
   // (the heads were launched above: the two coarse ones on the side stream as soon as their input
   // existed, the fine one here)
-  launch_head(0, s);
+  if (!head0_fused) launch_head(0, s);
   PXT_HIP_CHECK(hipEventRecord(ctx->ev_side, ctx->side));
   PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_side, 0));
   PXT_HIP_CHECK(hipGetLastError());
