@@ -140,44 +140,65 @@ def _timed_frames(tracker, frames, names, lo, hi):
     return (hi - lo) / dt, ok
 
 
-def run_extras(tracker, frames, names, first, dev):
-    """Untimed-by-contract extra passes over later frames of the same sequence (N = 1 only):
-    the same loop (a) when the mask and the reference image need TWO renders - the real-asset case,
-    where SfM camera 1 x reference_scale differs from the query camera (pixloc_tracker_r9.py:145-152),
-    (b) with the frames arriving from pinned HOST memory (H2D copy inside the loop, as the reference's
-    ImageIterator hands frames over) and --debug 1 (the shipped run_inference.sh setting),
-    (c) over 200 frames (the per-frame cost drifts along the synthetic orbit)."""
+def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, dev):
+    """Extra passes that say what the headline leaves out (N = 1 only; outside the contract's timed region):
+    (a) `value_two_renders`: the mask and the reference image need TWO renders - the real-asset case, where
+        SfM camera 1 x reference_scale differs from the query camera (pixloc_tracker_r9.py:145-152);
+    (b) `value_host_frames_debug1`: frames arrive from pinned HOST memory (H2D copy inside the loop, as the
+        reference's ImageIterator hands frames over) and --debug 1 (the shipped run_inference.sh setting);
+    both REPLAY the frames of the timed region (same warm-up frames, same timed frames) on a fresh tracker,
+    so they compare with `value` frame for frame;
+    (c) `value_k200`: the headline configuration over the 200 frames that follow (the per-frame cost drifts
+        along the synthetic orbit as the object turns its broad side to the camera)."""
     import gc
 
+    from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+
+    out = {}
+
+    def replay(setup, make_frame):
+        tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets)
+        setup(tr)
+        fr = [make_frame(frames[i]) for i in range(n_timed_end)]
+        for i in range(warmup):
+            tr.run_single_frame((names[i], fr[i]))
+        gc.collect()
+        gc.disable()
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(warmup, n_timed_end):
+                tr.run_single_frame((names[i], fr[i]))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        n = n_timed_end - warmup
+        ok = sum(1 for i in range(warmup, n_timed_end) if tr.pose_history[names[i]].get("success"))
+        return round(n / dt, 2), n, ok
+
+    def two_renders(tr):
+        tr.fuse_identical_views = False
+
+    fps, n, ok = replay(two_renders, lambda f: f)
+    out["value_two_renders"] = {"frames_per_s": fps, "frames": n, "tracked_ok": ok,
+                                "what": "same frames as `value`; mask (Depth) and reference (Shade) rendered separately"}
+
+    def debug1(tr):
+        tr.debug = 1
+
+    fps, n, ok = replay(debug1, lambda f: f.cpu().pin_memory())
+    out["value_host_frames_debug1"] = {"frames_per_s": fps, "frames": n, "tracked_ok": ok,
+                                       "what": "same frames as `value`, float32 in pinned host memory (3.7 MB H2D per "
+                                               "frame inside the loop), DebugTracker at --debug 1"}
     gc.collect()
     gc.disable()
-    out = {}
     try:
-        tracker.fuse_identical_views = False
-        tracker._coincide_cache = None
-        fps, ok = _timed_frames(tracker, frames, names, first, first + 40)
-        out["value_two_renders"] = {"frames_per_s": round(fps, 2), "frames": 40, "tracked_ok": ok,
-                                    "what": "mask (Depth) and reference (Shade) rendered separately each frame"}
-        tracker.fuse_identical_views = True
-        tracker._coincide_cache = None
-        host = [frames[i].cpu().pin_memory() for i in range(first + 40, first + 80)]
-        tracker.debug = 1
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k, i in enumerate(range(first + 40, first + 80)):
-            tracker.run_single_frame((names[i], host[k]))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        tracker.debug = 0
-        ok = sum(1 for i in range(first + 40, first + 80) if tracker.pose_history[names[i]].get("success"))
-        out["value_host_frames_debug1"] = {"frames_per_s": round(40 / dt, 2), "frames": 40, "tracked_ok": ok,
-                                           "what": "float32 frames in pinned host memory (3.7 MB H2D per frame inside "
-                                                   "the loop), DebugTracker at --debug 1"}
-        fps, ok = _timed_frames(tracker, frames, names, first + 80, first + 280)
-        out["value_k200"] = {"frames_per_s": round(fps, 2), "frames": 200, "tracked_ok": ok,
-                             "what": "same configuration as `value`, 200 consecutive frames"}
+        fps, ok = _timed_frames(tracker, frames, names, first_free, first_free + 200)
     finally:
         gc.enable()
+    out["value_k200"] = {"frames_per_s": round(fps, 2), "frames": 200, "tracked_ok": ok,
+                         "what": "headline configuration, the 200 frames after the timed and diagnostic ones"}
     return out
 
 
@@ -307,7 +328,7 @@ def main():
     n_diag = min(20, args.steps)  # untimed diagnostic pass (per-stage HIP-event times)
     n_timed_end = args.warmup + args.steps
     extras_on = ws == 1 and not args.no_extras and args.config == "frames640"
-    n_extra = (40 + 40 + 200) if extras_on else 0
+    n_extra = 200 if extras_on else 0
     n_frames = n_timed_end + n_diag + n_extra
     unit = parallel.shard_units(ws, rank, ws)[0]  # one sequence per rank, seeds 1002, 1003, ...
     obj = None
@@ -382,17 +403,18 @@ def main():
     tracker.testbed.timing_enable(1)
     tracker.testbed.stats_accum.zero_()
     n_renders1 = tracker.testbed.n_renders
-    for i in range(n_timed_end + n_stage, n_frames):
+    for i in range(n_timed_end + n_stage, n_timed_end + n_diag):
         tracker.run_single_frame((names[i], frames[i]))
     torch.cuda.synchronize()
     tracker.testbed.timing_enable(0)
     tracker.testbed.set_pipelines(0)
     iso_ms, iso_launches = tracker.testbed.timing_read()
     iso_samples = tracker.testbed.stats_accum.cpu().tolist()[0]
+    iso_renders = tracker.testbed.n_renders - n_renders1
 
     extras = None
     if extras_on:
-        extras = run_extras(tracker, frames, names, n_timed_end + n_diag, dev)
+        extras = run_extras(tracker, assets, frames, names, args.warmup, n_timed_end, n_timed_end + n_diag, dev)
 
     records = parallel.pack_pose_records(tracker.pose_history, names[args.warmup:n_timed_end])
     gathered = parallel.gather_pose_records(records.to(coll_dev), coll_dev)  # the one collective (RCCL)
@@ -424,14 +446,14 @@ def main():
     # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes of this command
     # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be taken live here)
     traffic, traffic_src = None, None
-    pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+    pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
     if pmc.exists():
         rec = json.loads(pmc.read_text()).get("pxt::ngp_encode_kernel")
         if rec:
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
+            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
     iso_avg_ms = iso_ms / max(iso_launches, 1)
-    iso_spl = iso_samples / max((tracker.testbed.n_renders - n_renders1) * 5, 1)  # one pipeline: 5 launches per render
+    iso_spl = iso_samples / max(iso_renders * 5, 1)  # one pipeline: 5 launches per render
     iso_achieved = iso_spl * NERF_BYTES_PER_SAMPLE / (iso_avg_ms * 1e-3) / 1e9 if iso_avg_ms > 0 else 0.0
     roofline = {"kernel": "ngp_encode_kernel", "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -477,6 +499,18 @@ def main():
         "stage_ms_note": f"HIP-event times of a separate untimed pass over the next {n_diag // 2} frames",
         "roofline": roofline,
     }
+    # other kernels' utilisation from the committed rocprofv3 SQ counter pass of this command
+    # (profiles/r02_pmc_sq.json; scripts/pmc_sq_summary.py): matrix-pipe busy of the UNet convolutions,
+    # VALU busy of the march (a serial DDA per ray: latency- and tail-bound, not VALU-bound)
+    sq = ROOT / "profiles" / "r02_pmc_sq.json"
+    if sq.exists():
+        rec = json.loads(sq.read_text())
+        pick = {}
+        for name, r in rec.items():
+            if "conv3x3_v2_kernel" in name or "ngp_march" in name or "ngp_shade" in name or "ngp_encode" in name:
+                pick[name.replace("void pxt::", "").replace("pxt::", "")] = {
+                    k: round(r[k], 4) for k in ("mfma_busy", "valu_busy", "mean_waves_per_simd") if k in r}
+        out["kernel_utilisation"] = {"source": "profiles/r02_pmc_sq.json (rocprofv3 --pmc SQ_*, same command)", "kernels": pick}
     if extras is not None:
         out["extras"] = extras
     if not args.no_cpu_baseline and ws == 1:
