@@ -113,6 +113,23 @@ __device__ inline unsigned pool2x2_pk(unsigned v) {
 // when two or three waves share a SIMD; the deep layers (60x80 and 30x40 maps: <= 1 workgroup per CU,
 // 2.4-4.7 MB of taps per layer that every workgroup streams once, cold) use 9 with one wave per SIMD:
 // their loop was bound by the miss latency of each new fragment, not by the matrix pipe.
+// Timing experiment (scripts/conv_stamps.py, a library built with -DPXT_EXP_STAMPS=1): s_memtime stamps of
+// every workgroup's first lane at kernel start (0), after the first halo chunk (1), after each 32-channel
+// chunk (4 + i), after the loop (2) and after the epilogue (3); s_memrealtime at 14 / 15.
+#if PXT_EXP_STAMPS
+__device__ unsigned long long pxt_stamps[8192 * 16];
+#define PXT_STAMP(k)                                                                              \
+  do {                                                                                            \
+    if (threadIdx.x == 0) {                                                                       \
+      const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);        \
+      if (wg_ < 8192) pxt_stamps[wg_ * 16 + (k)] = __builtin_amdgcn_s_memtime();                 \
+      if (wg_ < 8192 && ((k) == 0 || (k) == 3))                                                   \
+        pxt_stamps[wg_ * 16 + ((k) == 0 ? 14 : 15)] = __builtin_amdgcn_s_memrealtime();          \
+    }                                                                                             \
+  } while (0)
+#else
+#define PXT_STAMP(k)
+#endif
 template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3>
 __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const ConvArgs a) {
   static_assert(18 % AR == 0, "the ring is indexed by the step modulo AR at compile time");
@@ -126,6 +143,7 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   constexpr int kBuf = HR * kV2RowBytes;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  PXT_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,6 +320,7 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   // Explicit software pipeline: filter fragments travel AR - 1 steps ahead of their use (an L2 hit
   // is ~300-500 cycles under load, one step only 4-8 MFMAs), pixel fragments one step ahead (LDS).
   // The rings are indexed with compile-time constants (18 steps per chunk, 18 % AR == 0).
+  PXT_STAMP(1);
   half8 a_q[AR][CW], b_q[2][PBW];
   const int n_steps = (ch_end - ch_begin) * 18;
   if (n_steps > 0) {
@@ -358,7 +377,9 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
           acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_q[st % AR][c], b_q[st & 1][p], acc[c][p], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
+    if (ch - ch_begin < 10) PXT_STAMP(4 + ch - ch_begin);
   }
+  PXT_STAMP(2);
 
   // ---- epilogue: D[row = cout][col = pixel]; lane: col = lane & 31, rows (r&3) + 8*(r>>2) + 4*khalf
   const int cw0 = co0 + 32 * CW * wc;
@@ -442,6 +463,7 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
         if (inside) *(uint4*)(dst + 32 * c + 8 * (g + khalf)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       }
   }
+  PXT_STAMP(3);
 }
 
 }  // namespace pxt

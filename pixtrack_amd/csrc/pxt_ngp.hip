@@ -375,45 +375,54 @@ __device__ inline Ray ray_from_record(const NgpParams& P, const float4 rd) {
   return r;
 }
 
+// One lattice point of a ray: its position, step and cascade, and whether its occupancy cell is set.
+__device__ inline bool probe_cell(const NgpParams& P, const Ray& r, float t, float* pos, float& dt, int& mip) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) pos[a] = r.o[a] + t * r.d[a];
+  dt = calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+  const int e = frexp_exp(dt * (float)kGrid);
+  mip = min(P.cascades - 1, max(e, mip_from_pos(pos[0], pos[1], pos[2], P.cascades)));
+  const float msc = pow2i(-mip);
+  int ci[3];
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = (pos[a] - 0.5f) * msc + 0.5f;
+    ci[a] = (int)floorf(p * (float)kGrid);
+    inside = inside && ci[a] >= 0 && ci[a] < kGrid;
+    ci[a] = min(max(ci[a], 0), kGrid - 1);
+  }
+  const unsigned lin = (unsigned)((ci[2] * kGrid + ci[1]) * kGrid + ci[0]) +
+                       (unsigned)mip * (unsigned)(kGrid * kGrid * kGrid);
+  return inside && ((P.occ[lin >> 3] >> (lin & 7u)) & 1u);
+}
+
+// advance_to_next_voxel: step in dt increments past the border of the (empty) cell at `pos`
+__device__ inline void advance_past_cell(const NgpParams& P, const Ray& r, float& t, const float* pos, int mip) {
+  const float res = pow2i(7 - mip), ires = pow2i(mip - 7);  // 128 / 2^mip cells per unit
+  float tm = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = res * (pos[a] - 0.5f);
+    const float sg = r.d[a] > 0.f ? 1.f : (r.d[a] < 0.f ? -1.f : 0.f);
+    const float tx = (floorf(p + 0.5f + 0.5f * sg) - p) * r.idir[a];
+    if (r.d[a] != 0.f) tm = fminf(tm, tx);
+  }
+  const float t_target = t + fmaxf(tm * ires, 0.f);  // exact: res is a power of two
+  do {
+    t = t + calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+  } while (t < t_target);
+}
+
 // Advances t along the dt lattice to the next sample whose occupancy cell is set.
 // Returns false when the ray leaves the render box first.  pos/dt describe the sample.
 __device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, float* pos, float& dt) {
-  for (int guard = 0; guard < 1000000; ++guard) {
+  for (;;) {
     if (t >= r.tmax) return false;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) pos[a] = r.o[a] + t * r.d[a];
-    dt = calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-    const int e = frexp_exp(dt * (float)kGrid);
-    const int mip = min(P.cascades - 1, max(e, mip_from_pos(pos[0], pos[1], pos[2], P.cascades)));
-    const float msc = pow2i(-mip);
-    int ci[3];
-    bool inside = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float p = (pos[a] - 0.5f) * msc + 0.5f;
-      ci[a] = (int)floorf(p * (float)kGrid);
-      inside = inside && ci[a] >= 0 && ci[a] < kGrid;
-      ci[a] = min(max(ci[a], 0), kGrid - 1);
-    }
-    const unsigned lin = (unsigned)((ci[2] * kGrid + ci[1]) * kGrid + ci[0]) +
-                         (unsigned)mip * (unsigned)(kGrid * kGrid * kGrid);
-    if (inside && ((P.occ[lin >> 3] >> (lin & 7u)) & 1u)) return true;
-    // advance_to_next_voxel: step in dt increments past the cell border
-    const float res = pow2i(7 - mip), ires = pow2i(mip - 7);  // 128 / 2^mip cells per unit
-    float tm = INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float p = res * (pos[a] - 0.5f);
-      const float sg = r.d[a] > 0.f ? 1.f : (r.d[a] < 0.f ? -1.f : 0.f);
-      const float tx = (floorf(p + 0.5f + 0.5f * sg) - p) * r.idir[a];
-      if (r.d[a] != 0.f) tm = fminf(tm, tx);
-    }
-    const float t_target = t + fmaxf(tm * ires, 0.f);  // exact: res is a power of two
-    do {
-      t = t + calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-    } while (t < t_target);
+    int mip;
+    if (probe_cell(P, r, t, pos, dt, mip)) return true;
+    advance_past_cell(P, r, t, pos, mip);
   }
-  return false;
 }
 
 struct RayState {  // SoA, indexed by compact slot; two copies ping-pong between rounds
@@ -568,29 +577,71 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
   }
 }
 
+#if PXT_EXP_STAMPS  // timing experiment (scripts/march_stamps.py): per-wave stamps of one round of pipeline 0
+__device__ unsigned long long pxt_ngp_stamps[16384 * 8];
+__device__ int pxt_ngp_stamp_round = 0;
+#define PXT_MARCH_STAMP_BEGIN                                                                  \
+  const bool stamp = round == pxt_ngp_stamp_round && P.enum_lo == 0;                           \
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);                                          \
+  unsigned long long* stp = pxt_ngp_stamps + (size_t)(gw & 16383) * 8;                         \
+  const bool stamper = stamp && (threadIdx.x & 63) == 0 && gw < 16384;                         \
+  int dbg_trips = 0;                                                                           \
+  if (stamper) { stp[0] = __builtin_amdgcn_s_memrealtime(); stp[1] = __builtin_amdgcn_s_memtime(); stp[5] = 0; }
+#define PXT_MARCH_STAMP_LOADED                                                                 \
+  if (stamper) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[2] = __builtin_amdgcn_s_memtime(); stp[5] += 1; }
+#define PXT_MARCH_TRIP ++dbg_trips;
+#define PXT_MARCH_STAMP_RAY                                                                    \
+  {                                                                                            \
+    int mh = dbg_trips;                                                                        \
+    for (int m = 32; m >= 1; m >>= 1) mh = max(mh, __shfl_xor(mh, m, 64));                     \
+    if (stamper) { stp[6] = mh; stp[7] = 0; }                                                  \
+  }
+#define PXT_MARCH_STAMP_END \
+  if (stamper) { stp[3] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define PXT_MARCH_STAMP_BEGIN
+#define PXT_MARCH_STAMP_LOADED
+#define PXT_MARCH_TRIP
+#define PXT_MARCH_STAMP_RAY
+#define PXT_MARCH_STAMP_END
+#endif
+// One thread per live ray.  The ray walks its lattice as a flat state machine - one lattice point per
+// loop trip, which is either taken as the ray's next sample or skipped to the far side of its empty
+// cell - so a wave makes max-over-lanes(samples + empty cells) trips.  (The first version nested the
+// empty-cell loop inside the loop over the K samples: a wave then made sum-over-k max-over-lanes trips,
+// every trip a dependent occupancy load; in-kernel stamps showed a median wave at 25 us, the slowest
+// at 110 us, and the launch waiting for those.)
 __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
   const int n = Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
+  PXT_MARCH_STAMP_BEGIN
   for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
     const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
     float t = S.t[slot];
+    PXT_MARCH_STAMP_LOADED
+    const size_t s0 = (size_t)slot * kK;
+    int k = 0;
     bool out = false;
-    for (int k = 0; k < kK; ++k) {
-      float pos[3], dt = 0.f;
-      const bool found = !out && next_sample(P, r, t, pos, dt);
-      const size_t si = (size_t)slot * kK + k;
-      if (found) {
-        Wk.spos[si] = make_float4(pos[0], pos[1], pos[2], dt);
-        Wk.st_t[si] = t;
+    while (k < kK) {
+      if (t >= r.tmax) { out = true; break; }
+      float pos[3], dt;
+      int mip;
+      PXT_MARCH_TRIP
+      if (probe_cell(P, r, t, pos, dt, mip)) {
+        Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
+        Wk.st_t[s0 + k] = t;
         t = t + dt;
+        ++k;
       } else {
-        out = true;
-        Wk.spos[si] = make_float4(0.f, 0.f, 0.f, 0.f);
+        advance_past_cell(P, r, t, pos, mip);
       }
     }
+    for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
     S.t[slot] = t;
     Wk.exhausted[slot] = out ? 1 : 0;
+    PXT_MARCH_STAMP_RAY
   }
+  PXT_MARCH_STAMP_END
 }
 
 // Level-major encode: work item = (level, chunk of 256 samples), items ordered by level.
@@ -1216,3 +1267,10 @@ extern "C" int pxt_ngp_timing_read(pxt_ngp* ctx, float* total_ms, int32_t* n_lau
   ctx->events.clear();
   return PXT_OK;
 }
+
+#if PXT_EXP_STAMPS
+extern "C" int pxt_debug_ngp_stamps(void* host, int64_t bytes, int32_t round) {
+  if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(pxt::pxt_ngp_stamps), (size_t)bytes) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(pxt::pxt_ngp_stamp_round), &round, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -832,3 +832,9 @@ extern "C" int pxt_conv3x3_nhwc_f16(const void* in, int32_t H, int32_t W, int32_
   if (rc != PXT_OK) return rc;
   return pxt_conv3x3_packed(in, H, W, Cin, scratch, bias, Cout, relu, out, nullptr, 0, 1, nullptr, 0, stream);
 }
+
+#if PXT_EXP_STAMPS
+extern "C" int pxt_debug_read_stamps(void* host, int64_t bytes) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pxt::pxt_stamps), (size_t)bytes) == hipSuccess ? 0 : -1;
+}
+#endif
