@@ -50,6 +50,7 @@ struct NgpLevel {
 
 struct NgpParams {
   const unsigned* grid;        // [entries] packed 2 x fp16
+  unsigned grid_bytes;
   const half8* wfrag;          // [kNumFrags][64] fragment-ordered weights
   const uint8_t* occ;          // bitfield
   NgpLevel lv[kMaxLevels];
@@ -160,6 +161,52 @@ __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, c
     else
       idx = min(cx + cy * Lv.res + cz * Lv.res * Lv.res, Lv.size - 1u);
     vals[c] = grid[idx + Lv.offset];
+  }
+  float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float w = 1.0f;
+    w = w * ((c & 1) ? ax : (1.0f - ax));
+    w = w * ((c & 2) ? ay : (1.0f - ay));
+    w = w * ((c & 4) ? az : (1.0f - az));
+    const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
+    f0 += w * (float)hv[0];
+    f1 += w * (float)hv[1];
+  }
+  return pack_h2(f0, f1);
+}
+
+// The same level, for a caller whose level is wave-uniform (the level-major encoder): identical indices and
+// arithmetic, with the integer work pared down - the two y and two z hash products (or row / plane
+// offsets) are formed once and shared by the 8 corners (v_mul_lo_u32 is quarter rate), and the gathers
+// are buffer loads with a 32-bit byte offset and the level's base as the scalar offset instead of 64-bit
+// address arithmetic per corner (18 v_mad_u64_u32 + 14 v_lshl_add_u64 per item in the first version).
+__device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t grid, const NgpLevel& Lv, float ux,
+                                                    float uy, float uz) {
+  const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
+  const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+  const float ax = qx - fx, ay = qy - fy, az = qz - fz;
+  const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
+  unsigned vals[8];
+  const int base = (int)(Lv.offset * 4u);
+  if (Lv.hashed) {
+    const unsigned mask = Lv.size - 1u;
+    const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
+    const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned idx = ((gx + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask;
+      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
+    }
+  } else {
+    const unsigned r2 = Lv.res * Lv.res;
+    const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
+    const unsigned rz[2] = {gz * r2, gz * r2 + r2};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned idx = min((gx + (c & 1)) + ry[(c >> 1) & 1] + rz[(c >> 2) & 1], Lv.size - 1u);
+      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
+    }
   }
   float f0 = 0.f, f1 = 0.f;
 #pragma unroll
@@ -652,15 +699,15 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, cons
   if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)ns);
   const float half_s = P.aabb_scale * 0.5f;
   const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
+  const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   for (long long item = blockIdx.x; item < chunks * P.n_levels; item += gridDim.x) {
     const int l = (int)(item / chunks);
     const long long s = (item % chunks) * 256 + threadIdx.x;
     if (s >= ns) continue;
     const float4 sp = Wk.spos[s];
     if (sp.w == 0.f) continue;  // no sample in this slot: shade never reads its features
-    Wk.feat[(size_t)l * Wk.feat_stride + s] =
-        ngp_encode_level(P.grid, P.lv[l], (sp.x - scene_lo) * inv_s, (sp.y - scene_lo) * inv_s,
-                         (sp.z - scene_lo) * inv_s);
+    Wk.feat[(size_t)l * Wk.feat_stride + s] = ngp_encode_level_uniform(
+        grid, P.lv[l], (sp.x - scene_lo) * inv_s, (sp.y - scene_lo) * inv_s, (sp.z - scene_lo) * inv_s);
   }
 }
 
@@ -924,6 +971,7 @@ __global__ __launch_bounds__(256) void ngp_query_kernel(const NgpParams P, const
 struct pxt_ngp {
   pxt_ngp_model model;
   unsigned* grid = nullptr;
+  unsigned grid_bytes = 0;
   pxt::half8* wfrag = nullptr;
   uint8_t* occ = nullptr;
   pxt::NgpLevel lv[pxt::kMaxLevels];
@@ -1007,6 +1055,7 @@ extern "C" int pxt_ngp_create(const pxt_ngp_model* model, const void* grid_param
   pack_layer(mp + 3072, 64, 32, 2, kFragC1, frag);
   pack_layer(mp + 5120, 64, 64, 1, kFragC2, frag);
   pack_layer(mp + 9216, 16, 64, 1, kFragC3, frag);
+  ctx->grid_bytes = (unsigned)((size_t)off * 4);
   hipError_t e = hipMalloc((void**)&ctx->grid, (size_t)off * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->wfrag, frag.size() * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->occ, (size_t)n_occ_bytes);
@@ -1040,6 +1089,7 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
 static void fill_model(const pxt_ngp* ctx, NgpParams& P) {
   std::memset(&P, 0, sizeof(P));
   P.grid = ctx->grid;
+  P.grid_bytes = ctx->grid_bytes;
   P.wfrag = ctx->wfrag;
   P.occ = ctx->occ;
   for (int l = 0; l < kMaxLevels; ++l) P.lv[l] = ctx->lv[l < ctx->model.n_levels ? l : 0];
