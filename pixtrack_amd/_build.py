@@ -30,8 +30,10 @@ FLAGS = [
 ]
 
 
-# per-file extra flags: the NeRF march must round exactly like the numpy oracle
-EXTRA = {"pxt_ngp": ["-ffp-contract=off"]}
+# per-file extra flags: the NeRF march must round exactly like the numpy oracle; MFMA results of the
+# NeRF MLPs go straight to VGPRs (hipcc's default puts them in AGPRs and copied 214 registers back per
+# 64 samples with v_accvgpr_read: a quarter of the shade kernel's VALU instructions)
+EXTRA = {"pxt_ngp": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():

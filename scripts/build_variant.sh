@@ -3,7 +3,7 @@
 set -e
 name=$1; stem=$2; shift 2
 cd "$(dirname "$0")/.."
-extra=""; [ "$stem" = pxt_ngp ] && extra="-ffp-contract=off"
+extra=""; [ "$stem" = pxt_ngp ] && extra="-ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on -Wno-comment -Wno-unused-result $extra "$@" \
   -c pixtrack_amd/csrc/$stem.hip -o /tmp/${stem}_$name.o
 objs=""
