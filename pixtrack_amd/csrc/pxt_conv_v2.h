@@ -160,6 +160,11 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   const half_t* in = a.in + (size_t)img * (UPCAT ? a.up.Hs : H) * in_w * Cs;
   const half_t* prev = UPCAT ? a.up.prev + (size_t)img * a.up.Hp * a.up.Wp * a.up.Cp : nullptr;
 
+  // the workgroup's biases wait in LDS for the epilogue (fetched there from global memory they cost the
+  // epilogue ~2.5k cycles of exposed latency; stamps)
+  float* const s_bias = (float*)(smem + 2 * kBuf + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0));
+  if (tid < BNC) s_bias[tid] = a.bias[co0 + tid];
+
   f32x16 acc[CW][PBW];
 #pragma unroll
   for (int c = 0; c < CW; ++c)
@@ -382,6 +387,8 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   PXT_STAMP(2);
 
   // ---- epilogue: D[row = cout][col = pixel]; lane: col = lane & 31, rows (r&3) + 8*(r>>2) + 4*khalf
+  __syncthreads();  // every wave is done with the halo buffers: the plain-output path stages tiles there
+  PXT_STAMP(12);
   const int cw0 = co0 + 32 * CW * wc;
   half_t* out = a.out + (size_t)img * H * W * Cout;
 #pragma unroll
@@ -432,7 +439,13 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
       }
       continue;
     }
-    half_t* dst = out + ((size_t)gy * W + gx) * Cout + cw0;
+    // Plain output.  The accumulator layout puts ONE pixel's 8 channels in a lane, so direct 16-B stores hit
+    // 32 different 128-B lines per instruction with 32 B each, and the epilogue ran at the speed of the
+    // address unit (stamps: ~9.8k cycles, a quarter of a 128-channel layer's workgroup time).  The tile goes
+    // through LDS instead (the halo buffers, free after the loop): written pixel-major with a padded pitch,
+    // read back so that 4 * CW consecutive lanes cover one pixel's 64 * CW contiguous bytes.
+    constexpr int kPitch = CW * 64 + 16;
+    char* const stage = smem + wave * (32 * kPitch);
     half_t* pdst = nullptr;
     const bool pool_lane = a.pool && (r31 & 17) == 0 && (gy >> 1) < (H >> 1) && (gx >> 1) < (W >> 1);
     if (a.pool)
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
         unsigned lo[2], hi[2];  // packed fp16 pairs of row groups g and g + 1
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float4 bv = *(const float4*)(a.bias + cw0 + 32 * c + 8 * (g + h) + 4 * khalf);
+          const float4 bv = *(const float4*)(s_bias + 32 * (CW * wc + c) + 8 * (g + h) + 4 * khalf);
           float v0 = acc[c][p][4 * (g + h) + 0] + bv.x, v1 = acc[c][p][4 * (g + h) + 1] + bv.y;
           float v2 = acc[c][p][4 * (g + h) + 2] + bv.z, v3 = acc[c][p][4 * (g + h) + 3] + bv.w;
           if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
@@ -460,8 +473,21 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
         // lanes 0-31 (khalf 0) end up with channels 8g .. 8g+7, lanes 32-63 with 8(g+1) .. 8(g+1)+7
         auto s0 = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
-        if (inside) *(uint4*)(dst + 32 * c + 8 * (g + khalf)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        *(uint4*)(stage + r31 * kPitch + (32 * c + 8 * (g + khalf)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       }
+    if (p == 0) PXT_STAMP(13);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the staged tile is read by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int kLpp = 4 * CW;  // lanes per pixel (16 B each)
+#pragma unroll
+    for (int it = 0; it < 2 * CW; ++it) {
+      const int pix = it * (64 / kLpp) + lane / kLpp, piece = lane % kLpp;
+      const uint4 v = *(const uint4*)(stage + pix * kPitch + piece * 16);
+      const int oy = ty0 + 2 * PBW * wp + 2 * p + (pix >> 4), ox = tx0 + (pix & 15);
+      if (oy < H && ox < W) *(uint4*)(out + ((size_t)oy * W + ox) * Cout + cw0 + piece * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();  // the next pixel block overwrites the stage
   }
   PXT_STAMP(3);
 }

@@ -412,7 +412,7 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
 
 template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3>
 void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = 2 * (2 * PBW * WP + 2) * kV2RowBytes + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0);
+  constexpr int lds = 2 * (2 * PBW * WP + 2) * kV2RowBytes + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0) + 32 * CW * WC * 4;
   static bool attr_done = false;  // the double-buffered halo of the 32-row tiles exceeds the 64 KiB default
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>,

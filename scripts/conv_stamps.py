@@ -39,6 +39,10 @@ prev = st[:, 1]
 for c in range(min(nch, 11)):
     print(f"chunk {c:2d}    ", q(st[:, 4 + c] - prev)); prev = st[:, 4 + c]
 print("epilogue    ", q(st[:, 3] - st[:, 2]))
+if st[:, 12].max() > 0:
+    print("  barrier   ", q(st[:, 12] - st[:, 2]))
+    print("  bias+pack ", q(st[:, 13] - st[:, 12]))
+    print("  rest      ", q(st[:, 3] - st[:, 13]))
 print("total per wg", q(st[:, 3] - st[:, 0]))
 print("end         ", q(rel[:, 3]))
 rt = st[:, 15] - st[:, 14]
