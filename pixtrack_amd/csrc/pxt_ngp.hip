@@ -222,6 +222,35 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
   return pack_h2(f0, f1);
 }
 
+// The LDS variant north_star names: the first PXT_NGP_LDS_LEVELS dense levels are
+// copied into LDS by every shade workgroup and evaluated there, sample by sample, instead of being
+// gathered by the encoder and round-tripped through feat[].  Same indices, same arithmetic, same results.
+#ifndef PXT_NGP_LDS_LEVELS
+#define PXT_NGP_LDS_LEVELS 0
+#endif
+__device__ inline unsigned ngp_encode_level_lds(const unsigned* tab, const NgpLevel& Lv, float ux, float uy, float uz) {
+  const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
+  const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+  const float ax = qx - fx, ay = qy - fy, az = qz - fz;
+  const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
+  const unsigned r2 = Lv.res * Lv.res;
+  const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
+  const unsigned rz[2] = {gz * r2, gz * r2 + r2};
+  float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned idx = min((gx + (c & 1)) + ry[(c >> 1) & 1] + rz[(c >> 2) & 1], Lv.size - 1u);
+    float w = 1.0f;
+    w = w * ((c & 1) ? ax : (1.0f - ax));
+    w = w * ((c & 2) ? ay : (1.0f - ay));
+    w = w * ((c & 4) ? az : (1.0f - az));
+    const half2_t hv = __builtin_bit_cast(half2_t, tab[idx]);
+    f0 += w * (float)hv[0];
+    f1 += w * (float)hv[1];
+  }
+  return pack_h2(f0, f1);
+}
+
 // Both MLPs for the wave's 64 samples (lane = sample).  Flo/Fhi: this lane's 32 encoded
 // features as 16 packed dwords (levels 0..7 / 8..15).  All 64 lanes must call (MFMA).
 // One 32-sample column block through both MLPs.  x0/x1: the block's two input B fragments,
@@ -700,7 +729,7 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, cons
   const float half_s = P.aabb_scale * 0.5f;
   const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
   const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
-  for (long long item = blockIdx.x; item < chunks * P.n_levels; item += gridDim.x) {
+  for (long long item = blockIdx.x + chunks * PXT_NGP_LDS_LEVELS; item < chunks * P.n_levels; item += gridDim.x) {
     const int l = (int)(item / chunks);
     const long long s = (item % chunks) * 256 + threadIdx.x;
     if (s >= ns) continue;
@@ -723,6 +752,14 @@ template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays i
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
+#if PXT_NGP_LDS_LEVELS > 0
+  extern __shared__ unsigned s_tab[];  // the first dense levels, back to back
+  {
+    const unsigned n_tab = P.lv[PXT_NGP_LDS_LEVELS - 1].offset + P.lv[PXT_NGP_LDS_LEVELS - 1].size;
+    for (unsigned i = threadIdx.x; i < n_tab; i += 256) s_tab[i] = P.grid[i];
+  }
+  const float half_s_ = P.aabb_scale * 0.5f, scene_lo_ = 0.5f - half_s_, inv_s_ = 1.0f / P.aabb_scale;
+#endif
   __syncthreads();
   const int n = Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
@@ -746,9 +783,16 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     unsigned Flo[8], Fhi[8];
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
-      Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
+      if (l >= PXT_NGP_LDS_LEVELS) Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
       Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
     }
+#if PXT_NGP_LDS_LEVELS > 0
+#pragma unroll
+    for (int l = 0; l < PXT_NGP_LDS_LEVELS; ++l)
+      Flo[l] = valid ? ngp_encode_level_lds(s_tab + P.lv[l].offset, P.lv[l], (sp.x - scene_lo_) * inv_s_,
+                                            (sp.y - scene_lo_) * inv_s_, (sp.z - scene_lo_) * inv_s_)
+                     : 0u;
+#endif
     float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
     // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
     // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
@@ -1222,6 +1266,20 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     for (int w = 1; w < n_pipe; ++w) PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side[w], ctx->ev_fork, 0));
   }
   const int wide = 2048, enc_grid = 4096, cmp_grid = 1024;  // grid-stride kernels: full grids measured best
+#if PXT_NGP_LDS_LEVELS > 0
+  const size_t shade_lds = (size_t)(ctx->lv[PXT_NGP_LDS_LEVELS - 1].offset + ctx->lv[PXT_NGP_LDS_LEVELS - 1].size) * 4;
+  static const int shade_grid = [] { const char* e = getenv("PXT_NGP_SHADE_GRID"); return e ? atoi(e) : 768; }();
+  static bool attr_set = false;
+  if (!attr_set) {
+    attr_set = true;
+    (void)hipFuncSetAttribute((const void*)ngp_shade_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shade_lds);
+    (void)hipFuncSetAttribute((const void*)ngp_shade_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shade_lds);
+    (void)hipFuncSetAttribute((const void*)ngp_shade_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shade_lds);
+  }
+#else
+  const size_t shade_lds = 0;
+  const int shade_grid = wide;
+#endif
   for (int w = 0; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
     hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
@@ -1251,11 +1309,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     }
     for (int w = 0; w < n_pipe; ++w) {
       if (mode == 1)
-        hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
       else if (mode == 2)
-        hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
       else
-        hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
     }
     for (int w = 0; w < n_pipe; ++w)
       hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
