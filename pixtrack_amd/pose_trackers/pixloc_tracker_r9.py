@@ -35,7 +35,8 @@ from ..tracker import DebugTracker
 from ..utils.colmap import ColmapCamera
 from ..utils.ingp_utils import initialize_ingp, load_nerf2sfm, sfm_to_nerf_pose
 from ..utils.io import ArrayIterator, ImageIterator
-from ..utils.pose_utils import geodesic_distance_for_rotations, get_camera_in_world_from_pixpose
+from ..utils.pose_utils import (geodesic_distance_for_rotations, geodesic_distances_to,
+                                get_camera_in_world_from_pixpose)
 from ..visualization.run_vis_on_poses import get_nerf_image_device, rgba_to_u8
 from .base_pose_tracker import PoseTracker
 
@@ -171,14 +172,18 @@ class PixLocPoseTrackerR9(PoseTracker):
     def update_reference_ids(self):
         if self.cache_hit == True:  # noqa: E712  (kept: see Appendix D.2)
             return self.reference_ids
-        curr_refs = self.reference_ids
-        R_qry = self.pose.numpy()[0]
-        dbs = self.localizer.model3d.dbs
-        gdists = {curr_refs[0]: geodesic_distance_for_rotations(R_qry, dbs[curr_refs[0]].qvec2rotmat())}
-        covis = {k: v for k, v in self.covis[curr_refs[0]].items() if v > 50}
-        for ref in covis:
-            gdists[ref] = geodesic_distance_for_rotations(R_qry, dbs[ref].qvec2rotmat())
-        self.reference_ids = sorted(gdists, key=lambda x: gdists[x])[:1]
+        # candidates: the current reference, then its covisible images (> 50 shared points), ranked by the
+        # geodesic distance of their rotation to the current pose; ties keep this order (stable sort)
+        curr = self.reference_ids[0]
+        cache = self.__dict__.setdefault("_ref_candidates", {})  # static per model: rotations of each reference's candidates
+        cand = cache.get(curr)
+        if cand is None:
+            dbs = self.localizer.model3d.dbs
+            ids = list(dict.fromkeys([curr] + [k for k, v in self.covis[curr].items() if v > 50]))
+            cand = cache[curr] = (ids, np.stack([dbs[r].qvec2rotmat() for r in ids]))
+        ids, rots = cand
+        gd = geodesic_distances_to(self.pose.numpy()[0], rots)
+        self.reference_ids = [ids[int(np.argmin(gd))]]
         return self.reference_ids
 
     # ------------------------------------------------------------------ NeRF reference + mask

@@ -17,6 +17,19 @@ def geodesic_distance_for_rotations(R1: np.ndarray, R2: np.ndarray) -> float:
     return float(np.arctan2(sin, cos))
 
 
+def geodesic_distances_to(R1: np.ndarray, R2s: np.ndarray) -> np.ndarray:
+    """geodesic_distance_for_rotations(R1, R2s[i]) for a stack R2s [n,3,3] in one pass (the tracker ranks
+    every covisible reference each frame, on the frame's critical path): the same atan2(|sin|, cos), with
+    the relative rotation's entries written out as sums of three products."""
+    A = np.asarray(R1, dtype=np.float64)
+    B = np.asarray(R2s, dtype=np.float64)
+    Rd = np.matmul(A[None], B.transpose(0, 2, 1))  # A @ B[i].T
+    cos = (Rd[:, 0, 0] + Rd[:, 1, 1] + Rd[:, 2, 2] - 1.0) * 0.5
+    sx, sy, sz = Rd[:, 2, 1] - Rd[:, 1, 2], Rd[:, 0, 2] - Rd[:, 2, 0], Rd[:, 1, 0] - Rd[:, 0, 1]
+    sin = 0.5 * np.sqrt(sx * sx + sy * sy + sz * sz)
+    return np.arctan2(sin, cos)
+
+
 def get_world_in_camera_from_pixpose(pixpose) -> np.ndarray:
     """4x4 world->camera matrix [R|t] of a Pose (reference pose_utils.py:16-21)."""
     R, t = pixpose.cpu().numpy()

@@ -103,3 +103,21 @@ def test_resize_factor_is_the_unrounded_one_pixloc_returns():
     h, w, sc = fe.target_size(1081, 1920, 1)   # 576.53 -> 577 rows, the factor stays 1024 / 1920
     assert (h, w) == (577, 1024) and sc == (1024 / 1920, 1024 / 1920)
     assert fe.target_size(480, 640, 1) == (480, 640, (1.0, 1.0))
+
+
+def test_vectorised_reference_ranking_equals_the_scalar_one():
+    """update_reference_ids ranks [current] + covisible (> 50) references by geodesic distance; the one-pass
+    form (geodesic_distances_to + argmin) must pick what the reference's dict + stable sort picks."""
+    from pixtrack_amd.utils.pose_utils import geodesic_distance_for_rotations, geodesic_distances_to
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(3)
+    rots = Rotation.random(40, random_state=5).as_matrix()
+    for trial in range(50):
+        Rq = Rotation.random(random_state=100 + trial).as_matrix()
+        ids = list(rng.permutation(40)[: rng.integers(1, 12)])
+        scalar = np.array([geodesic_distance_for_rotations(Rq, rots[i]) for i in ids])
+        vector = geodesic_distances_to(Rq, rots[ids])
+        assert np.allclose(scalar, vector, rtol=0, atol=1e-14)
+        gd = {i: geodesic_distance_for_rotations(Rq, rots[i]) for i in ids}
+        assert sorted(gd, key=lambda x: gd[x])[0] == ids[int(np.argmin(vector))]
