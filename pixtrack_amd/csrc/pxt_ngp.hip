@@ -379,7 +379,10 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // samples; samples a round evaluates past a ray's termination point are discarded.
 // ===========================================================================
 constexpr int kK = 8;          // samples per ray per round
-constexpr int kRounds = 5;     // wavefront rounds before the tail kernel
+#ifndef PXT_NGP_ROUNDS
+#define PXT_NGP_ROUNDS 5  // 3 / 4 / 6 measured: 1.08 / 1.02 / 1.01 ms per render against 1.00 (profiles/r02_ngp_experiments.md)
+#endif
+constexpr int kRounds = PXT_NGP_ROUNDS;  // wavefront rounds before the tail kernel
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {
