@@ -723,6 +723,78 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
   PXT_MARCH_STAMP_END
 }
 
+// Compaction of round r's survivors AND round r + 1's march in one launch: a workgroup compacts a tile of 256
+// slots (ballot + prefix, ONE atomic per tile for the tile's base, survivors keep their order inside the tile)
+// and every thread marches its own surviving ray straight away, writing to the ray's NEW slot.  Saves the
+// compaction launch of every round but the last (15-30 us each on a pipeline's serial chain).  Tiles land in
+// the order of their atomics, i.e. roughly in dispatch order: neighbours in the new list are still neighbours
+// in the image (unlike the per-wave queues tried in the shade kernel, profiles/r02_ngp_experiments.md #10).
+__global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int n = Wk.counters[round * kCtrStride];
+  const RayState& S = Wk.st[round & 1];
+  const RayState& D = Wk.st[(round + 1) & 1];
+  int* out_count = Wk.counters + (round + 1) * kCtrStride;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles = (n + 255) / 256;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int i = tile * 256 + threadIdx.x;
+    const bool kept = i < n && Wk.keep[i] != 0;
+    const unsigned long long m = __ballot(kept);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    // the survivor's record is fetched while the tile's base is still being negotiated
+    unsigned rid = 0;
+    float t = 0.f, T_ = 0.f, accd_ = 0.f;
+    float4 acc_ = make_float4(0.f, 0.f, 0.f, 0.f), rdir = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (kept) {
+      rid = S.rid[i];
+      t = S.t[i];
+      T_ = S.T[i];
+      acc_ = S.acc[i];
+      accd_ = S.accd[i];
+      rdir = Wk.raydir[rid];
+    }
+    __syncthreads();
+    int wave_off = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) wave_off += s_wave[w];
+      tile_total += s_wave[w];
+    }
+    if (threadIdx.x == 0) s_base = tile_total ? atomicAdd(out_count, tile_total) : 0;
+    __syncthreads();
+    if (kept) {
+      const int slot = s_base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
+      D.rid[slot] = rid;
+      D.T[slot] = T_;
+      D.acc[slot] = acc_;
+      D.accd[slot] = accd_;
+      const Ray r = ray_from_record(P, rdir);
+      const size_t s0 = (size_t)slot * kK;
+      int k = 0;
+      bool out = false;
+      while (k < kK) {
+        if (t >= r.tmax) { out = true; break; }
+        float pos[3], dt;
+        int mip;
+        if (probe_cell(P, r, t, pos, dt, mip)) {
+          Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
+          Wk.st_t[s0 + k] = t;
+          t = t + dt;
+          ++k;
+        } else {
+          advance_past_cell(P, r, t, pos, mip);
+        }
+      }
+      for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      D.t[slot] = t;
+      Wk.exhausted[slot] = out ? 1 : 0;
+    }
+    __syncthreads();
+  }
+}
+
 // Level-major encode: work item = (level, chunk of 256 samples), items ordered by level.
 __global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, const NgpWork Wk, int round) {
   const int n = Wk.counters[round * kCtrStride];
@@ -1288,9 +1360,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
+  static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
   for (int r = 0; r < kRounds; ++r) {
-    for (int w = 0; w < n_pipe; ++w)
-      hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+    if (r == 0 || !fuse_cm)
+      for (int w = 0; w < n_pipe; ++w)
+        hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
     for (int w = 0; w < n_pipe; ++w) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) {
@@ -1318,8 +1392,12 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
       else
         hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
     }
-    for (int w = 0; w < n_pipe; ++w)
-      hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+    for (int w = 0; w < n_pipe; ++w) {
+      if (fuse_cm && r + 1 < kRounds)  // compaction of round r + march of round r + 1 in one launch
+        hipLaunchKernelGGL(ngp_compact_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      else
+        hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+    }
   }
   for (int w = 0; w < n_pipe; ++w) {
     if (mode == 1)
