@@ -17,6 +17,7 @@
 #include "pxt_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -301,8 +302,16 @@ struct pxt_unet {
   void* dev_packed = nullptr;          // conv taps in MFMA A-fragment order (pxt_conv_v2.h)
   const pxt::half_t* conv_packed[pxt::kNumConv];
   int64_t n_bytes = 0;
-  hipStream_t side = nullptr;          // the coarse heads run here, beside the decoder
-  hipEvent_t ev_enc4 = nullptr, ev_dec1 = nullptr, ev_side = nullptr;
+  // Side streams.  A pass owns one SideSet: its coarse heads run on `side` beside the decoder.  A batch of two
+  // images runs as TWO single-image passes, image 0 on the caller's stream, image 1 on `pass2` (fork / join
+  // with events): the layers of a pass are 20-75 us launches whose tails the other pass fills (two-image
+  // pass 0.91 -> 0.87 ms in scripts/exp_unet_two_streams.py).  PXT_UNET_STREAMS=1 keeps the batched launches.
+  struct SideSet {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_enc4 = nullptr, ev_dec1 = nullptr, ev_side = nullptr;
+  } sides[2];
+  hipStream_t pass2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   pxt::UnetLayer conv[pxt::kNumConv];
   pxt::UnetLayer head[pxt::kNumHeads];
 };
@@ -605,29 +614,35 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (ctx->dev_head) (void)hipFree(ctx->dev_head);
   if (ctx->dev_packed) (void)hipFree(ctx->dev_packed);
   if (ctx->dev_head0) (void)hipFree(ctx->dev_head0);
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
-  if (ctx->ev_enc4) (void)hipEventDestroy(ctx->ev_enc4);
-  if (ctx->ev_dec1) (void)hipEventDestroy(ctx->ev_dec1);
-  if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+  for (auto& ss : ctx->sides) {
+    if (ss.side) (void)hipStreamDestroy(ss.side);
+    if (ss.ev_enc4) (void)hipEventDestroy(ss.ev_enc4);
+    if (ss.ev_dec1) (void)hipEventDestroy(ss.ev_dec1);
+    if (ss.ev_side) (void)hipEventDestroy(ss.ev_side);
+  }
+  if (ctx->pass2) (void)hipStreamDestroy(ctx->pass2);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
   return PXT_OK;
 }
 
 extern "C" int64_t pxt_unet_workspace_bytes_batch(const pxt_unet* ctx, int32_t n_images, int32_t H, int32_t W) {
   if (!ctx) return PXT_E_ARG;
-  Plan P;
-  if (!make_plan(ctx, n_images, H, W, P)) return 0;
-  return (int64_t)P.total;
+  Plan P, P1;
+  if (!make_plan(ctx, n_images, H, W, P) || !make_plan(ctx, 1, H, W, P1)) return 0;
+  // (a batch of two may run as two single-image passes in the two halves of the workspace)
+  return (int64_t)std::max(P.total, (size_t)n_images * P1.total);
 }
 
 extern "C" int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W) {
   return pxt_unet_workspace_bytes_batch(ctx, 1, H, W);
 }
 
-extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* images,
-                                      const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H,
-                                      int32_t W, float* const* out_maps, const int32_t out_cstride[3],
-                                      const int32_t* normalize, void* workspace, void* stream) {
+static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* images,
+                        const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H,
+                        int32_t W, float* const* out_maps, const int32_t out_cstride[3],
+                        const int32_t* normalize, void* workspace, void* stream, pxt_unet::SideSet& ss) {
   if (!ctx || !images || !image_is_u8 || !out_maps || !out_cstride || !normalize || !workspace) return PXT_E_ARG;
   Plan P;
   const int B = n_images;
@@ -644,11 +659,11 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   auto buf = [&](size_t off) { return (half_t*)(ws + off); };
   static const int block_first[5] = {0, 2, 4, 7, 10};
   static const int block_n[5] = {2, 2, 3, 3, 3};
-  if (!ctx->side) {
-    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_enc4, hipEventDisableTiming));
-    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_dec1, hipEventDisableTiming));
-    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_side, hipEventDisableTiming));
+  if (!ss.side) {
+    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_enc4, hipEventDisableTiming));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_dec1, hipEventDisableTiming));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_side, hipEventDisableTiming));
   }
   // 1x1 heads at output scales 0, 2, 4 (per image: separate output tensors and normalisation
   // flags).  The two coarse ones are small, latency-bound launches whose inputs (enc4, dec1) exist
@@ -722,9 +737,9 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   }
   // decoder
   pre[4] = skip[4];
-  PXT_HIP_CHECK(hipEventRecord(ctx->ev_enc4, s));
-  PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_enc4, 0));
-  launch_head(2, ctx->side);
+  PXT_HIP_CHECK(hipEventRecord(ss.ev_enc4, s));
+  PXT_HIP_CHECK(hipStreamWaitEvent(ss.side, ss.ev_enc4, 0));
+  launch_head(2, ss.side);
   const half_t* prev = skip[4];
   bool head0_fused = false;
   int ph = P.h[4], pw = P.w[4], pc = ctx->conv[12].cout;
@@ -755,17 +770,48 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;
     pre[3 - d] = o;
     if (d == 1) {  // dec1 feeds the stride-4 head
-      PXT_HIP_CHECK(hipEventRecord(ctx->ev_dec1, s));
-      PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_dec1, 0));
-      launch_head(1, ctx->side);
+      PXT_HIP_CHECK(hipEventRecord(ss.ev_dec1, s));
+      PXT_HIP_CHECK(hipStreamWaitEvent(ss.side, ss.ev_dec1, 0));
+      launch_head(1, ss.side);
     }
   }
   // (the heads were launched above: the two coarse ones on the side stream as soon as their input
   // existed, the fine one here)
   if (!head0_fused) launch_head(0, s);
-  PXT_HIP_CHECK(hipEventRecord(ctx->ev_side, ctx->side));
-  PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_side, 0));
+  PXT_HIP_CHECK(hipEventRecord(ss.ev_side, ss.side));
+  PXT_HIP_CHECK(hipStreamWaitEvent(s, ss.ev_side, 0));
   PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* images,
+                                      const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H,
+                                      int32_t W, float* const* out_maps, const int32_t out_cstride[3],
+                                      const int32_t* normalize, void* workspace, void* stream) {
+  if (!ctx || !images || !image_is_u8 || !out_maps || !out_cstride || !normalize || !workspace) return PXT_E_ARG;
+  static const int n_streams = [] { const char* e = getenv("PXT_UNET_STREAMS"); return e ? atoi(e) : 2; }();
+  if (n_images != 2 || n_streams < 2)
+    return forward_pass(ctx, n_images, images, image_is_u8, masks, H, W, out_maps, out_cstride, normalize, workspace,
+                        stream, ctx->sides[0]);
+  Plan P1;
+  if (!make_plan(ctx, 1, H, W, P1)) return PXT_E_ARG;
+  if (!ctx->pass2) {
+    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pass2, hipStreamNonBlocking));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  hipStream_t s = (hipStream_t)stream;
+  PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s));  // the second pass starts after the caller's earlier work
+  PXT_HIP_CHECK(hipStreamWaitEvent(ctx->pass2, ctx->ev_fork, 0));
+  const uint8_t* const no_mask[1] = {nullptr};
+  for (int im = 0; im < 2; ++im) {
+    int rc = forward_pass(ctx, 1, images + im, image_is_u8 + im, masks ? masks + im : no_mask, H, W, out_maps + 3 * im,
+                          out_cstride, normalize + im, (char*)workspace + (size_t)im * P1.total,
+                          im == 0 ? (void*)s : (void*)ctx->pass2, ctx->sides[im]);
+    if (rc != PXT_OK) return rc;
+  }
+  PXT_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->pass2));
+  PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
   return PXT_OK;
 }
 
