@@ -2,6 +2,8 @@
 // All are HBM-bound elementwise / stencil passes over at most a few MB.
 #include "pxt_common.h"
 
+#include <cstdlib>
+
 namespace pxt {
 
 // get_mask head (pixloc_tracker_r9.py:210-212 with run_vis_on_poses.py:53-54):
@@ -101,6 +103,125 @@ __global__ __launch_bounds__(256) void depth_mask_fused_kernel(const float* __re
   }
 }
 
+// The same mask on BIT PLANES.  A tile row is one 128-bit word (bit j = column x0 - 32 + j: the 64 tile columns
+// sit at bits 32..95, up to 32 halo columns on either side), built with two wave ballots per row; a box erosion /
+// dilation along x is a few shift-AND / shift-OR steps on that word (radius 10 = shifts 1, 2, 4, 3), along y an
+// AND / OR over neighbouring rows' words.  Bit for bit the result of the byte version above, which spent ~100 k
+// single-byte LDS reads per tile on it (26 us per 640x480 mask, on the frame's chain between the render and the
+// UNet; this one is bound by the latency of its input loads).
+struct Row128 {
+  unsigned long long lo, hi;
+};
+__device__ inline Row128 r_and(Row128 a, Row128 b) { return {a.lo & b.lo, a.hi & b.hi}; }
+__device__ inline Row128 r_or(Row128 a, Row128 b) { return {a.lo | b.lo, a.hi | b.hi}; }
+__device__ inline Row128 r_shl(Row128 a, int s) {  // towards higher columns; 0 < s < 64
+  return {a.lo << s, (a.hi << s) | (a.lo >> (64 - s))};
+}
+__device__ inline Row128 r_shr(Row128 a, int s) {
+  return {(a.lo >> s) | (a.hi << (64 - s)), a.hi >> s};
+}
+
+__global__ __launch_bounds__(256) void depth_mask_bits_kernel(const float* __restrict__ rgba, int H, int W, int re,
+                                                              int rd, uint8_t* __restrict__ out) {
+  __shared__ Row128 sA[kMH + 2 * 16], sB[kMH + 2 * 16];
+  const int R = re + rd;                 // <= 16
+  const int ah = kMH + 2 * R;            // rows y0 - R .. y0 + kMH + R - 1
+  const int x0 = blockIdx.x * kMW, y0 = blockIdx.y * kMH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- the `!= 0` plane: one row per wave trip, columns x0 - R .. x0 + 63 + R in two ballots; outside the
+  // image: 1 (neutral for the erosion)
+  for (int r = wave; r < ah; r += 4) {
+    const int yy = y0 - R + r;
+    unsigned long long w[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const int c = part * 64 + lane;      // column index within [0, 64 + 2R)
+      const int xx = x0 - R + c;
+      bool bit = true;
+      if (c < kMW + 2 * R && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float f = rgba[4 * ((size_t)yy * W + xx)] * 255.0f;
+        bit = (((long long)f & 255) != 0);  // numpy float32 -> uint8 astype, then != 0
+      }
+      w[part] = __ballot(bit);
+    }
+    if (lane == 0) {
+      // column c sits at bit 32 - R + c
+      Row128 v = {w[0], w[1]};
+      sA[r] = r_shl(v, 32 - R);            // 16 <= 32 - R <= 32 (R >= 0): bits below 32 - R are zero-filled ...
+      if (32 - R > 0) sA[r].lo |= (1ull << (32 - R)) - 1ull;  // ... make them neutral too
+    }
+  }
+  __syncthreads();
+  // ---- erosion along x, then along y (radius re); then clear everything outside the image (neutral for the
+  // dilation) - one thread per row
+  if (tid < ah) {
+    Row128 a = sA[tid], e = a;
+    for (int d = 1; d <= re; ++d) e = r_and(e, r_and(r_shl(a, d), r_shr(a, d)));
+    // r_shl / r_shr shift zeros in at the ends of the 128-bit word: those columns are > 16 away from the tile
+    sB[tid] = e;
+  }
+  __syncthreads();
+  if (tid < ah) {
+    Row128 e = {~0ull, ~0ull};
+    for (int d = -re; d <= re; ++d) {
+      const int q = tid + d;
+      if (q >= 0 && q < ah) e = r_and(e, sB[q]);  // rows beyond the staged band are > R away from the tile
+    }
+    const int yy = y0 - R + tid;
+    Row128 in_img = {0ull, 0ull};
+    if (yy >= 0 && yy < H) {
+      // columns 0 .. W-1 <-> bits 32 - x0 .. 32 - x0 + W - 1, clipped to [0, 128)
+      const int b_lo = max(32 - x0, 0), b_hi = min(32 - x0 + W, 128);  // [b_lo, b_hi)
+      for (int b = 0; b < 2; ++b) {
+        const int lo = max(b_lo - 64 * b, 0), hi = min(b_hi - 64 * b, 64);
+        unsigned long long mbits = 0ull;
+        if (hi > lo) mbits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+        (b == 0 ? in_img.lo : in_img.hi) = mbits;
+      }
+    }
+    sA[tid] = r_and(e, in_img);
+  }
+  __syncthreads();
+  // ---- dilation along x (radius rd in doubling shifts), then along y
+  if (tid < ah) {
+    Row128 d = sA[tid];
+    for (int covered = 0, step = 1; covered < rd; step *= 2) {
+      const int sft = min(step, rd - covered);
+      d = r_or(d, r_or(r_shl(d, sft), r_shr(d, sft)));
+      covered += sft;
+    }
+    sB[tid] = d;
+  }
+  __syncthreads();
+  if (tid < kMH) {
+    Row128 d = {0ull, 0ull};
+    const int rc = tid + R;  // this output row in the staged band
+    for (int q = rc - rd; q <= rc + rd; ++q) d = r_or(d, sB[q]);  // 0 <= rc - rd, rc + rd < ah
+    sA[tid] = d;
+  }
+  __syncthreads();
+  // ---- bits 32..95 of the 16 output rows -> bytes, 4 per thread
+  {
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const Row128 d = sA[r];
+    const int yy = y0 + r, xx = x0 + c4;
+    if (yy < H && xx < W) {
+      unsigned bytes = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = 32 + c4 + j;
+        const unsigned bit = (unsigned)(((b < 64 ? d.lo >> b : d.hi >> (b - 64))) & 1ull);
+        bytes |= bit << (8 * j);
+      }
+      if (xx + 3 < W && (W & 3) == 0) {
+        *(unsigned*)(out + (size_t)yy * W + xx) = bytes;
+      } else {
+        for (int j = 0; j < 4 && xx + j < W; ++j) out[(size_t)yy * W + xx + j] = (uint8_t)((bytes >> (8 * j)) & 1u);
+      }
+    }
+  }
+}
+
 // get_nerf_image tail (run_vis_on_poses.py:52-54): zero where alpha < thresh, *255,
 // astype(uint8).
 __global__ void rgba_to_u8_kernel(const float* __restrict__ rgba, int n, float alpha_thresh,
@@ -154,8 +275,13 @@ extern "C" int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int
   if (R <= 16) {
     const int aw = kMW + 2 * R, ah = kMH + 2 * R, bw = kMW + 2 * rd, ch = kMH + 2 * rd;
     const size_t lds = (size_t)ah * aw + (size_t)ah * bw + (size_t)ch * bw + (size_t)ch * kMW;
-    hipLaunchKernelGGL(depth_mask_fused_kernel, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(64, 4), lds, s,
-                       depth_rgba, H, W, re, rd, mask_out);
+    static const bool bytes_version = [] { const char* e = getenv("PXT_MASK_BYTES"); return e && atoi(e) != 0; }();
+    if (bytes_version)
+      hipLaunchKernelGGL(depth_mask_fused_kernel, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(64, 4), lds, s,
+                         depth_rgba, H, W, re, rd, mask_out);
+    else
+      hipLaunchKernelGGL(depth_mask_bits_kernel, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(256), 0, s,
+                         depth_rgba, H, W, re, rd, mask_out);
     PXT_HIP_CHECK(hipGetLastError());
     return PXT_OK;
   }
