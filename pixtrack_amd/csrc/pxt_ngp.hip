@@ -1007,31 +1007,36 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
 }
 
 __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk) {
-  // Eight lanes per pixel: lane j fetches spp pass j, j + 8, ... (coalesced 16-B reads), lane 0 of
-  // the group then adds them in pass order - the fixed order of a sequential mean.  All passes of
-  // a pixel share one ray (snap_to_pixel_centers), so a pixel whose ray misses the box has no
-  // finished rays to read: nothing zero-fills the buffers.
+  // One lane per pixel: it reads the pixel's spp finished rays (contiguous: 16 B x spp, whole lines per lane)
+  // and adds them in pass order - the fixed order of a sequential mean.  All passes of a pixel share one ray
+  // (snap_to_pixel_centers), so a pixel whose ray misses the box has no finished rays to read: nothing
+  // zero-fills the buffers.  (The first version spread a pixel over 8 lanes and funnelled the passes through
+  // 40 ds_bpermute shuffles per pixel: 21.6 us per 640x480x8 resolve.)
   const int wh = P.W * P.H;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int pix = gid >> 3, j = gid & 7;
-  const bool in_img = pix < wh;
-  const int pc = in_img ? pix : 0;
-  const bool hit = in_img && make_ray(P, pc % P.W, pc / P.W).hit;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= wh) return;
+  const bool hit = make_ray(P, pix % P.W, pix / P.W).hit;
   float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f, ad = 0.f;
-  for (int s0 = 0; s0 < P.spp; s0 += 8) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    float vd = 0.f;
-    if (hit && s0 + j < P.spp) {
-      v = Wk.sppbuf[(size_t)pc * P.spp + s0 + j];
-      if (P.out_depth) vd = Wk.sppbuf_d[(size_t)pc * P.spp + s0 + j];
-    }
-    const int cnt = min(8, P.spp - s0);
-    for (int k = 0; k < cnt; ++k) {  // sequential: ((v0 + v1) + v2) + ...
-      ar += __shfl(v.x, k, 8); ag += __shfl(v.y, k, 8); ab += __shfl(v.z, k, 8); aa += __shfl(v.w, k, 8);
-      if (P.out_depth) ad += __shfl(vd, k, 8);
+  if (hit) {
+    const float4* src = Wk.sppbuf + (size_t)pix * P.spp;
+    const float* srcd = Wk.sppbuf_d + (size_t)pix * P.spp;
+    for (int s0 = 0; s0 < P.spp; s0 += 8) {
+      float4 v[8];
+      float vd[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = (s0 + k < P.spp) ? src[s0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        vd[k] = (P.out_depth && s0 + k < P.spp) ? srcd[s0 + k] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // sequential: ((v0 + v1) + v2) + ...
+        if (s0 + k < P.spp) {
+          ar += v[k].x; ag += v[k].y; ab += v[k].z; aa += v[k].w;
+          if (P.out_depth) ad += vd[k];
+        }
+      }
     }
   }
-  if (!in_img || j != 0) return;
   const float inv = 1.0f / (float)P.spp;
   if (P.out_depth) {  // what a separate Depth-mode render would have written
     float4 od;
@@ -1411,7 +1416,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));
     PXT_HIP_CHECK(hipStreamWaitEvent(s0, ctx->ev_join[w], 0));
   }
-  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height * 8 + 255) / 256), dim3(256), 0, s0, P, ctx->work[0]);
+  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s0, P, ctx->work[0]);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }
