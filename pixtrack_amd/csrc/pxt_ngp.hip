@@ -729,32 +729,55 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
 // compaction launch of every round but the last (15-30 us each on a pipeline's serial chain).  Tiles land in
 // the order of their atomics, i.e. roughly in dispatch order: neighbours in the new list are still neighbours
 // in the image (unlike the per-wave queues tried in the shade kernel, profiles/r02_ngp_experiments.md #10).
+// FROM_INIT: the tile's items are enumerated rays generated in place (round 0: ray generation, box test,
+// compaction and the first march in one launch; every lane builds its own ray - the 8 passes of a pixel repeat
+// make_ray, which is cheaper than the launch it saves).
+template <bool FROM_INIT>
 __global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
-  const int n = Wk.counters[round * kCtrStride];
+  const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
   const RayState& S = Wk.st[round & 1];
-  const RayState& D = Wk.st[(round + 1) & 1];
-  int* out_count = Wk.counters + (round + 1) * kCtrStride;
+  const RayState& D = FROM_INIT ? Wk.st[0] : Wk.st[(round + 1) & 1];
+  int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tiles = (n + 255) / 256;
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int i = tile * 256 + threadIdx.x;
-    const bool kept = i < n && Wk.keep[i] != 0;
+  const long long tiles = (n + 255) / 256;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long i = tile * 256 + threadIdx.x;
+    bool kept;
+    // the survivor's record is fetched (or the new ray built) while the tile's base is still being negotiated
+    unsigned rid = 0;
+    float t = 0.f, T_ = 1.f, accd_ = 0.f;
+    float4 acc_ = make_float4(0.f, 0.f, 0.f, 0.f);
+    Ray r;
+    if (FROM_INIT) {
+      int px, py, sp;
+      kept = false;
+      if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
+        const int pix = py * P.W + px;
+        r = make_ray(P, px, py);
+        t = ray_start(P, r, pix, sp);
+        rid = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
+        kept = t >= 0.f;
+        // the shade kernel runs 8 lanes per ray per round: it reads the direction instead of redoing
+        // make_ray's fourteen divisions in every lane
+        if (kept) Wk.raydir[rid] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
+      }
+    } else {
+      kept = i < n && Wk.keep[i] != 0;
+      float4 rdir = make_float4(0.f, 0.f, 1.f, 0.f);
+      if (kept) {
+        rid = S.rid[i];
+        t = S.t[i];
+        T_ = S.T[i];
+        acc_ = S.acc[i];
+        accd_ = S.accd[i];
+        rdir = Wk.raydir[rid];
+      }
+      r = ray_from_record(P, rdir);
+    }
     const unsigned long long m = __ballot(kept);
     if (lane == 0) s_wave[wave] = __popcll(m);
-    // the survivor's record is fetched while the tile's base is still being negotiated
-    unsigned rid = 0;
-    float t = 0.f, T_ = 0.f, accd_ = 0.f;
-    float4 acc_ = make_float4(0.f, 0.f, 0.f, 0.f), rdir = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (kept) {
-      rid = S.rid[i];
-      t = S.t[i];
-      T_ = S.T[i];
-      acc_ = S.acc[i];
-      accd_ = S.accd[i];
-      rdir = Wk.raydir[rid];
-    }
     __syncthreads();
     int wave_off = 0, tile_total = 0;
 #pragma unroll
@@ -770,7 +793,6 @@ __global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams 
       D.T[slot] = T_;
       D.acc[slot] = acc_;
       D.accd[slot] = accd_;
-      const Ray r = ray_from_record(P, rdir);
       const size_t s0 = (size_t)slot * kK;
       int k = 0;
       bool out = false;
@@ -1360,14 +1382,20 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   const size_t shade_lds = 0;
   const int shade_grid = wide;
 #endif
+  static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
+  // (ray generation fused with the first march as well: measured, no gain - 0.952-0.956 vs 0.938-0.959 ms; the
+  // 256-ray tiles of a half image are 4800 atomics on one counter word.  Off.)
+  static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : false; }();
   for (int w = 0; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
-    hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
+    if (fuse_init)  // ray generation + compaction + the first march
+      hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
+    else
+      hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
-  static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
   for (int r = 0; r < kRounds; ++r) {
-    if (r == 0 || !fuse_cm)
+    if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
         hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
     for (int w = 0; w < n_pipe; ++w) {
@@ -1399,7 +1427,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     }
     for (int w = 0; w < n_pipe; ++w) {
       if (fuse_cm && r + 1 < kRounds)  // compaction of round r + march of round r + 1 in one launch
-        hipLaunchKernelGGL(ngp_compact_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        hipLaunchKernelGGL(ngp_compact_march_kernel<false>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
       else
         hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
     }
