@@ -336,6 +336,12 @@ inline int cfg_bnc(int cfg) { return 32 * kV2Cfgs[cfg].CW * kV2Cfgs[cfg].WC; }
 
 struct ConvPlan { int cfg, tiles, nb, splits; };
 
+// Passes running side by side on the chip (2 while a batch of two runs as two single-image passes): the tile
+// configuration, the split-K factor and the deep-ring choice look at the workgroups of ALL of them - a lone
+// 120x160 layer has 160-300 workgroups and would take the one-wave-per-SIMD configuration, two of those do not
+// share a CU.
+thread_local int g_conv_peers = 1;
+
 // Split-K factor: only the smallest maps (conv5: 12 tiles per image pair) leave most of the 256 CUs
 // without a workgroup; measured on the 60x80 layers (160 workgroups) every split loses to no split.
 int choose_splits(int wgs, int n_chunks, bool upcat) {
@@ -351,7 +357,7 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   ConvPlan P;
   auto wgs_of = [&](int cfg) {
     const int th = cfg_th(cfg);
-    return n_img * ((H + th - 1) / th) * ((W + 15) / 16) * (cout / cfg_bnc(cfg));
+    return g_conv_peers * n_img * ((H + th - 1) / th) * ((W + 15) / 16) * (cout / cfg_bnc(cfg));
   };
   int cfg = force_cfg;
   if (cfg < 1 || cfg > 6 || cfg == 3 || cfg == 5 || cout % cfg_bnc(cfg) != 0) {
@@ -365,7 +371,7 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   const int th = cfg_th(cfg);
   P.tiles = n_img * ((H + th - 1) / th) * ((W + 15) / 16);
   P.nb = cout / cfg_bnc(cfg);
-  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(P.tiles * P.nb, cin / 32, upcat)) : 1;
+  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(g_conv_peers * P.tiles * P.nb, cin / 32, upcat)) : 1;
   return P;
 }
 
@@ -442,7 +448,7 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
     return;
   }
   // <= 1 workgroup per CU: nothing hides a miss on the streamed taps but a deeper fragment ring
-  const bool deep = (long long)grid.x * grid.y * grid.z <= 256;
+  const bool deep = (long long)g_conv_peers * grid.x * grid.y * grid.z <= 256;
   switch (cfg) {
     case 1:
       if (deep) launch_v2<2, 4, 2, 2, false, 9>(a, grid, s);
@@ -804,6 +810,7 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s));  // the second pass starts after the caller's earlier work
   PXT_HIP_CHECK(hipStreamWaitEvent(ctx->pass2, ctx->ev_fork, 0));
   const uint8_t* const no_mask[1] = {nullptr};
+  struct Peers { Peers() { g_conv_peers = 2; } ~Peers() { g_conv_peers = 1; } } peers_guard;
   for (int im = 0; im < 2; ++im) {
     int rc = forward_pass(ctx, 1, images + im, image_is_u8 + im, masks ? masks + im : no_mask, H, W, out_maps + 3 * im,
                           out_cstride, normalize + im, (char*)workspace + (size_t)im * P1.total,
