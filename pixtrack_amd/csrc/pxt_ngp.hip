@@ -826,7 +826,11 @@ __global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, cons
   const float half_s = P.aabb_scale * 0.5f;
   const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
   const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
+#if PXT_EXP_ENC_LEVELS  // timing experiment (scripts/enc_levels.sh): only levels [lo, hi) are encoded, the image is wrong
+  for (long long item = blockIdx.x + chunks * (PXT_EXP_ENC_LEVELS >> 8); item < chunks * (PXT_EXP_ENC_LEVELS & 255); item += gridDim.x) {
+#else
   for (long long item = blockIdx.x + chunks * PXT_NGP_LDS_LEVELS; item < chunks * P.n_levels; item += gridDim.x) {
+#endif
     const int l = (int)(item / chunks);
     const long long s = (item % chunks) * 256 + threadIdx.x;
     if (s >= ns) continue;
