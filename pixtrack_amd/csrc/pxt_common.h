@@ -13,6 +13,7 @@ namespace pxt {
 
 // ---- error plumbing --------------------------------------------------------
 void set_last_error(const char* what, hipError_t e);
+hipStream_t shared_side_stream(int i);  // i in 0..2, per device, shared by all contexts (pxt_core.hip)
 #define PXT_HIP_CHECK(expr)                         \
   do {                                              \
     hipError_t _e = (expr);                         \

@@ -1228,7 +1228,6 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (ctx->occ) (void)hipFree(ctx->occ);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
-    if (ctx->side[w]) (void)hipStreamDestroy(ctx->side[w]);
     if (ctx->ev_join[w]) (void)hipEventDestroy(ctx->ev_join[w]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -1353,7 +1352,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   if (n_pipe > 1 && !ctx->ev_fork) {
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
-      PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side[w], hipStreamNonBlocking));
+      ctx->side[w] = pxt::shared_side_stream(w - 1);  // shared by all contexts of the device (pxt_core.hip)
+      if (!ctx->side[w]) return PXT_E_HIP;
       PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join[w], hipEventDisableTiming));
     }
   }

@@ -621,12 +621,10 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (ctx->dev_packed) (void)hipFree(ctx->dev_packed);
   if (ctx->dev_head0) (void)hipFree(ctx->dev_head0);
   for (auto& ss : ctx->sides) {
-    if (ss.side) (void)hipStreamDestroy(ss.side);
     if (ss.ev_enc4) (void)hipEventDestroy(ss.ev_enc4);
     if (ss.ev_dec1) (void)hipEventDestroy(ss.ev_dec1);
     if (ss.ev_side) (void)hipEventDestroy(ss.ev_side);
   }
-  if (ctx->pass2) (void)hipStreamDestroy(ctx->pass2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
@@ -666,7 +664,8 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
   static const int block_first[5] = {0, 2, 4, 7, 10};
   static const int block_n[5] = {2, 2, 3, 3, 3};
   if (!ss.side) {
-    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ss.side, hipStreamNonBlocking));
+    ss.side = pxt::shared_side_stream(&ss == &ctx->sides[0] ? 1 : 2);  // shared by all contexts (pxt_core.hip)
+    if (!ss.side) return PXT_E_HIP;
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_enc4, hipEventDisableTiming));
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_dec1, hipEventDisableTiming));
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ss.ev_side, hipEventDisableTiming));
@@ -802,7 +801,8 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   Plan P1;
   if (!make_plan(ctx, 1, H, W, P1)) return PXT_E_ARG;
   if (!ctx->pass2) {
-    PXT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pass2, hipStreamNonBlocking));
+    ctx->pass2 = pxt::shared_side_stream(0);
+    if (!ctx->pass2) return PXT_E_HIP;
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }

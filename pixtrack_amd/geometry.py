@@ -239,9 +239,16 @@ class Camera(TensorWrapper):
     def scale(self, scales: Union[float, int, Tuple[float, float]]) -> "Camera":
         if isinstance(scales, (int, float)):
             scales = (scales, scales)
-        s = self._data.new_tensor(scales)
-        data = torch.cat([self.size * s, self.f * s, (self.c + 0.5) * s - 0.5, self.dist], -1)
-        return self.__class__(data)
+        # memo per instance: the tracking loop rescales the same (immutable) cameras with the same pyramid
+        # factors seven times per frame, ~20 us of small tensor ops each on the host that feeds the GPU
+        key = (float(scales[0]), float(scales[1]))
+        memo = self.__dict__.setdefault("_scaled", {})
+        hit = memo.get(key)
+        if hit is None:
+            s = self._data.new_tensor(scales)
+            data = torch.cat([self.size * s, self.f * s, (self.c + 0.5) * s - 0.5, self.dist], -1)
+            hit = memo[key] = self.__class__(data)
+        return hit
 
     def in_image(self, p2d: torch.Tensor) -> torch.Tensor:
         size = self.size.unsqueeze(-2)

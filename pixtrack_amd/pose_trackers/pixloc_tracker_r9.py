@@ -223,7 +223,9 @@ class PixLocPoseTrackerR9(PoseTracker):
 
     def create_dynamic_reference_image(self, pose):
         nerf_img = self.get_reference_image(pose)
-        dynamic_id = hash(str(pose.numpy()[0]))
+        # (the reference hashes str(R); the id is only a dictionary key - the bytes of R serve, without numpy's
+        # array printer on the per-frame host path)
+        dynamic_id = hash(pose.numpy()[0].tobytes())
         features = self.localizer.refiner.extract_reference_features(self.reference_ids, pose, nerf_img)
         return dynamic_id, features
 

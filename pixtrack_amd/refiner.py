@@ -147,7 +147,11 @@ class PoseTrackerRefiner:
                                    p3dids: List[int], pose: Optional[Pose] = None,
                                    p3d: Optional[torch.Tensor] = None) -> SparseReferenceFeatures:
         image = self.model3d.dbs[image_id]
-        camera = Camera.from_colmap(self.model3d.cameras[image.camera_id]).scale(self.reference_scale)
+        ck = (image.camera_id, float(self.reference_scale))
+        cams_memo = self.__dict__.setdefault("_ref_cameras", {})  # model cameras are static: build each once
+        camera = cams_memo.get(ck)
+        if camera is None:
+            camera = cams_memo[ck] = Camera.from_colmap(self.model3d.cameras[image.camera_id]).scale(self.reference_scale)
         T_w2cam = Pose.from_colmap(image) if pose is None else pose
         if p3d is None:
             p3d = torch.from_numpy(np.array([self.model3d.points3D[p].xyz for p in p3dids], np.float32)).to(self.device)
