@@ -22,5 +22,5 @@ for i in range(5, n):
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(38)
 print(s.getvalue()[:9000])

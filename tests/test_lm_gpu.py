@@ -210,3 +210,27 @@ def test_config5_sized_problem(device):
     assert ref["success"] and not res.failed
     assert O.rotation_angle_rad(res.T.R.double(), ref["R"]) < ROT_TOL
     assert float((res.T.t.double() - ref["t"]).norm()) < TRANS_TOL
+
+
+def test_dirty_workspace_and_back_to_back_launches(device):
+    """The inter-workgroup exchange polls tagged granules in the workspace: every polled word is zeroed by the
+    launch's own memset, so a workspace full of garbage (or of the previous launch's tags) changes nothing, and
+    two refinements enqueued back to back on one workspace give the bits of two separate ones."""
+    sc = make_lm_scene(seed=1006, width=320, height=240, n_points=1200, sigma_px=2.0)
+    lam = lambdas(CONSTS)
+    opt = PixTrackOptimizer(dict(num_iters=150, pad=1))
+    packs = []
+    for level in reversed(range(3)):
+        fmap, fref, Cc, cam = pack_level(sc, level, device, sc.camera)
+        packs.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    nbytes = int(_lib.lib().pxt_lm_workspace_bytes())
+    clean = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    want = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), clean).result()
+    dirty = torch.full((nbytes,), 0xA5, dtype=torch.uint8, device=device)
+    got = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), dirty).result()
+    assert torch.equal(got.T.as12(), want.T.as12()) and got.iters == want.iters
+    first = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), dirty)
+    second = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), dirty)
+    r1, r2 = first.result(), second.result()
+    assert torch.equal(r1.T.as12(), want.T.as12()) and torch.equal(r2.T.as12(), want.T.as12())

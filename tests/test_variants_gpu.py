@@ -1,0 +1,30 @@
+"""Run-time variants of the hot path must be bit-identical: the compaction fused into the march vs separate
+launches, one vs two NeRF pipelines, the two UNet passes on two streams vs one batched pass, the bit-plane vs
+byte-plane mask kernel.  Each variant is a knob read once per process, so every run is a subprocess of
+scripts/variant_checksum.py; the digests of its outputs are compared."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _digests(env_extra):
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, str(ROOT / "scripts" / "variant_checksum.py"), "320", "240"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = dict(line.split()[1:3] for line in out.stdout.splitlines() if line.startswith("DIGEST"))
+    assert len(d) == 9, out.stdout
+    return d
+
+
+def test_runtime_variants_are_bit_identical():
+    base = _digests({})
+    for knobs in ({"PXT_NGP_FUSE_COMPACT_MARCH": "0"}, {"PXT_NGP_PIPES": "1"}, {"PXT_UNET_STREAMS": "1"},
+                  {"PXT_MASK_BYTES": "1"}):
+        assert _digests(knobs) == base, knobs
