@@ -391,7 +391,12 @@ def main():
     # Two untimed passes over the next frames of the same sequence.
     # (1) per-stage times: event pairs around every stage cost ~10 % of a frame, so they stay out
     #     of the timed region;
+    #     with the tracker's render-ahead off: a render enqueued behind the LM launch would be booked to "lm"
     n_stage = n_diag // 2
+    render_ahead = getattr(tracker, "render_ahead", False)
+    tracker.render_ahead = False
+    tracker._ahead_ok = None  # (the render queued behind the last timed frame's LM launch is not used either)
+    torch.cuda.synchronize()
     timer.enabled = True
     for i in range(n_timed_end, n_timed_end + n_stage):
         tracker.run_single_frame((names[i], frames[i]))
@@ -411,6 +416,7 @@ def main():
     iso_ms, iso_launches = tracker.testbed.timing_read()
     iso_samples = tracker.testbed.stats_accum.cpu().tolist()[0]
     iso_renders = tracker.testbed.n_renders - n_renders1
+    tracker.render_ahead = render_ahead
 
     extras = None
     if extras_on:
@@ -488,6 +494,8 @@ def main():
                    "n_points_per_reference": int(tracker.localizer.refiner._points_of(tracker.reference_ids)[1].shape[0]),
                    "parallelism": f"{ws} independent sequence(s), 1 process/GPU, final RCCL all_gather of poses",
                    "mask_and_reference_render_fused": bool(tracker._views_coincide()),
+                   "next_render_enqueued_behind_lm": bool(render_ahead),
+                   "renders_ahead_used": int(getattr(tracker, "renders_ahead_used", 0)),
                    "host_numa_node": numa_node},
         "tracked_ok": n_ok,
         "frames_total": total_frames,

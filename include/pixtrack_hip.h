@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (5), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (6), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -238,6 +238,18 @@ int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
  * (pixloc_tracker_r9.py:224,227); when those two cameras coincide the tracker uses this. */
 int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba, float* out_depth_rgba,
                         uint64_t* stats, void* stream);
+
+/* pxt_ngp_render_both of a view whose CAMERA is not known on the host yet: `pose12` (device-readable, e.g. the pinned
+ * record pxt_lm_refine writes: world->camera R row-major, then t, float32) is turned into the camera by a one-thread
+ * kernel ahead of the render in `stream`, in the float64 arithmetic of the host chain it replaces
+ * (pixtrack/utils/pose_utils.py:24-27 -> ingp_utils.py:47-63 -> Testbed.set_nerf_camera_matrix); view_host->cam is
+ * ignored.  conv27 (host): nerf2sfm centroid[3], 3 / avglen, R[16] row-major, totp[3], then the snapshot's scale and
+ * offset[3].  cam_out13 (optional, pinned host): the 12 camera floats + a completion word set last (system scope),
+ * so that the caller can verify, once the pose reaches it, that the render used the bits it would have passed itself.
+ * This lets a tracker enqueue frame t+1's render behind frame t's LM launch instead of after its result. */
+int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* view_host, const float* pose12,
+                                  const double* conv27_host, float* cam_out13, float* out_rgba,
+                                  float* out_depth_rgba, uint64_t* stats, void* stream);
 
 /* A render of >= 2^19 rays runs as n pipelines over equal slices of the rays, on the caller's
  * stream and n-1 internal side streams joined before the final resolve: the image is bit for bit

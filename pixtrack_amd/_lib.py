@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PxtError(RuntimeError):
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "pxt_ngp_destroy": (C.c_int, [_VP]),
     "pxt_ngp_render": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP]),
     "pxt_ngp_render_both": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP, _VP]),
+    "pxt_ngp_render_both_from_pose": (C.c_int, [_VP, C.POINTER(NgpView), _VP, C.POINTER(C.c_double), _VP, _VP, _VP, _VP, _VP]),
     "pxt_ngp_set_pipelines": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_enable": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_read": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),

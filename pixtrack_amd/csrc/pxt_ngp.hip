@@ -58,6 +58,7 @@ struct NgpParams {
   float aabb_scale, cone_angle, depth_scale, dt_lo, dt_hi;
   // view
   float cam[12];
+  const float* cam_dev;  // when set, the camera is read from here (written on the device: pxt_ngp_render_both_from_pose)
   float focal, k1;
   float lo[3], hi[3];
   float bg[4];
@@ -406,6 +407,18 @@ __device__ inline void ray_clip(const NgpParams& P, Ray& r) {
   r.hit = r.tmax > fmaxf(r.tmin, 0.f);
 }
 
+// The camera: a kernel argument, or - for a render enqueued before its pose is known on the host - 12 floats in
+// device memory that a one-thread kernel derived from the pose record of the LM kernel ahead of it in the stream.
+__device__ inline void load_camera(const NgpParams& P, float* cam) {
+  if (P.cam_dev) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cam[i] = P.cam_dev[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) cam[i] = P.cam[i];
+  }
+}
+
 __device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
   Ray r;
   const float u = ((float)px + 0.5f) / (float)P.W, vv = ((float)py + 0.5f) / (float)P.H;
@@ -421,10 +434,12 @@ __device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
     dxn = xu;
     dyn = yu;
   }
+  float cam[12];
+  load_camera(P, cam);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    r.d[a] = (dxn * P.cam[4 * a + 0] + dyn * P.cam[4 * a + 1]) + P.cam[4 * a + 2];
-    r.o[a] = P.cam[4 * a + 3];
+    r.d[a] = (dxn * cam[4 * a + 0] + dyn * cam[4 * a + 1]) + cam[4 * a + 2];
+    r.o[a] = cam[4 * a + 3];
   }
   const float nrm = sqrtf((r.d[0] * r.d[0] + r.d[1] * r.d[1]) + r.d[2] * r.d[2]);
 #pragma unroll
@@ -432,8 +447,8 @@ __device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
     r.d[a] = r.d[a] / nrm;
     r.idir[a] = 1.0f / r.d[a];
   }
-  const float fn = sqrtf((P.cam[2] * P.cam[2] + P.cam[6] * P.cam[6]) + P.cam[10] * P.cam[10]);
-  r.zdot = (r.d[0] * (P.cam[2] / fn) + r.d[1] * (P.cam[6] / fn)) + r.d[2] * (P.cam[10] / fn);
+  const float fn = sqrtf((cam[2] * cam[2] + cam[6] * cam[6]) + cam[10] * cam[10]);
+  r.zdot = (r.d[0] * (cam[2] / fn) + r.d[1] * (cam[6] / fn)) + r.d[2] * (cam[10] / fn);
   ray_clip(P, r);
   return r;
 }
@@ -447,7 +462,7 @@ __device__ inline Ray ray_from_record(const NgpParams& P, const float4 rd) {
   r.zdot = rd.w;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    r.o[a] = P.cam[4 * a + 3];
+    r.o[a] = P.cam_dev ? P.cam_dev[4 * a + 3] : P.cam[4 * a + 3];
     r.idir[a] = 1.0f / r.d[a];
   }
   ray_clip(P, r);
@@ -1032,6 +1047,60 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
   }
 }
 
+// Pose (world -> camera, row-major R then t: the LM kernel's record) -> the renderer's camera, on the device, in
+// the float64 arithmetic of the host chain it stands in for: get_camera_in_world_from_pixpose (pose_utils.py:24),
+// sfm_to_nerf_pose (ingp_utils.py:47-63), nerf_matrix_to_ngp.  The host recomputes the camera when the pose
+// reaches it and compares: a render that ran ahead of the host is used only if the 12 floats are the same bits.
+struct PoseConv {
+  double centroid[3], scale3_over_avglen, Rn[16], totp[3], ngp_scale, ngp_offset[3];
+};
+__global__ void ngp_pose_to_camera_kernel(const float* __restrict__ pose12, const PoseConv cv, float* __restrict__ cam_dev,
+                                          float* __restrict__ cam_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double R[9], t[3];
+  for (int i = 0; i < 9; ++i) R[i] = (double)pose12[i];
+  for (int i = 0; i < 3; ++i) t[i] = (double)pose12[9 + i];
+  // camera in world: [R^T | (-R^T) t]
+  double c[16];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) c[4 * i + j] = R[3 * j + i];
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) acc += (-R[3 * k + i]) * t[k];
+    c[4 * i + 3] = acc;
+  }
+  c[12] = c[13] = c[14] = 0.0; c[15] = 1.0;
+  // sfm_to_nerf_pose: camera y/z flip (columns 1, 2), rows 0 <-> 1, row 2 negated, recentre, scale, rotate, recentre
+  for (int i = 0; i < 4; ++i) { c[4 * i + 1] = -c[4 * i + 1]; c[4 * i + 2] = -c[4 * i + 2]; }
+  for (int j = 0; j < 4; ++j) { const double a = c[j]; c[j] = c[4 + j]; c[4 + j] = a; }
+  for (int j = 0; j < 4; ++j) c[8 + j] = -c[8 + j];
+  for (int i = 0; i < 3; ++i) { c[4 * i + 3] -= cv.centroid[i]; c[4 * i + 3] *= cv.scale3_over_avglen; }
+  double p[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += cv.Rn[4 * i + k] * c[4 * k + j];
+      p[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 3; ++i) p[4 * i + 3] -= cv.totp[i];
+  // nerf_matrix_to_ngp: flip camera y/z, scale + offset the origin, rows (x, y, z) <- (y, z, x)
+  double m[12];
+  for (int i = 0; i < 3; ++i) {
+    m[4 * i + 0] = p[4 * i + 0];
+    m[4 * i + 1] = -p[4 * i + 1];
+    m[4 * i + 2] = -p[4 * i + 2];
+    m[4 * i + 3] = p[4 * i + 3] * cv.ngp_scale + cv.ngp_offset[i];
+  }
+  const int perm[3] = {1, 2, 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const float v = (float)m[4 * perm[i] + j];
+      cam_dev[4 * i + j] = v;
+      if (cam_out) cam_out[4 * i + j] = v;
+    }
+  // cam_out[12] flips to 1 once the 12 floats are visible system-wide (the host polls it in pinned memory)
+  if (cam_out) __hip_atomic_store(&cam_out[12], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk) {
   // One lane per pixel: it reads the pixel's spp finished rays (contiguous: 16 B x spp, whole lines per lane)
   // and adds them in pass order - the fixed order of a sequential mean.  All passes of a pixel share one ray
@@ -1124,10 +1193,13 @@ struct pxt_ngp {
   unsigned grid_bytes = 0;
   pxt::half8* wfrag = nullptr;
   uint8_t* occ = nullptr;
+  float* cam_dev = nullptr;  // 12 floats: the camera of a render enqueued ahead of its pose (render_both_from_pose)
   pxt::NgpLevel lv[pxt::kMaxLevels];
   // scratch of the wavefront renderer, grown on demand (rays = W*H*spp)
   void* scratch = nullptr;
   size_t scratch_rays = 0;
+  size_t scratch_cap = 0;   // rays one pipeline's buffers hold
+  int scratch_pipes = 0;    // pipelines the scratch was laid out for
   static constexpr int kMaxPipes = 4;
   pxt::NgpWork work[kMaxPipes];            // independent pipelines over equal slices of the rays
   hipStream_t side[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};  // streams of pipelines 1..
@@ -1209,6 +1281,7 @@ extern "C" int pxt_ngp_create(const pxt_ngp_model* model, const void* grid_param
   hipError_t e = hipMalloc((void**)&ctx->grid, (size_t)off * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->wfrag, frag.size() * 2);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->occ, (size_t)n_occ_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->cam_dev, 16 * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(ctx->grid, grid_params, (size_t)off * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ctx->wfrag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(ctx->occ, occupancy, (size_t)n_occ_bytes, hipMemcpyHostToDevice);
@@ -1226,6 +1299,7 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (ctx->grid) (void)hipFree(ctx->grid);
   if (ctx->wfrag) (void)hipFree(ctx->wfrag);
   if (ctx->occ) (void)hipFree(ctx->occ);
+  if (ctx->cam_dev) (void)hipFree(ctx->cam_dev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
     if (ctx->ev_join[w]) (void)hipEventDestroy(ctx->ev_join[w]);
@@ -1266,8 +1340,18 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
 // Scratch for a render of `rays` enumerated rays.  Per-pipeline buffers (live-ray state, samples,
 // features) are sized for half the rays each; the per-ray result buffers indexed by ray id
 // (finished passes, direction records) are shared.
-static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
-  if (ctx->scratch && ctx->scratch_rays >= rays) return PXT_OK;
+// Per-pipeline buffers hold the pipeline's whole slice of the rays (every ray of a slice may hit the box): `cap` =
+// the largest slice.  (The first version sized them for half the rays whatever the number of pipelines: a
+// one-pipeline render - any render below 2^19 rays - whose camera sees the box in more than half of its pixels
+// wrote past them.)
+static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
+  size_t cap = (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile;
+  if (ctx->scratch && ctx->scratch_rays >= rays && ctx->scratch_cap >= cap && ctx->scratch_pipes >= n_pipe) return PXT_OK;
+  // grow only: a context that alternates between pipeline counts (bench: the isolated one-pipeline pass) keeps
+  // the larger layout
+  cap = std::max(cap, ctx->scratch_cap);
+  n_pipe = std::max(n_pipe, ctx->scratch_pipes);
+  rays = std::max(rays, ctx->scratch_rays);
   if (ctx->scratch) {
     hipError_t e0 = hipDeviceSynchronize();
     (void)e0;
@@ -1275,8 +1359,8 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
     ctx->scratch = nullptr;
   }
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  const int kP = pxt_ngp::kMaxPipes;
-  const size_t half = (rays + 1) / 2 + kTile;  // the largest slice (two pipelines), rounded to whole tiles
+  const int kP = n_pipe;
+  const size_t half = cap;
   const size_t samples = half * kK;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
@@ -1315,16 +1399,25 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays) {
     W.feat_stride = samples;
   }
   ctx->scratch_rays = rays;
+  ctx->scratch_cap = cap;
+  ctx->scratch_pipes = n_pipe;
   return PXT_OK;
 }
 
 static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
-                       uint64_t* stats, void* stream) {
+                       uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
+                       float* cam_out = nullptr) {
   if (!ctx || !v || !out_rgba) return PXT_E_ARG;
   if (v->width < 1 || v->height < 1 || v->spp < 1 || !(v->focal > 0.f)) return PXT_E_ARG;
   NgpParams P;
   fill_model(ctx, P);
   for (int i = 0; i < 12; ++i) P.cam[i] = v->cam[i];
+  if (pose_src) {  // the camera is derived on the device, in stream order, from a pose record the host has not seen
+    if (!conv) return PXT_E_ARG;
+    hipLaunchKernelGGL(ngp_pose_to_camera_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pose_src, *conv, ctx->cam_dev,
+                       cam_out);
+    P.cam_dev = ctx->cam_dev;
+  }
   P.focal = v->focal;
   P.k1 = v->k1;
   for (int i = 0; i < 3; ++i) { P.lo[i] = v->aabb_min[i]; P.hi[i] = v->aabb_max[i]; }
@@ -1337,8 +1430,6 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // padded to whole 4x2 pixel blocks (the enumeration order of enum_ray)
   const size_t rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
   if (rays > 0x7fffffffull / kK) return PXT_E_ARG;
-  int rc = ensure_scratch(ctx, rays);
-  if (rc != PXT_OK) return rc;
   hipStream_t s0 = (hipStream_t)stream;
 
   // Two pipelines over the two halves of the ray enumeration, on the caller's stream and on a
@@ -1349,6 +1440,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   static const int env_pipes = [] { const char* e = getenv("PXT_NGP_PIPES"); return e ? atoi(e) : 2; }();
   const int want_pipes = ctx->pipelines > 0 ? ctx->pipelines : env_pipes;
   const int n_pipe = rays >= ((size_t)1 << 19) ? std::min(std::max(want_pipes, 1), pxt_ngp::kMaxPipes) : 1;
+  int rc = ensure_scratch(ctx, rays, n_pipe);
+  if (rc != PXT_OK) return rc;
   if (n_pipe > 1 && !ctx->ev_fork) {
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
@@ -1463,6 +1556,20 @@ extern "C" int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* v, float* o
                                    uint64_t* stats, void* stream) {
   if (!out_depth_rgba) return PXT_E_ARG;
   return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream);
+}
+
+extern "C" int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* v, const float* pose12,
+                                             const double* conv27, float* cam_out13, float* out_rgba,
+                                             float* out_depth_rgba, uint64_t* stats, void* stream) {
+  if (!pose12 || !conv27 || !out_depth_rgba) return PXT_E_ARG;
+  PoseConv cv;
+  for (int i = 0; i < 3; ++i) cv.centroid[i] = conv27[i];
+  cv.scale3_over_avglen = conv27[3];
+  for (int i = 0; i < 16; ++i) cv.Rn[i] = conv27[4 + i];
+  for (int i = 0; i < 3; ++i) cv.totp[i] = conv27[20 + i];
+  cv.ngp_scale = conv27[23];
+  for (int i = 0; i < 3; ++i) cv.ngp_offset[i] = conv27[24 + i];
+  return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream, pose12, &cv, cam_out13);
 }
 
 extern "C" int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n) {

@@ -405,6 +405,32 @@ class Testbed:
         self.n_renders += 1
         return rgba, depth
 
+    def pose_conversion(self, nerf2sfm) -> list:
+        """The 27 doubles pxt_ngp_render_both_from_pose needs to turn a world->camera pose into this testbed's
+        camera: nerf2sfm centroid, 3 / avglen, R (4x4 row-major), totp, then the snapshot's scale and offset."""
+        off = np.broadcast_to(np.asarray(self._snap.offset, np.float64), (3,))
+        return ([float(x) for x in np.asarray(nerf2sfm["centroid"], np.float64).reshape(3)]
+                + [3.0 / float(nerf2sfm["avglen"])]
+                + [float(x) for x in np.asarray(nerf2sfm["R"], np.float64).reshape(16)]
+                + [float(x) for x in np.asarray(nerf2sfm["totp"], np.float64).reshape(3)]
+                + [float(self._snap.scale)] + [float(x) for x in off])
+
+    def render_both_from_pose_device(self, width: int, height: int, spp: int, pose_record: torch.Tensor, conv: list):
+        """render_both_device for a pose the host has not seen yet: `pose_record` is the pinned record of an
+        ENQUEUED refinement (optimizer.PendingLM.buf); the camera is derived from it on the device, in stream
+        order.  Returns (rgba, depth, cam_out): cam_out (pinned, 16 floats) receives the 12 camera floats the
+        render used and, last, cam_out[12] = 1."""
+        assert self._ctx is not None, "load_snapshot first"
+        if not self.snap_to_pixel_centers:
+            raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
+        rgba = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
+        depth = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
+        cam_out = torch.zeros(16, dtype=torch.float32).pin_memory()
+        ops.ngp_render_both_from_pose(self._ctx_int(), self._view_for(width, height), pose_record, conv, int(width),
+                                      int(height), int(spp), rgba, depth, cam_out, self.stats_accum)
+        self.n_renders += 1
+        return rgba, depth, cam_out
+
     def _ctx_int(self) -> int:
         return int(self._ctx.value) if hasattr(self._ctx, "value") else int(self._ctx)
 

@@ -321,8 +321,13 @@ class PoseTrackerRefiner:
             packs.append(LevelPack(features_query[level], ref.packed[level], OUTPUT_DIMS[level],
                                    qcamera.scale(scales_query[level]), opt.dampingnet()))
         opt0 = self.optimizer[order[0]] if isinstance(self.optimizer, (list, tuple)) else self.optimizer
-        res = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws,
-                                              mask=ref.valid).result()
+        pending = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws, mask=ref.valid)
+        # the refinement is enqueued, its result not yet awaited: a caller may queue work behind it that reads the
+        # pose record on the device (the tracker's next render, pixloc_tracker_r9._render_ahead)
+        hook = getattr(self, "after_lm_enqueued", None)
+        if hook is not None:
+            hook(pending)
+        res = pending.result()
         self.last_lm.append(res)
         # replay the iteration log into the tracker hooks, level by level (only when someone listens:
         # DebugTracker ignores everything below debug level 1, tracker.py:33-34)
