@@ -246,6 +246,7 @@ int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_
  * ignored.  conv27 (host): nerf2sfm centroid[3], 3 / avglen, R[16] row-major, totp[3], then the snapshot's scale and
  * offset[3].  cam_out13 (optional, pinned host): the 12 camera floats + a completion word set last (system scope),
  * so that the caller can verify, once the pose reaches it, that the render used the bits it would have passed itself.
+ * out_depth_rgba == NULL: ONE render in view_host->mode (0 Shade, 1 Depth) into out_rgba.
  * This lets a tracker enqueue frame t+1's render behind frame t's LM launch instead of after its result. */
 int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* view_host, const float* pose12,
                                   const double* conv27_host, float* cam_out13, float* out_rgba,

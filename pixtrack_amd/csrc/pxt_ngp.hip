@@ -1558,10 +1558,12 @@ extern "C" int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* v, float* o
   return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream);
 }
 
+// out_depth_rgba != NULL: Shade + Depth in one march (pxt_ngp_render_both); NULL: one render in view->mode.
 extern "C" int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* v, const float* pose12,
                                              const double* conv27, float* cam_out13, float* out_rgba,
                                              float* out_depth_rgba, uint64_t* stats, void* stream) {
-  if (!pose12 || !conv27 || !out_depth_rgba) return PXT_E_ARG;
+  if (!v || !pose12 || !conv27) return PXT_E_ARG;
+  if (!out_depth_rgba && v->mode != 0 && v->mode != 1) return PXT_E_ARG;
   PoseConv cv;
   for (int i = 0; i < 3; ++i) cv.centroid[i] = conv27[i];
   cv.scale3_over_avglen = conv27[3];
@@ -1569,7 +1571,7 @@ extern "C" int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* v
   for (int i = 0; i < 3; ++i) cv.totp[i] = conv27[20 + i];
   cv.ngp_scale = conv27[23];
   for (int i = 0; i < 3; ++i) cv.ngp_offset[i] = conv27[24 + i];
-  return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream, pose12, &cv, cam_out13);
+  return render_impl(ctx, v, out_depth_rgba ? 2 : v->mode, out_rgba, out_depth_rgba, stats, stream, pose12, &cv, cam_out13);
 }
 
 extern "C" int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n) {

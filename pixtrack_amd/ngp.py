@@ -427,9 +427,22 @@ class Testbed:
         depth = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
         cam_out = torch.zeros(16, dtype=torch.float32).pin_memory()
         ops.ngp_render_both_from_pose(self._ctx_int(), self._view_for(width, height), pose_record, conv, int(width),
-                                      int(height), int(spp), rgba, depth, cam_out, self.stats_accum)
+                                      int(height), int(spp), 0, rgba, depth, cam_out, self.stats_accum)
         self.n_renders += 1
         return rgba, depth, cam_out
+
+    def render_from_pose_device(self, width: int, height: int, spp: int, pose_record: torch.Tensor, conv: list):
+        """render_device (in the current render_mode) for a pose that is still on the device; see
+        render_both_from_pose_device.  Returns (rgba, cam_out)."""
+        assert self._ctx is not None, "load_snapshot first"
+        if not self.snap_to_pixel_centers:
+            raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
+        out = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
+        cam_out = torch.zeros(16, dtype=torch.float32).pin_memory()
+        ops.ngp_render_both_from_pose(self._ctx_int(), self._view_for(width, height), pose_record, conv, int(width),
+                                      int(height), int(spp), int(self.render_mode), out, None, cam_out, self.stats_accum)
+        self.n_renders += 1
+        return out, cam_out
 
     def _ctx_int(self) -> int:
         return int(self._ctx.value) if hasattr(self._ctx, "value") else int(self._ctx)

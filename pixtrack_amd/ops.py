@@ -48,8 +48,8 @@ SCHEMAS = {
         "(int ctx, float[] view, int width, int height, int spp, Tensor(a!) rgba, Tensor(b!) depth, "
         "Tensor(c!)? stats) -> ()"),
     "ngp_render_both_from_pose": (
-        "(int ctx, float[] view, Tensor pose_record, float[] conv, int width, int height, int spp, Tensor(a!) rgba, "
-        "Tensor(b!) depth, Tensor(c!) cam_out, Tensor(d!)? stats) -> ()"),
+        "(int ctx, float[] view, Tensor pose_record, float[] conv, int width, int height, int spp, int mode, "
+        "Tensor(a!) rgba, Tensor(b!)? depth, Tensor(c!) cam_out, Tensor(d!)? stats) -> ()"),
     "depth_mask": "(Tensor depth_rgba, int n_erode, int n_dilate, Tensor(a!) mask, Tensor(b!) scratch) -> ()",
     "rgba_to_u8": "(Tensor rgba, float alpha_thresh, Tensor(a!) out) -> ()",
     "resize_linear": "(Tensor src, Tensor(a!) dst) -> ()",
@@ -214,21 +214,23 @@ def _ngp_render_both(ctx, view, width, height, spp, rgba, depth, stats):
                                               _stream(rgba)), "pxt_ngp_render_both")
 
 
-def _ngp_render_both_from_pose(ctx, view, pose_record, conv, width, height, spp, rgba, depth, cam_out, stats):
+def _ngp_render_both_from_pose(ctx, view, pose_record, conv, width, height, spp, mode, rgba, depth, cam_out, stats):
     """pxt_ngp_render_both with the camera derived ON THE DEVICE from `pose_record` (pinned float32, >= 12 floats:
     the record pxt_lm_refine writes), so that the render can be enqueued behind the LM launch.  `cam_out`: pinned
-    float32 [>= 13], receives the camera + a completion word."""
+    float32 [>= 13], receives the camera + a completion word.  `depth` given: Shade + Depth in one march (`mode`
+    ignored); None: one render in `mode` (0 Shade, 1 Depth) into `rgba`."""
     _check_frame(rgba, width, height, "rgba")
-    _check_frame(depth, width, height, "depth")
+    if depth is not None:
+        _check_frame(depth, width, height, "depth")
     for t, n, what in ((pose_record, 12, "pose_record"), (cam_out, 13, "cam_out")):
         if t.dtype != torch.float32 or t.numel() < n or t.is_cuda or not t.is_pinned():
             raise _lib.PxtError(f"{what} must be a pinned host float32 tensor of >= {n} elements")
     if len(conv) != 27:
         raise _lib.PxtError("conv holds 27 doubles (nerf2sfm centroid, 3/avglen, R, totp, snapshot scale, offset)")
-    v = _view(view, width, height, spp, 0)
+    v = _view(view, width, height, spp, int(mode) if depth is None else 0)
     cv = (C.c_double * 27)(*[float(x) for x in conv])
     _lib.check(_lib.lib().pxt_ngp_render_both_from_pose(ctx, C.byref(v), pose_record.data_ptr(), cv, cam_out.data_ptr(),
-                                                        rgba.data_ptr(), depth.data_ptr(), _lib.dptr(stats),
+                                                        rgba.data_ptr(), _lib.dptr(depth), _lib.dptr(stats),
                                                         _stream(rgba)), "pxt_ngp_render_both_from_pose")
 
 

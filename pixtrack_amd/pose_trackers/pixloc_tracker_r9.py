@@ -260,7 +260,7 @@ class PixLocPoseTrackerR9(PoseTracker):
 
     def get_mask(self, pose) -> torch.Tensor:
         """uint8 [H,W] on the device: depth render != 0, erode 5x5 x1, dilate 5x5 x5."""
-        if self._ahead_ok is not None and self._ahead_ok[0] is pose and self._views_coincide():
+        if self._ahead_ok is not None and self._ahead_ok[0] is pose:
             _, mask, ref_u8 = self._ahead_ok
             self._ahead_ok = None
             self._fused_reference = (pose, ref_u8)
@@ -289,12 +289,27 @@ class PixLocPoseTrackerR9(PoseTracker):
         whose camera a one-thread kernel derives from the LM kernel's pose record on the device."""
         import math
 
-        width, height, fl_x = self._coincide_cache[2]
-        self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
         conv = self.__dict__.get("_pose_conv")
         if conv is None:
             conv = self._pose_conv = self.testbed.pose_conversion(self.nerf2sfm)
-        rgba, depth, cam_out = self.testbed.render_both_from_pose_device(width, height, self.spp, pending.buf, conv)
+
+        def fov_of(cam):
+            w, h = (int(v) for v in cam.size)
+            return w, h, math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
+
+        if self._views_coincide():  # one march yields the mask's depth and the reference image
+            width, height, fl_x = self._coincide_cache[2]
+            self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
+            rgba, depth, cam_out = self.testbed.render_both_from_pose_device(width, height, self.spp, pending.buf, conv)
+        else:  # two renders: Depth with the query camera, Shade with SfM camera 1 x reference_scale (:145-152, :207-214)
+            width, height, self.testbed.fov = fov_of(self.camera)
+            self.testbed.render_mode = self.testbed.render_mode.Depth
+            try:
+                depth, cam_out = self.testbed.render_from_pose_device(width, height, self.spp, pending.buf, conv)
+            finally:
+                self.testbed.render_mode = self.testbed.render_mode.Shade
+            rw, rh, self.testbed.fov = fov_of(self._reference_camera())
+            rgba, _ = self.testbed.render_from_pose_device(rw, rh, self.spp, pending.buf, conv)
         ref_u8 = rgba_to_u8(rgba, 0.0)
         mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
         tmp = torch.empty(2 * height * width, dtype=torch.uint8, device=self.device)
@@ -344,7 +359,7 @@ class PixLocPoseTrackerR9(PoseTracker):
         steady = (not self.cold_start and self.success and refiner.query_mask is not None
                   and refiner.conf.multiscale == [1] and len(self.reference_ids) == 1)
         self._ahead = None
-        refiner.after_lm_enqueued = self._render_ahead if (self.render_ahead and steady and self._views_coincide()) else None
+        refiner.after_lm_enqueued = self._render_ahead if (self.render_ahead and steady) else None
         self.dynamic_id = self.get_dynamic_id(self.pose)
         rotation, translation = self.pose.numpy()
         rotation = R.from_matrix(rotation).as_matrix()

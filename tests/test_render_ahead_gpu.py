@@ -53,12 +53,14 @@ def test_device_camera_and_render_equal_the_host_path(device):
     assert same >= 22  # the two chains may differ in a last float64 bit (BLAS vs sequential products); the tracker checks
 
 
-def test_tracking_is_identical_with_and_without_render_ahead(device):
+@pytest.mark.parametrize("fused", [True, False])
+def test_tracking_is_identical_with_and_without_render_ahead(device, fused):
     n = 14
     assets = make_tracking_assets(seed=1002, width=320, height=240, n_frames=n)
     hist = {}
     for ahead in (False, True):
         tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+        tr.fuse_identical_views = fused  # False: mask and reference image are two renders (the real-asset case)
         tr.render_ahead = ahead
         frames = render_query_frames(assets, tr.testbed)
         for i in range(n):
