@@ -177,6 +177,10 @@ __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, c
   return pack_h2(f0, f1);
 }
 
+#ifndef PXT_NGP_PAIR  // experiment 16 (profiles/r02_ngp_experiments.md): bit-exact, no gain; off
+#define PXT_NGP_PAIR 0
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned uint2_t;
 // The same level, for a caller whose level is wave-uniform (the level-major encoder): identical indices and
 // arithmetic, with the integer work pared down - the two y and two z hash products (or row / plane
 // offsets) are formed once and shared by the 8 corners (v_mul_lo_u32 is quarter rate), and the gathers
@@ -194,11 +198,45 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
     const unsigned mask = Lv.size - 1u;
     const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
     const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
+#if PXT_NGP_PAIR
+    // The x-neighbours of an even gx hash to idx and idx ^ 1 (the x term enters the hash unmultiplied): one
+    // 8-byte load of the aligned pair serves both corners.  An odd gx needs its +1 corners separately; for an
+    // even gx those four loads carry an offset beyond the buffer's range, which the address unit drops
+    // (returns 0, no cache access; PXT_NGP_PAIR=2 masks them with the exec mask instead): 6 L1 lookups per level
+    // instead of 8.  Measured: render unchanged - the encoder is not bound by lookups per lane either.
+    const bool odd = (gx & 1u) != 0;
+    uint2_t pr[4];
+    unsigned single[4] = {0u, 0u, 0u, 0u};
+    unsigned i0s[4], i1s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned h = hy[c & 1] ^ hz[(c >> 1) & 1];
+      i0s[c] = (gx ^ h) & mask;
+      i1s[c] = ((gx + 1u) ^ h) & mask;
+      pr[c] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(grid, (int)((i0s[c] & ~1u) << 2), base, 0));
+    }
+#if PXT_NGP_PAIR == 2
+    if (odd) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) single[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(i1s[c] << 2), base, 0);
+    }
+#else
+#pragma unroll
+    for (int c = 0; c < 4; ++c) single[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, odd ? (int)(i1s[c] << 2) : (int)0xfffffff0u, base, 0);
+#endif
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool hi = (i0s[c] & 1u) != 0;
+      vals[2 * c] = hi ? pr[c].y : pr[c].x;
+      vals[2 * c + 1] = odd ? single[c] : (hi ? pr[c].x : pr[c].y);
+    }
+#else
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const unsigned idx = ((gx + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask;
       vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
     }
+#endif
   } else {
     const unsigned r2 = Lv.res * Lv.res;
     const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
