@@ -39,6 +39,9 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
+# the dominant kernel: gathers + both MLPs of a round's samples (Shade + Depth of the same rays: MODE 2)
+GATHER_KERNEL = "ngp_shade_kernel<2, true> (hash-grid gathers + MLPs of its own samples)"
+GATHER_KERNEL_PMC = "pxt::ngp_shade_kernel<2, true>"
 
 
 class StageTimer:
@@ -358,7 +361,7 @@ def main():
     start_pose = tracker.pose.numpy()
     tracker.testbed.stats_accum.zero_()
     n_renders0 = tracker.testbed.n_renders
-    # HIP events around the ngp_encode_kernel launches of every 4th render: live over the timed
+    # HIP events around the gather-kernel launches (GATHER_KERNEL) of every 4th render: live over the timed
     # region, sampled so that the marker packets do not slow what they measure
     tracker.testbed.timing_enable(4)
 
@@ -403,7 +406,7 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = False
     # (2) the dominant kernel in isolation: one render pipeline (no overlapping second slice),
-    #     events around every encode launch, nothing else instrumented.
+    #     events around every gather-kernel launch, nothing else instrumented.
     tracker.testbed.set_pipelines(1)
     tracker.testbed.timing_enable(1)
     tracker.testbed.stats_accum.zero_()
@@ -430,11 +433,13 @@ def main():
     if rank != 0:
         return
     stage = timer.totals_ms()
-    # dominant kernel: ngp_encode_kernel (level-major hash-grid gathers), kRounds launches per render.
+    # dominant kernel: the round's gather kernel - ngp_shade_kernel<MODE, true>, which gathers the hash-grid features
+    # of its own samples and runs both MLPs on them (PXT_NGP_INLINE_FROM=5: the separate level-major
+    # ngp_encode_kernel of the first half of round 2); kRounds launches per render and pipeline.
     # ALGORITHMIC bytes per launch = composited samples per launch x 512 B; samples the
     # rounds evaluate past a ray's termination are waste and are not credited.
     enc_avg_ms = enc_ms / max(enc_launches, 1)          # over the timed (sampled) launches
-    # encode launches per render (5 rounds x the renderer's pipeline count), from the sampled renders
+    # gather launches per render (5 rounds x the renderer's pipeline count), from the sampled renders
     sampled_renders = (n_renders + 3) // 4
     launches_total = int(round(enc_launches / max(sampled_renders, 1))) * n_renders
     samples_per_launch = stats[0] / max(launches_total, 1)
@@ -454,14 +459,15 @@ def main():
     traffic, traffic_src = None, None
     pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
     if pmc.exists():
-        rec = json.loads(pmc.read_text()).get("pxt::ngp_encode_kernel")
+        recs = json.loads(pmc.read_text())
+        rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void pxt::" + GATHER_KERNEL_PMC)
         if rec:
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
             traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
     iso_avg_ms = iso_ms / max(iso_launches, 1)
     iso_spl = iso_samples / max(iso_renders * 5, 1)  # one pipeline: 5 launches per render
     iso_achieved = iso_spl * NERF_BYTES_PER_SAMPLE / (iso_avg_ms * 1e-3) / 1e9 if iso_avg_ms > 0 else 0.0
-    roofline = {"kernel": "ngp_encode_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+    roofline = {"kernel": GATHER_KERNEL, "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_unit": "MB per launch", "traffic_source": traffic_src,
                 "algorithmic_mb_per_launch": round(samples_per_launch * NERF_BYTES_PER_SAMPLE / 1e6, 2),

@@ -902,10 +902,19 @@ __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, b
   Wk.sppbuf[rid] = acc;
 }
 
-template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
+#ifndef PXT_NGP_INLINE_GROUP
+#define PXT_NGP_INLINE_GROUP 4
+#endif
+// INLINE: the wave encodes its own 64 samples (all levels, same function as the encoder: same bits) instead of
+// reading feat[] - for the late rounds, whose few samples make the encoder launch + feature round trip mostly
+// launch latency (PXT_NGP_INLINE_FROM).
+template <int MODE, bool INLINE = false>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
+  __shared__ unsigned s_feat[INLINE ? 4 * 16 * 64 : 1];
+  const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
+  const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
 #if PXT_NGP_LDS_LEVELS > 0
   extern __shared__ unsigned s_tab[];  // the first dense levels, back to back
   {
@@ -916,6 +925,7 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
 #endif
   __syncthreads();
   const int n = Wk.counters[round * kCtrStride];
+  if (INLINE && P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)n * kK);
   const RayState& S = Wk.st[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
@@ -934,11 +944,13 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     const float rdir[3] = {rd.x, rd.y, rd.z};
     unsigned shB0[4], shB1[4];
     sh_fragments(rdir, shB0, shB1);
-    unsigned Flo[8], Fhi[8];
+    unsigned Flo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Fhi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (!INLINE) {
 #pragma unroll
-    for (int l = 0; l < 8; ++l) {
-      if (l >= PXT_NGP_LDS_LEVELS) Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
-      Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
+      for (int l = 0; l < 8; ++l) {
+        if (l >= PXT_NGP_LDS_LEVELS) Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
+        Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
+      }
     }
 #if PXT_NGP_LDS_LEVELS > 0
 #pragma unroll
@@ -950,7 +962,22 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
     // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
     // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
-    if (__any(valid)) ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+    if (__any(valid)) {
+      if (INLINE) {  // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
+        const float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
+        // a rolled loop over the levels (unrolled, all 128 gathers are hoisted: 256 VGPRs, one wave per SIMD); the
+        // features pass through the lane's own LDS column so that Flo / Fhi keep static register indices
+        unsigned* col = s_feat + wave * (16 * 64) + lane;
+#pragma unroll PXT_NGP_INLINE_GROUP
+        for (int l = 0; l < 16; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+          Flo[l] = valid ? col[l * 64] : 0u;
+          Fhi[l] = valid ? col[(l + 8) * 64] : 0u;
+        }
+      }
+      ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+    }
     // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
     const float T0 = S.T[sl];
     float alpha = 0.f;
@@ -1515,7 +1542,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   }
 #else
   const size_t shade_lds = 0;
-  const int shade_grid = wide;
+  static const int shade_grid = [] { const char* e = getenv("PXT_NGP_SHADE_GRID"); return e ? atoi(e) : 2048; }();
 #endif
   static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
   // (ray generation fused with the first march as well: measured, no gain - 0.952-0.956 vs 0.938-0.959 ms; the
@@ -1529,10 +1556,14 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
       hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
+  static const int inline_from = [] { const char* e = getenv("PXT_NGP_INLINE_FROM"); return e ? atoi(e) : 0; }();
   for (int r = 0; r < kRounds; ++r) {
+    const bool inl = r >= inline_from;  // the shade kernel encodes its own samples: no encoder launch
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
         hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+    // the round's gather kernel (the encoder, or the shade kernel that encodes its own samples) is the one the
+    // timing events bracket (bench.py's roofline)
     for (int w = 0; w < n_pipe; ++w) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) {
@@ -1546,13 +1577,21 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
         }
         PXT_HIP_CHECK(hipEventRecord(e0, st[w]));
       }
-      hipLaunchKernelGGL(ngp_encode_kernel, dim3(enc_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      if (!inl) {
+        hipLaunchKernelGGL(ngp_encode_kernel, dim3(enc_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      } else if (mode == 1) {
+        hipLaunchKernelGGL((ngp_shade_kernel<1, true>), dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
+      } else if (mode == 2) {
+        hipLaunchKernelGGL((ngp_shade_kernel<2, true>), dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
+      } else {
+        hipLaunchKernelGGL((ngp_shade_kernel<0, true>), dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
+      }
       if (timed) {
         PXT_HIP_CHECK(hipEventRecord(e1, st[w]));
         ctx->events.emplace_back(e0, e1);
       }
     }
-    for (int w = 0; w < n_pipe; ++w) {
+    for (int w = 0; w < n_pipe && !inl; ++w) {
       if (mode == 1)
         hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
       else if (mode == 2)
