@@ -6,6 +6,9 @@ i=0
 for set in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TCC_WRITE_REQ_sum TCC_TAG_STALL_sum" \
+           "TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+           "TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum" \
+           "SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \
            "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- "$@" > $out/p$i.log 2>&1
