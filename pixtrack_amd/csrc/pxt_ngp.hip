@@ -261,116 +261,6 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
   return pack_h2(f0, f1);
 }
 
-// G levels at once, their gathers in two phases: the x corners first, a wait, then the x + 1 corners.  The
-// x-neighbour of a corner sits in the same 128-B line almost always (dense: next entry; hashed: a few low index
-// bits differ), and the L1 stalls its in-order pipeline on a hit to a line whose fill is still pending
-// (TCP_PENDING_STALL_CYCLES: a third of the kernel's L1 time when the eight corners are issued back to back); after
-// the wait the second phase only meets lines that have arrived.  Same indices, same order of the sum: same bits.
-template <int G>
-__device__ inline void ngp_encode_levels_two_phase(const __amdgpu_buffer_rsrc_t grid, const NgpLevel* lv, float ux,
-                                                   float uy, float uz, unsigned* out) {
-  unsigned vals[G][8];
-  unsigned off[G][8];
-  float ax[G], ay[G], az[G];
-  int base[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const NgpLevel& Lv = lv[g];
-    const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
-    const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-    ax[g] = qx - fx; ay[g] = qy - fy; az[g] = qz - fz;
-    const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
-    base[g] = (int)(Lv.offset * 4u);
-    if (Lv.hashed) {
-      const unsigned mask = Lv.size - 1u;
-      const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
-      const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
-#pragma unroll
-      for (int c = 0; c < 8; ++c) off[g][c] = (((gx + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask) << 2;
-    } else {
-      const unsigned r2 = Lv.res * Lv.res;
-      const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
-      const unsigned rz[2] = {gz * r2, gz * r2 + r2};
-#pragma unroll
-      for (int c = 0; c < 8; ++c) off[g][c] = min((gx + (c & 1)) + ry[(c >> 1) & 1] + rz[(c >> 2) & 1], Lv.size - 1u) << 2;
-    }
-  }
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int c = 0; c < 8; c += 2) vals[g][c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)off[g][c], base[g], 0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int c = 1; c < 8; c += 2) vals[g][c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)off[g][c], base[g], 0);
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float w = 1.0f;
-      w = w * ((c & 1) ? ax[g] : (1.0f - ax[g]));
-      w = w * ((c & 2) ? ay[g] : (1.0f - ay[g]));
-      w = w * ((c & 4) ? az[g] : (1.0f - az[g]));
-      const half2_t hv = __builtin_bit_cast(half2_t, vals[g][c]);
-      f0 += w * (float)hv[0];
-      f1 += w * (float)hv[1];
-    }
-    out[g] = pack_h2(f0, f1);
-  }
-}
-
-// The same level evaluated by a PAIR of lanes (2p, 2p + 1) for one sample: lane `xbit` gathers the four corners
-// with x = gx + xbit, the pair swaps its values (DPP quad_perm) and both lanes form the 8-term sum in the
-// encoder's order - same bits.  The x-neighbours of a hashed level differ in a few low index bits, so the two
-// lanes of a pair nearly always address the same 64-B sector: half as many distinct sectors per gather instruction.
-__device__ inline unsigned ngp_encode_level_pair(const __amdgpu_buffer_rsrc_t grid, const NgpLevel& Lv, float ux,
-                                                 float uy, float uz, unsigned xbit) {
-  const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
-  const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-  const float ax = qx - fx, ay = qy - fy, az = qz - fz;
-  const unsigned gx = (unsigned)(int)fx + xbit, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
-  unsigned mine[4];
-  const int base = (int)(Lv.offset * 4u);
-  if (Lv.hashed) {
-    const unsigned mask = Lv.size - 1u;
-    const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
-    const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const unsigned idx = (gx ^ hy[c & 1] ^ hz[c >> 1]) & mask;
-      mine[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
-    }
-  } else {
-    const unsigned r2 = Lv.res * Lv.res;
-    const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
-    const unsigned rz[2] = {gz * r2, gz * r2 + r2};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const unsigned idx = min(gx + ry[c & 1] + rz[c >> 1], Lv.size - 1u);
-      mine[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
-    }
-  }
-  float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned m = mine[c >> 1];
-    const unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);  // the partner lane's value
-    const unsigned v = ((unsigned)(c & 1) == xbit) ? m : o;
-    float w = 1.0f;
-    w = w * ((c & 1) ? ax : (1.0f - ax));
-    w = w * ((c & 2) ? ay : (1.0f - ay));
-    w = w * ((c & 4) ? az : (1.0f - az));
-    const half2_t hv = __builtin_bit_cast(half2_t, v);
-    f0 += w * (float)hv[0];
-    f1 += w * (float)hv[1];
-  }
-  return pack_h2(f0, f1);
-}
-
 // The LDS variant north_star names: the first PXT_NGP_LDS_LEVELS dense levels are
 // copied into LDS by every shade workgroup and evaluated there, sample by sample, instead of being
 // gathered by the encoder and round-tripped through feat[].  Same indices, same arithmetic, same results.
@@ -1012,27 +902,20 @@ __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, b
   Wk.sppbuf[rid] = acc;
 }
 
-#ifndef PXT_NGP_PAIR_LANES
-#define PXT_NGP_PAIR_LANES 0
-#endif
-#ifndef PXT_NGP_TWO_PHASE
-#define PXT_NGP_TWO_PHASE 0
-#endif
-#ifndef PXT_NGP_INLINE_HALVES
-#define PXT_NGP_INLINE_HALVES 1
-#endif
-constexpr int kInlineLevels = (PXT_NGP_INLINE_HALVES && !PXT_NGP_PAIR_LANES) ? 8 : 16;
 #ifndef PXT_NGP_INLINE_GROUP
 #define PXT_NGP_INLINE_GROUP 4
 #endif
-// INLINE: the wave encodes its own 64 samples (all levels, same function as the encoder: same bits) instead of
-// reading feat[] - for the late rounds, whose few samples make the encoder launch + feature round trip mostly
-// launch latency (PXT_NGP_INLINE_FROM).
+// INLINE (the product path, rounds >= PXT_NGP_INLINE_FROM = 0): the wave gathers the hash-grid features of its own
+// 64 samples (all levels, same function as the level-major encoder: same bits) and feeds them to the MLPs - no
+// encoder launch, no feature round trip through HBM (16 x 4 B written and read back per sample), and the gathers of
+// one wave overlap the matrix work of the others.  Render 0.92 -> 0.715 ms.  The level loop stays rolled (unrolled,
+// all 128 gathers are hoisted: 256 VGPRs, one wave per SIMD) and runs in two halves of 8 levels through an 8-KB LDS
+// staging area, which keeps Flo / Fhi on static register indices at 4 waves per SIMD.
 template <int MODE, bool INLINE = false>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
-  __shared__ unsigned s_feat[INLINE ? 4 * kInlineLevels * 64 : 1];
+  __shared__ unsigned s_feat[INLINE ? 4 * 8 * 64 : 1];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
 #if PXT_NGP_LDS_LEVELS > 0
@@ -1085,68 +968,17 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     if (__any(valid)) {
       if (INLINE) {  // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
         const float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
-        // a rolled loop over the levels (unrolled, all 128 gathers are hoisted: 256 VGPRs, one wave per SIMD); the
-        // features pass through the lane's own LDS column so that Flo / Fhi keep static register indices
-        unsigned* col = s_feat + wave * (kInlineLevels * 64) + lane;
-#if PXT_NGP_PAIR_LANES
-        // two lanes per sample, 32 samples at a time (ngp_encode_level_pair); the even lane files the feature
-        // under its sample's column
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          const int src = 32 * h + (lane >> 1);
-          const float px = __shfl(ux, src, 64), py = __shfl(uy, src, 64), pz = __shfl(uz, src, 64);
-          unsigned* dst = s_feat + wave * (16 * 64) + src;
-#pragma unroll PXT_NGP_INLINE_GROUP
-          for (int l = 0; l < 16; ++l) {
-            const unsigned f = ngp_encode_level_pair(grid_rsrc, P.lv[l], px, py, pz, (unsigned)(lane & 1));
-            if (!(lane & 1)) dst[l * 64] = f;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-#else
-#if PXT_NGP_INLINE_HALVES  // 8 levels at a time through an 8-KB staging area (one more workgroup per CU)
-#if PXT_NGP_TWO_PHASE
-#pragma unroll 1
-        for (int l = 0; l < 8; l += PXT_NGP_INLINE_GROUP) {
-          unsigned f[PXT_NGP_INLINE_GROUP];
-          ngp_encode_levels_two_phase<PXT_NGP_INLINE_GROUP>(grid_rsrc, P.lv + l, ux, uy, uz, f);
-#pragma unroll
-          for (int g = 0; g < PXT_NGP_INLINE_GROUP; ++g) col[(l + g) * 64] = f[g];
-        }
-#else
+        // the features pass through the lane's own LDS column (see the kernel's header)
+        unsigned* col = s_feat + wave * (8 * 64) + lane;
 #pragma unroll PXT_NGP_INLINE_GROUP
         for (int l = 0; l < 8; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
-#endif
 #pragma unroll
         for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
-#if PXT_NGP_TWO_PHASE
-#pragma unroll 1
-        for (int l = 0; l < 8; l += PXT_NGP_INLINE_GROUP) {
-          unsigned f[PXT_NGP_INLINE_GROUP];
-          ngp_encode_levels_two_phase<PXT_NGP_INLINE_GROUP>(grid_rsrc, P.lv + 8 + l, ux, uy, uz, f);
-#pragma unroll
-          for (int g = 0; g < PXT_NGP_INLINE_GROUP; ++g) col[(l + g) * 64] = f[g];
-        }
-#else
 #pragma unroll PXT_NGP_INLINE_GROUP
         for (int l = 0; l < 8; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
-#endif
 #pragma unroll
         for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
       }
-#else
-#pragma unroll PXT_NGP_INLINE_GROUP
-        for (int l = 0; l < 16; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
-#endif
-#endif
-#if !PXT_NGP_INLINE_HALVES || PXT_NGP_PAIR_LANES
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-          Flo[l] = valid ? col[l * 64] : 0u;
-          Fhi[l] = valid ? col[(l + 8) * 64] : 0u;
-        }
-      }
-#endif
       ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
     }
     // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
