@@ -1412,6 +1412,13 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
 // the largest slice.  (The first version sized them for half the rays whatever the number of pipelines: a
 // one-pipeline render - any render below 2^19 rays - whose camera sees the box in more than half of its pixels
 // wrote past them.)
+// First round whose shade kernel gathers its own features (0: all of them, the product; kRounds: the level-major
+// encoder + feature planes of the first half of round 2, kept for A/B and tests/test_variants_gpu.py).
+static int ngp_inline_from() {
+  static const int v = [] { const char* e = getenv("PXT_NGP_INLINE_FROM"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
   size_t cap = (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile;
   if (ctx->scratch && ctx->scratch_rays >= rays && ctx->scratch_cap >= cap && ctx->scratch_pipes >= n_pipe) return PXT_OK;
@@ -1442,7 +1449,8 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
     }
     o[w].cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
     o[w].spos = take(samples * 16); o[w].stt = take(samples * 4);
-    o[w].feat = take(samples * 4 * kMaxLevels); o[w].exh = take(half); o[w].keep = take(half);
+    // feat[]: only the level-major encoder path (PXT_NGP_INLINE_FROM > 0) round-trips features through memory
+    o[w].feat = take(ngp_inline_from() > 0 ? samples * 4 * kMaxLevels : 256); o[w].exh = take(half); o[w].keep = take(half);
   }
   const size_t o_sppd = take(rays * 4), o_spp = take(rays * 16), o_rdir = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
@@ -1559,7 +1567,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
       hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
-  static const int inline_from = [] { const char* e = getenv("PXT_NGP_INLINE_FROM"); return e ? atoi(e) : 0; }();
+  const int inline_from = ngp_inline_from();
   for (int r = 0; r < kRounds; ++r) {
     const bool inl = r >= inline_from;  // the shade kernel encodes its own samples: no encoder launch
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
