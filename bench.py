@@ -460,7 +460,7 @@ def main():
     pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
     if pmc.exists():
         recs = json.loads(pmc.read_text())
-        rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void pxt::" + GATHER_KERNEL_PMC)
+        rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
         if rec:
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
             traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
