@@ -572,7 +572,7 @@ struct NgpWork {
   float* st_t;         // t of each sample (depth mode)
   unsigned* feat;      // [level][sample] packed fp16 pair
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
-  uint8_t* keep;       // per slot: the ray continues into the next round (written by shade)
+  uint8_t* keep[2];    // [round & 1] per slot: the ray continues into the next round (written by shade)
   float4* raydir;      // [pixel * spp + s] = (unit direction, d . camera z): what shading needs of a ray
   float4* sppbuf;      // [pixel][spp] finished rays
   float* sppbuf_d;     // mode 2: finished rays' depth
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, con
           if (k[j]) Wk.raydir[rid_new[j]] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
         }
       } else {
-        k[j] = i < n && Wk.keep[i] != 0;
+        k[j] = i < n && Wk.keep[round & 1][i] != 0;
       }
       cnt += k[j] ? 1 : 0;
     }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams 
         if (kept) Wk.raydir[rid] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
       }
     } else {
-      kept = i < n && Wk.keep[i] != 0;
+      kept = i < n && Wk.keep[round & 1][i] != 0;
       float4 rdir = make_float4(0.f, 0.f, 1.f, 0.f);
       if (kept) {
         rid = S.rid[i];
@@ -911,6 +911,120 @@ __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, b
 // one wave overlap the matrix work of the others.  Render 0.92 -> 0.715 ms.  The level loop stays rolled (unrolled,
 // all 128 gathers are hoisted: 256 VGPRs, one wave per SIMD) and runs in two halves of 8 levels through an 8-KB LDS
 // staging area, which keeps Flo / Fhi on static register indices at 4 waves per SIMD.
+// One group of 8 rays x 8 samples (this wave's 64 lanes): features (gathered here when INLINE, else read from
+// feat[]), both MLPs, in-order compositing, termination; lane (rlane, k) handles sample k of the ray in `slot`.
+// A ray's result does not depend on which rays share its group.
+template <int MODE, bool INLINE>
+__device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
+                                                const half8* s_w, unsigned* s_feat, const unsigned* s_tab,
+                                                const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
+                                                int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
+  const int sl = ray_ok ? slot : safe_slot;  // lanes beyond the list read a slot that is known to be filled
+  const size_t si = (size_t)sl * kK + k;
+  const float4 sp = Wk.spos[si];
+  const float dt = ray_ok ? sp.w : 0.f;
+  const bool valid = dt != 0.f;
+  const unsigned rid = S.rid[sl];
+  const float4 rd = Wk.raydir[rid];
+  const float rdir[3] = {rd.x, rd.y, rd.z};
+  unsigned shB0[4], shB1[4];
+  sh_fragments(rdir, shB0, shB1);
+  unsigned Flo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Fhi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (!INLINE) {
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      if (l >= PXT_NGP_LDS_LEVELS) Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
+      Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
+    }
+  }
+#if PXT_NGP_LDS_LEVELS > 0
+#pragma unroll
+  for (int l = 0; l < PXT_NGP_LDS_LEVELS; ++l)
+    Flo[l] = valid ? ngp_encode_level_lds(s_tab + P.lv[l].offset, P.lv[l], (sp.x - enc_lo) * enc_inv,
+                                          (sp.y - enc_lo) * enc_inv, (sp.z - enc_lo) * enc_inv)
+                   : 0u;
+#endif
+  float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
+  // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
+  // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
+  if (__any(valid)) {
+    if (INLINE) {  // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
+      const float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
+      // the features pass through the lane's own LDS column (see the kernel's header)
+      unsigned* col = s_feat + wave * (8 * 64) + lane;
+#pragma unroll PXT_NGP_INLINE_GROUP
+      for (int l = 0; l < 8; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
+#pragma unroll
+      for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
+#pragma unroll PXT_NGP_INLINE_GROUP
+      for (int l = 0; l < 8; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
+#pragma unroll
+      for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
+    }
+    ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+  }
+  // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
+  const float T0 = S.T[sl];
+  float alpha = 0.f;
+  if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
+  float depth = 0.f;
+  if (MODE != 0) depth = (Wk.st_t[si] * rd.w) * P.depth_scale;
+  if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
+  // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
+  float pinc = 1.0f - alpha;
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    const float o = __shfl_up(pinc, m, 8);
+    if (k >= m) pinc = pinc * o;
+  }
+  float pexc = __shfl_up(pinc, 1, 8);
+  if (k == 0) pexc = 1.0f;
+  const float T_before = T0 * pexc, T_after = T0 * pinc;
+  // the first sample after which T drops below the threshold ends the ray (it is included)
+  const bool ends = valid && (T_after < P.min_T);
+  const unsigned long long bal = __ballot(ends);
+  const unsigned grp = (unsigned)((bal >> (rlane * 8)) & 0xFFull);
+  const int k_term = grp ? (__ffs((int)grp) - 1) : 8;
+  const bool contributes = valid && k <= k_term;
+  const float wgt = contributes ? alpha * T_before : 0.f;
+  float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt, cd = wgt * depth;
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    cr += __shfl_xor(cr, m, 8);
+    cg += __shfl_xor(cg, m, 8);
+    cb += __shfl_xor(cb, m, 8);
+    ca += __shfl_xor(ca, m, 8);
+    if (MODE == 2) cd += __shfl_xor(cd, m, 8);
+  }
+  if (contributes) n_samples += 1;
+  // last valid sample's T_after (or the terminating one) is the ray's new transmittance
+  const unsigned long long vb = __ballot(valid);
+  const unsigned vgrp = (unsigned)((vb >> (rlane * 8)) & 0xFFull);
+  const int n_valid = __popc(vgrp);
+  const int k_last = grp ? k_term : n_valid - 1;
+  const float T_new = (k_last >= 0) ? __shfl(T_after, rlane * 8 + max(k_last, 0), 64) : T0;
+  if (k == 0 && ray_ok) {
+    float4 acc = S.acc[slot];
+    acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
+    float accd = 0.f;
+    if (MODE == 2) accd = S.accd[slot] + cd;
+    const bool terminated = grp != 0;
+    const bool exhausted = Wk.exhausted[slot] != 0;
+    if (terminated || exhausted) {
+      if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
+      finish_ray(Wk, rid, acc, terminated);
+      keep_out[slot] = 0;
+    } else {  // the compaction kernel moves the survivors into the next round's list
+      S.T[slot] = T_new;
+      S.acc[slot] = acc;
+      if (MODE == 2) S.accd[slot] = accd;
+      keep_out[slot] = 1;
+    }
+  }
+}
+
 template <int MODE, bool INLINE = false>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
@@ -924,121 +1038,23 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     const unsigned n_tab = P.lv[PXT_NGP_LDS_LEVELS - 1].offset + P.lv[PXT_NGP_LDS_LEVELS - 1].size;
     for (unsigned i = threadIdx.x; i < n_tab; i += 256) s_tab[i] = P.grid[i];
   }
-  const float half_s_ = P.aabb_scale * 0.5f, scene_lo_ = 0.5f - half_s_, inv_s_ = 1.0f / P.aabb_scale;
 #endif
   __syncthreads();
   const int n = Wk.counters[round * kCtrStride];
   if (INLINE && P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)n * kK);
   const RayState& S = Wk.st[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
+  const int rlane = lane >> 3;
   unsigned long long n_samples = 0;
   const int n_groups = (n + 7) / 8;
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
     const int slot = g * 8 + rlane;
-    const bool ray_ok = slot < n;
-    const int sl = ray_ok ? slot : 0;
-    const size_t si = (size_t)sl * kK + k;
-    const float4 sp = Wk.spos[si];
-    const float dt = ray_ok ? sp.w : 0.f;
-    const bool valid = dt != 0.f;
-    const unsigned rid = S.rid[sl];
-    const float4 rd = Wk.raydir[rid];
-    const float rdir[3] = {rd.x, rd.y, rd.z};
-    unsigned shB0[4], shB1[4];
-    sh_fragments(rdir, shB0, shB1);
-    unsigned Flo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Fhi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    if (!INLINE) {
-#pragma unroll
-      for (int l = 0; l < 8; ++l) {
-        if (l >= PXT_NGP_LDS_LEVELS) Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
-        Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
-      }
-    }
 #if PXT_NGP_LDS_LEVELS > 0
-#pragma unroll
-    for (int l = 0; l < PXT_NGP_LDS_LEVELS; ++l)
-      Flo[l] = valid ? ngp_encode_level_lds(s_tab + P.lv[l].offset, P.lv[l], (sp.x - scene_lo_) * inv_s_,
-                                            (sp.y - scene_lo_) * inv_s_, (sp.z - scene_lo_) * inv_s_)
-                     : 0u;
+    const unsigned* tab = s_tab;
+#else
+    const unsigned* tab = nullptr;
 #endif
-    float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
-    // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
-    // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
-    if (__any(valid)) {
-      if (INLINE) {  // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
-        const float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
-        // the features pass through the lane's own LDS column (see the kernel's header)
-        unsigned* col = s_feat + wave * (8 * 64) + lane;
-#pragma unroll PXT_NGP_INLINE_GROUP
-        for (int l = 0; l < 8; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
-#pragma unroll PXT_NGP_INLINE_GROUP
-        for (int l = 0; l < 8; ++l) col[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
-      }
-      ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
-    }
-    // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
-    const float T0 = S.T[sl];
-    float alpha = 0.f;
-    if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
-    float depth = 0.f;
-    if (MODE != 0) depth = (Wk.st_t[si] * rd.w) * P.depth_scale;
-    if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
-    // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
-    float pinc = 1.0f - alpha;
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-      const float o = __shfl_up(pinc, m, 8);
-      if (k >= m) pinc = pinc * o;
-    }
-    float pexc = __shfl_up(pinc, 1, 8);
-    if (k == 0) pexc = 1.0f;
-    const float T_before = T0 * pexc, T_after = T0 * pinc;
-    // the first sample after which T drops below the threshold ends the ray (it is included)
-    const bool ends = valid && (T_after < P.min_T);
-    const unsigned long long bal = __ballot(ends);
-    const unsigned grp = (unsigned)((bal >> (rlane * 8)) & 0xFFull);
-    const int k_term = grp ? (__ffs((int)grp) - 1) : 8;
-    const bool contributes = valid && k <= k_term;
-    const float wgt = contributes ? alpha * T_before : 0.f;
-    float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt, cd = wgt * depth;
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-      cr += __shfl_xor(cr, m, 8);
-      cg += __shfl_xor(cg, m, 8);
-      cb += __shfl_xor(cb, m, 8);
-      ca += __shfl_xor(ca, m, 8);
-      if (MODE == 2) cd += __shfl_xor(cd, m, 8);
-    }
-    if (contributes) n_samples += 1;
-    // last valid sample's T_after (or the terminating one) is the ray's new transmittance
-    const unsigned long long vb = __ballot(valid);
-    const unsigned vgrp = (unsigned)((vb >> (rlane * 8)) & 0xFFull);
-    const int n_valid = __popc(vgrp);
-    const int k_last = grp ? k_term : n_valid - 1;
-    const float T_new = (k_last >= 0) ? __shfl(T_after, rlane * 8 + max(k_last, 0), 64) : T0;
-    if (k == 0 && ray_ok) {
-      float4 acc = S.acc[slot];
-      acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
-      float accd = 0.f;
-      if (MODE == 2) accd = S.accd[slot] + cd;
-      const bool terminated = grp != 0;
-      const bool exhausted = Wk.exhausted[slot] != 0;
-      if (terminated || exhausted) {
-        if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
-        finish_ray(Wk, rid, acc, terminated);
-        Wk.keep[slot] = 0;
-      } else {  // the compaction kernel moves the survivors into the next round's list
-        S.T[slot] = T_new;
-        S.acc[slot] = acc;
-        if (MODE == 2) S.accd[slot] = accd;
-        Wk.keep[slot] = 1;
-      }
-    }
+    ngp_shade_group<MODE, INLINE>(P, Wk, S, Wk.keep[round & 1], s_w, s_feat, tab, grid_rsrc, enc_lo, enc_inv, slot, slot < n, 0, n_samples);
   }
   if (P.stats) {  // one atomic per workgroup: a single counter word sustains ~90 atomics/us
     __shared__ unsigned long long s_cnt[4];
@@ -1048,6 +1064,134 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
     const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     if (threadIdx.x == 0 && tot) atomicAdd(P.stats + 0, tot);
   }
+}
+
+#ifndef PXT_ROUND_WAVES
+#define PXT_ROUND_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+// One launch per round (PXT_NGP_FUSE_ROUND, the product path): a workgroup takes a tile of 256 slots of the previous
+// round (FROM_INIT: 256 enumerated rays), compacts its survivors into the round's list (ballot + prefix, one atomic
+// per tile, as ngp_compact_march_kernel), every thread marches its own ray into the ray's new slot, and after a
+// barrier the four waves shade the tile's rays, eight at a time (ngp_shade_group, gathers inline).  The march of
+// one workgroup - a latency chain - runs beside the gathers of the others on its CU, and a round is one launch
+// instead of two.  `round` is the round being marched and shaded; the survivors' flags go to keep[round & 1]
+// while other tiles still read keep[(round - 1) & 1].
+template <int MODE, bool FROM_INIT>
+__device__ __forceinline__ void ngp_round_body(const NgpParams& P, const NgpWork& Wk, int round) {
+  __shared__ half8 s_w[kNumFrags * 64];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
+  __shared__ unsigned s_feat[4 * 8 * 64];
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
+  const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
+  const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[(round - 1) * kCtrStride];
+  const RayState& S = Wk.st[(round - 1) & 1];  // (unused when FROM_INIT)
+  const RayState& D = Wk.st[round & 1];
+  int* out_count = Wk.counters + round * kCtrStride;
+  const uint8_t* keep_in = Wk.keep[(round - 1) & 1];
+  uint8_t* keep_out = Wk.keep[round & 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rlane = lane >> 3;
+  unsigned long long n_samples = 0;
+  const long long tiles = (n + 255) / 256;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long i = tile * 256 + threadIdx.x;
+    bool kept;
+    unsigned rid = 0;
+    float t = 0.f, T_ = 1.f, accd_ = 0.f;
+    float4 acc_ = make_float4(0.f, 0.f, 0.f, 0.f);
+    Ray r;
+    if (FROM_INIT) {
+      int px, py, sp;
+      kept = false;
+      if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
+        const int pix = py * P.W + px;
+        r = make_ray(P, px, py);
+        t = ray_start(P, r, pix, sp);
+        rid = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
+        kept = t >= 0.f;
+        if (kept) Wk.raydir[rid] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
+      }
+    } else {
+      kept = i < n && keep_in[i] != 0;
+      float4 rdir = make_float4(0.f, 0.f, 1.f, 0.f);
+      if (kept) {
+        rid = S.rid[i];
+        t = S.t[i];
+        T_ = S.T[i];
+        acc_ = S.acc[i];
+        accd_ = S.accd[i];
+        rdir = Wk.raydir[rid];
+      }
+      r = ray_from_record(P, rdir);
+    }
+    const unsigned long long m = __ballot(kept);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    int wave_off = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) wave_off += s_wave[w];
+      tile_total += s_wave[w];
+    }
+    if (threadIdx.x == 0) {
+      s_base = tile_total ? atomicAdd(out_count, tile_total) : 0;
+      if (P.stats && tile_total) atomicAdd(P.stats + 3, (unsigned long long)tile_total * kK);
+    }
+    __syncthreads();
+    const int base = s_base;
+    if (kept) {
+      const int slot = base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
+      D.rid[slot] = rid;
+      D.T[slot] = T_;
+      D.acc[slot] = acc_;
+      D.accd[slot] = accd_;
+      const size_t s0 = (size_t)slot * kK;
+      int k = 0;
+      bool out = false;
+      while (k < kK) {
+        if (t >= r.tmax) { out = true; break; }
+        float pos[3], dt;
+        int mip;
+        if (probe_cell(P, r, t, pos, dt, mip)) {
+          Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
+          Wk.st_t[s0 + k] = t;
+          t = t + dt;
+          ++k;
+        } else {
+          advance_past_cell(P, r, t, pos, mip);
+        }
+      }
+      for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      D.t[slot] = t;
+      Wk.exhausted[slot] = out ? 1 : 0;
+    }
+    __syncthreads();  // the tile's rays, states and sample positions are in memory (workgroup scope): shade them
+    for (int g = wave; g * 8 < tile_total; g += 4) {
+      const int j = g * 8 + rlane;
+      ngp_shade_group<MODE, true>(P, Wk, D, keep_out, s_w, s_feat, nullptr, grid_rsrc, enc_lo, enc_inv, base + j,
+                                  j < tile_total, base, n_samples);
+    }
+  }
+  if (P.stats) {
+    __shared__ unsigned long long s_cnt[4];
+    for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
+    if (lane == 0) s_cnt[wave] = n_samples;
+    __syncthreads();
+    const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x == 0 && tot) atomicAdd(P.stats + 0, tot);
+  }
+}
+
+// (128 VGPRs = 4 waves per SIMD for the rounds after the first; ray generation on top of that would spill)
+template <int MODE>
+__global__ __launch_bounds__(256) PXT_ROUND_WAVES void ngp_round_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  ngp_round_body<MODE, false>(P, Wk, round);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ngp_round0_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  ngp_round_body<MODE, true>(P, Wk, round);
 }
 
 // Stragglers: wave = 64 live rays (lane = ray), fused march + encode + MLP per step until done.
@@ -1450,7 +1594,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
     o[w].cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
     o[w].spos = take(samples * 16); o[w].stt = take(samples * 4);
     // feat[]: only the level-major encoder path (PXT_NGP_INLINE_FROM > 0) round-trips features through memory
-    o[w].feat = take(ngp_inline_from() > 0 ? samples * 4 * kMaxLevels : 256); o[w].exh = take(half); o[w].keep = take(half);
+    o[w].feat = take(ngp_inline_from() > 0 ? samples * 4 * kMaxLevels : 256); o[w].exh = take(half); o[w].keep = take(2 * al(half));
   }
   const size_t o_sppd = take(rays * 4), o_spp = take(rays * 16), o_rdir = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
@@ -1468,7 +1612,8 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
     W.st_t = (float*)(b + o[w].stt);
     W.feat = (unsigned*)(b + o[w].feat);
     W.exhausted = (uint8_t*)(b + o[w].exh);
-    W.keep = (uint8_t*)(b + o[w].keep);
+    W.keep[0] = (uint8_t*)(b + o[w].keep);
+    W.keep[1] = W.keep[0] + al(half);
     W.sppbuf = (float4*)(b + o_spp);
     W.sppbuf_d = (float*)(b + o_sppd);
     W.raydir = (float4*)(b + o_rdir);
@@ -1559,8 +1704,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
   // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)
   static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : true; }();
+  static const bool fuse_round0 = [] { const char* e = getenv("PXT_NGP_FUSE_ROUND"); return e ? atoi(e) != 0 : false; }();
+  static const int round_grid = [] { const char* e = getenv("PXT_NGP_ROUND_GRID"); return e ? atoi(e) : 2048; }();
   for (int w = 0; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
+    if (fuse_round0) continue;  // ray generation is inside round 0's kernel
     if (fuse_init)  // ray generation + compaction + the first march
       hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
     else
@@ -1568,7 +1716,41 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
   const int inline_from = ngp_inline_from();
-  for (int r = 0; r < kRounds; ++r) {
+  static const bool fuse_round = [] { const char* e = getenv("PXT_NGP_FUSE_ROUND"); return e ? atoi(e) != 0 : false; }();
+  for (int r = 0; r < kRounds && fuse_round; ++r) {  // one launch per round: compaction + march + gathers + MLPs
+    for (int w = 0; w < n_pipe; ++w) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timed) {
+        if (ctx->pool.empty()) {
+          PXT_HIP_CHECK(hipEventCreate(&e0));
+          PXT_HIP_CHECK(hipEventCreate(&e1));
+        } else {
+          e0 = ctx->pool.back().first;
+          e1 = ctx->pool.back().second;
+          ctx->pool.pop_back();
+        }
+        PXT_HIP_CHECK(hipEventRecord(e0, st[w]));
+      }
+      const dim3 g(round_grid);
+      if (r == 0) {
+        if (mode == 1) hipLaunchKernelGGL(ngp_round0_kernel<1>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        else if (mode == 2) hipLaunchKernelGGL(ngp_round0_kernel<2>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        else hipLaunchKernelGGL(ngp_round0_kernel<0>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      } else {
+        if (mode == 1) hipLaunchKernelGGL(ngp_round_kernel<1>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        else if (mode == 2) hipLaunchKernelGGL(ngp_round_kernel<2>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        else hipLaunchKernelGGL(ngp_round_kernel<0>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+      }
+      if (timed) {
+        PXT_HIP_CHECK(hipEventRecord(e1, st[w]));
+        ctx->events.emplace_back(e0, e1);
+      }
+    }
+    if (r + 1 == kRounds)
+      for (int w = 0; w < n_pipe; ++w)
+        hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+  }
+  for (int r = 0; r < kRounds && !fuse_round; ++r) {
     const bool inl = r >= inline_from;  // the shade kernel encodes its own samples: no encoder launch
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
