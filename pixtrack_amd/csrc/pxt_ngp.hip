@@ -1066,134 +1066,6 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   }
 }
 
-#ifndef PXT_ROUND_WAVES
-#define PXT_ROUND_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
-// One launch per round (PXT_NGP_FUSE_ROUND, the product path): a workgroup takes a tile of 256 slots of the previous
-// round (FROM_INIT: 256 enumerated rays), compacts its survivors into the round's list (ballot + prefix, one atomic
-// per tile, as ngp_compact_march_kernel), every thread marches its own ray into the ray's new slot, and after a
-// barrier the four waves shade the tile's rays, eight at a time (ngp_shade_group, gathers inline).  The march of
-// one workgroup - a latency chain - runs beside the gathers of the others on its CU, and a round is one launch
-// instead of two.  `round` is the round being marched and shaded; the survivors' flags go to keep[round & 1]
-// while other tiles still read keep[(round - 1) & 1].
-template <int MODE, bool FROM_INIT>
-__device__ __forceinline__ void ngp_round_body(const NgpParams& P, const NgpWork& Wk, int round) {
-  __shared__ half8 s_w[kNumFrags * 64];
-  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
-  __shared__ unsigned s_feat[4 * 8 * 64];
-  __shared__ int s_wave[4];
-  __shared__ int s_base;
-  const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
-  const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
-  const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[(round - 1) * kCtrStride];
-  const RayState& S = Wk.st[(round - 1) & 1];  // (unused when FROM_INIT)
-  const RayState& D = Wk.st[round & 1];
-  int* out_count = Wk.counters + round * kCtrStride;
-  const uint8_t* keep_in = Wk.keep[(round - 1) & 1];
-  uint8_t* keep_out = Wk.keep[round & 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rlane = lane >> 3;
-  unsigned long long n_samples = 0;
-  const long long tiles = (n + 255) / 256;
-  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const long long i = tile * 256 + threadIdx.x;
-    bool kept;
-    unsigned rid = 0;
-    float t = 0.f, T_ = 1.f, accd_ = 0.f;
-    float4 acc_ = make_float4(0.f, 0.f, 0.f, 0.f);
-    Ray r;
-    if (FROM_INIT) {
-      int px, py, sp;
-      kept = false;
-      if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
-        const int pix = py * P.W + px;
-        r = make_ray(P, px, py);
-        t = ray_start(P, r, pix, sp);
-        rid = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
-        kept = t >= 0.f;
-        if (kept) Wk.raydir[rid] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
-      }
-    } else {
-      kept = i < n && keep_in[i] != 0;
-      float4 rdir = make_float4(0.f, 0.f, 1.f, 0.f);
-      if (kept) {
-        rid = S.rid[i];
-        t = S.t[i];
-        T_ = S.T[i];
-        acc_ = S.acc[i];
-        accd_ = S.accd[i];
-        rdir = Wk.raydir[rid];
-      }
-      r = ray_from_record(P, rdir);
-    }
-    const unsigned long long m = __ballot(kept);
-    if (lane == 0) s_wave[wave] = __popcll(m);
-    __syncthreads();
-    int wave_off = 0, tile_total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) wave_off += s_wave[w];
-      tile_total += s_wave[w];
-    }
-    if (threadIdx.x == 0) {
-      s_base = tile_total ? atomicAdd(out_count, tile_total) : 0;
-      if (P.stats && tile_total) atomicAdd(P.stats + 3, (unsigned long long)tile_total * kK);
-    }
-    __syncthreads();
-    const int base = s_base;
-    if (kept) {
-      const int slot = base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
-      D.rid[slot] = rid;
-      D.T[slot] = T_;
-      D.acc[slot] = acc_;
-      D.accd[slot] = accd_;
-      const size_t s0 = (size_t)slot * kK;
-      int k = 0;
-      bool out = false;
-      while (k < kK) {
-        if (t >= r.tmax) { out = true; break; }
-        float pos[3], dt;
-        int mip;
-        if (probe_cell(P, r, t, pos, dt, mip)) {
-          Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
-          Wk.st_t[s0 + k] = t;
-          t = t + dt;
-          ++k;
-        } else {
-          advance_past_cell(P, r, t, pos, mip);
-        }
-      }
-      for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      D.t[slot] = t;
-      Wk.exhausted[slot] = out ? 1 : 0;
-    }
-    __syncthreads();  // the tile's rays, states and sample positions are in memory (workgroup scope): shade them
-    for (int g = wave; g * 8 < tile_total; g += 4) {
-      const int j = g * 8 + rlane;
-      ngp_shade_group<MODE, true>(P, Wk, D, keep_out, s_w, s_feat, nullptr, grid_rsrc, enc_lo, enc_inv, base + j,
-                                  j < tile_total, base, n_samples);
-    }
-  }
-  if (P.stats) {
-    __shared__ unsigned long long s_cnt[4];
-    for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
-    if (lane == 0) s_cnt[wave] = n_samples;
-    __syncthreads();
-    const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (threadIdx.x == 0 && tot) atomicAdd(P.stats + 0, tot);
-  }
-}
-
-// (128 VGPRs = 4 waves per SIMD for the rounds after the first; ray generation on top of that would spill)
-template <int MODE>
-__global__ __launch_bounds__(256) PXT_ROUND_WAVES void ngp_round_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  ngp_round_body<MODE, false>(P, Wk, round);
-}
-template <int MODE>
-__global__ __launch_bounds__(256) void ngp_round0_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  ngp_round_body<MODE, true>(P, Wk, round);
-}
-
 // Stragglers: wave = 64 live rays (lane = ray), fused march + encode + MLP per step until done.
 template <int MODE>
 __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round) {
@@ -1704,11 +1576,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
   // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)
   static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : true; }();
-  static const bool fuse_round0 = [] { const char* e = getenv("PXT_NGP_FUSE_ROUND"); return e ? atoi(e) != 0 : false; }();
-  static const int round_grid = [] { const char* e = getenv("PXT_NGP_ROUND_GRID"); return e ? atoi(e) : 2048; }();
   for (int w = 0; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
-    if (fuse_round0) continue;  // ray generation is inside round 0's kernel
     if (fuse_init)  // ray generation + compaction + the first march
       hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
     else
@@ -1716,41 +1585,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
   const int inline_from = ngp_inline_from();
-  static const bool fuse_round = [] { const char* e = getenv("PXT_NGP_FUSE_ROUND"); return e ? atoi(e) != 0 : false; }();
-  for (int r = 0; r < kRounds && fuse_round; ++r) {  // one launch per round: compaction + march + gathers + MLPs
-    for (int w = 0; w < n_pipe; ++w) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timed) {
-        if (ctx->pool.empty()) {
-          PXT_HIP_CHECK(hipEventCreate(&e0));
-          PXT_HIP_CHECK(hipEventCreate(&e1));
-        } else {
-          e0 = ctx->pool.back().first;
-          e1 = ctx->pool.back().second;
-          ctx->pool.pop_back();
-        }
-        PXT_HIP_CHECK(hipEventRecord(e0, st[w]));
-      }
-      const dim3 g(round_grid);
-      if (r == 0) {
-        if (mode == 1) hipLaunchKernelGGL(ngp_round0_kernel<1>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-        else if (mode == 2) hipLaunchKernelGGL(ngp_round0_kernel<2>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-        else hipLaunchKernelGGL(ngp_round0_kernel<0>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-      } else {
-        if (mode == 1) hipLaunchKernelGGL(ngp_round_kernel<1>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-        else if (mode == 2) hipLaunchKernelGGL(ngp_round_kernel<2>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-        else hipLaunchKernelGGL(ngp_round_kernel<0>, g, dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-      }
-      if (timed) {
-        PXT_HIP_CHECK(hipEventRecord(e1, st[w]));
-        ctx->events.emplace_back(e0, e1);
-      }
-    }
-    if (r + 1 == kRounds)
-      for (int w = 0; w < n_pipe; ++w)
-        hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-  }
-  for (int r = 0; r < kRounds && !fuse_round; ++r) {
+  for (int r = 0; r < kRounds; ++r) {
     const bool inl = r >= inline_from;  // the shade kernel encodes its own samples: no encoder launch
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
