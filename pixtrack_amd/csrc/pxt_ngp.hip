@@ -593,6 +593,13 @@ __device__ inline void sh_fragments(const float* d, unsigned* shB0, unsigned* sh
 // Ray id = pixel * spp + sample.  Rays are enumerated sample-fastest over 4x2 pixel blocks,
 // so one wave holds the 8 spp passes of 8 neighbouring pixels: at the coarse and middle
 // hash levels those 64 samples share grid cells and their gathers coalesce in the L1.
+// The start jitter of (pixel, pass) as a fraction of a step.
+__device__ inline float ray_jitter(int pix, int s) {
+  unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
 __device__ inline bool enum_ray(const NgpParams& P, long long i, int& px, int& py, int& s) {
   const int bx = (P.W + 3) / 4;
   s = (int)(i % P.spp);
@@ -600,7 +607,8 @@ __device__ inline bool enum_ray(const NgpParams& P, long long i, int& px, int& p
   const int blk = (int)(q / 8), within = (int)(q % 8);
   px = (blk % bx) * 4 + (within & 3);
   py = (blk / bx) * 2 + (within >> 2);
-  return px < P.W && py < P.H;
+  if (!(px < P.W && py < P.H)) return false;
+  return true;
 }
 
 __device__ inline long long enum_total(const NgpParams& P) {
@@ -612,10 +620,7 @@ __device__ inline long long enum_total(const NgpParams& P) {
 __device__ inline float ray_start(const NgpParams& P, const Ray& r, int pix, int s) {
   if (!r.hit) return -1.f;
   const float t = fmaxf(r.tmin, 0.f) + 1e-6f;
-  unsigned h = (unsigned)pix * 747796405u + (unsigned)s * 2891336453u + 1u;
-  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-  const float uj = (float)(h >> 8) * (1.0f / 16777216.0f);
-  return t + uj * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
+  return t + ray_jitter(pix, s) * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
 }
 
 // Order-preserving compaction of 2048-item tiles: ONE global atomic per tile (a single
