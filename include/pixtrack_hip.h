@@ -259,8 +259,9 @@ int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* view_host, c
  * n = 1 serialises the render on the caller's stream (isolated per-kernel timing); n <= 4. */
 int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n);
 
-/* Live HIP-event timing of the renderer's dominant kernel (ngp_encode_kernel), for the
- * roofline line of bench.py.  every_nth > 0: the encode launches of every every_nth-th render
+/* Live HIP-event timing of the renderer's dominant kernel (the round's gather kernel: ngp_shade_kernel<MODE, true>,
+ * or ngp_encode_kernel under PXT_NGP_INLINE_FROM=5), for the
+ * roofline line of bench.py.  every_nth > 0: those launches of every every_nth-th render
  * are bracketed by an event pair recorded on the render's own stream (an event record is a
  * marker packet between kernels, so sampling keeps the measurement from slowing what it
  * measures); 0 disables.  pxt_ngp_timing_read synchronises those events, returns their summed

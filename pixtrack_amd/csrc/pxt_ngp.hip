@@ -397,22 +397,25 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // ===========================================================================
 // Wavefront renderer.
 //
-// The hash table (26 MB) does not fit one XCD's 4 MB L2, so a kernel in which every wave
-// walks all 16 levels for its own samples re-fetches table lines from the Infinity Cache at
-// ~3 KB of 64/128-B lines per 512 algorithmic bytes (measured: 7 ms per 640x480x8 render, the
-// gathers 6 of them).  Here a render is a short chain of kernels over a COMPACT list of live
-// rays, and the encoder runs LEVEL-MAJOR: blocks are dispatched in level order, so at any
-// moment the whole chip gathers from one ~2 MB level, which every XCD's L2 holds.
+// A render is a short chain of kernels over a COMPACT list of live rays (wavefront style):
 //
-//   init     : (inside the first compaction) ray per (pixel, spp); rays that hit the render box
-//              enter the live list
-//   round r  : march   -- each live ray collects its next K occupied lattice samples
-//              encode  -- level-major gathers -> feat[level][sample] (fp16 x2)
-//              shade   -- 8 rays x K=8 samples per wave: MLPs on MFMA, in-order compositing,
-//                         early-out; surviving rays are re-compacted for round r+1
+//   round 0  : ray generation (ray per (pixel, spp), box test, start jitter) + tile compaction + first march in
+//              one launch (ngp_compact_march_kernel<true>)
+//   round r  : march   -- each live ray collects its next K occupied lattice samples (fused with the compaction of
+//                         the previous round's survivors: ngp_compact_march_kernel<false>)
+//              shade   -- ngp_shade_kernel<MODE, true>: 8 rays x K=8 samples per wave; the wave gathers the hash-grid
+//                         features of its own 64 samples (16 levels x 8 corners), runs both MLPs on MFMA, composites
+//                         in order, terminates rays early
 //   tail     : after kRounds rounds the few remaining rays (grazing the soft shell) finish in
 //              a fused per-ray loop (march + encode + MLP per step)
 //   resolve  : fixed-order mean over spp + background
+//
+// History (profiles/r02_ngp_experiments.md): round 1 gathered in a separate LEVEL-MAJOR kernel
+// (ngp_encode_kernel: blocks dispatched in level order, one ~2 MB level hot in every XCD's L2 at a time, features
+// round-tripped through feat[level][sample]) because its first all-levels-per-wave kernel, at one wave per SIMD and
+// without the ray order below, re-fetched ~3 KB of lines per 512 algorithmic bytes (7 ms per render).  With
+// sample-fastest ray order, four waves per SIMD and the lanes transposed for the gathers, the all-levels-per-wave
+// kernel is the faster one again (0.92 -> 0.68 ms per render); PXT_NGP_INLINE_FROM=5 keeps the level-major path.
 //
 // Every ray performs exactly the arithmetic of oracle/ngp_oracle.py on exactly the same
 // samples; samples a round evaluates past a ray's termination point are discarded.
