@@ -8,10 +8,11 @@
 // -ffp-contract=off so no multiply-add of the march is fused differently from numpy).
 //
 // Mapping to the machine
-//  * One wavefront owns an 8x8 pixel tile; lane = ray.  All `spp` passes of the tile
-//    run in that wave, so the spp average needs no atomics and is order-deterministic.
-//  * Per march step each lane finds ITS next occupied sample (bitfield DDA, divergent),
-//    then the wave evaluates the 64 samples together:
+//  * Rays are enumerated pass-fastest (ray id = pixel * spp + pass): the 8 passes of a pixel are neighbours in the
+//    live list, and the per-pass results land in a [pixel][spp] buffer that `resolve` averages in a fixed order (no
+//    atomics on the image, order-deterministic).
+//  * A march thread finds ITS ray's next K occupied samples (bitfield DDA, divergent); a shade wave then evaluates
+//    8 rays x 8 samples together:
 //      - hash grid: 16 levels x 8 corners of 4-byte (2 x fp16) gathers per lane;
 //      - both MLPs on v_mfma_f32_32x32x16_f16 with samples as the N (column) axis.
 //        Hidden activations never leave registers: the D fragment of one layer,
