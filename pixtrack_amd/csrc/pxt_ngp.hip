@@ -1211,7 +1211,13 @@ __global__ void ngp_pose_to_camera_kernel(const float* __restrict__ pose12, cons
   if (cam_out) __hip_atomic_store(&cam_out[12], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk) {
+// The last kernel of a render also zeroes the round counters of every pipeline for the NEXT render (everything that
+// reads them has finished by now): no memset launch in front of a render's first kernel.
+struct NgpCounterList { int* p[4]; int n; };
+__global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk, const NgpCounterList zl) {
+  if (blockIdx.x == 0)
+    for (int w = 0; w < zl.n; ++w)
+      for (int i = threadIdx.x; i < (kRounds + 2) * kCtrStride; i += 256) zl.p[w][i] = 0;
   // One lane per pixel: it reads the pixel's spp finished rays (contiguous: 16 B x spp, whole lines per lane)
   // and adds them in pass order - the fixed order of a sequential mean.  All passes of a pixel share one ray
   // (snap_to_pixel_centers), so a pixel whose ray misses the box has no finished rays to read: nothing
@@ -1310,6 +1316,7 @@ struct pxt_ngp {
   size_t scratch_rays = 0;
   size_t scratch_cap = 0;   // rays one pipeline's buffers hold
   int scratch_pipes = 0;    // pipelines the scratch was laid out for
+  bool counters_clean = false;  // the previous render's resolve kernel zeroed every pipeline's round counters
   static constexpr int kMaxPipes = 4;
   pxt::NgpWork work[kMaxPipes];            // independent pipelines over equal slices of the rays
   hipStream_t side[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};  // streams of pipelines 1..
@@ -1520,6 +1527,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
   ctx->scratch_rays = rays;
   ctx->scratch_cap = cap;
   ctx->scratch_pipes = n_pipe;
+  ctx->counters_clean = false;
   return PXT_OK;
 }
 
@@ -1602,8 +1610,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
   // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)
   static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : true; }();
+  const bool counters_clean = ctx->counters_clean;
+  ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
   for (int w = 0; w < n_pipe; ++w) {
-    PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
+    if (!counters_clean)
+      PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
     if (fuse_init)  // ray generation + compaction + the first march
       hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
     else
@@ -1672,8 +1683,12 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));
     PXT_HIP_CHECK(hipStreamWaitEvent(s0, ctx->ev_join[w], 0));
   }
-  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s0, P, ctx->work[0]);
+  NgpCounterList zl;
+  zl.n = std::min(ctx->scratch_pipes, 4);
+  for (int w = 0; w < 4; ++w) zl.p[w] = w < zl.n ? ctx->work[w].counters : nullptr;
+  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s0, P, ctx->work[0], zl);
   PXT_HIP_CHECK(hipGetLastError());
+  ctx->counters_clean = true;
   return PXT_OK;
 }
 
