@@ -160,3 +160,29 @@ def test_render_both_equals_two_renders(device, snap):
     c, d = tb.render_both_device(W, H, spp)
     assert torch.equal(a, c) and torch.equal(b, d)
     assert float(b[..., 0].max()) > 0
+
+
+def test_render_sequence_with_scratch_growth_and_pipeline_changes(device, snap):
+    """A render's last kernel zeroes the round counters for the next one (no memset in front of a render); a
+    (re)allocated scratch or another pipeline count must not see stale counters: the same view renders to the
+    same bits before and after renders of other sizes and pipeline counts."""
+    tb = make_testbed(snap, device)
+    tb._cam_ngp = ngp_camera((0.9, 0.5, 0.3), 1.69)
+    tb.fov = 45.0
+    big = (640, 480, 8)     # 2.4 M rays: two pipelines by default
+    ref_rgba, ref_depth = (t.clone() for t in tb.render_both_device(*big))
+    small = tuple(t.clone() for t in tb.render_both_device(72, 50, 3))
+    for _ in range(2):
+        a, b = tb.render_both_device(*big)
+        assert torch.equal(a, ref_rgba) and torch.equal(b, ref_depth)
+    tb.set_pipelines(1)
+    a, b = tb.render_both_device(*big)
+    assert torch.equal(a, ref_rgba) and torch.equal(b, ref_depth)
+    tb.set_pipelines(3)
+    a, b = tb.render_both_device(*big)
+    assert torch.equal(a, ref_rgba) and torch.equal(b, ref_depth)
+    tb.set_pipelines(0)
+    c, d = tb.render_both_device(72, 50, 3)
+    assert torch.equal(c, small[0]) and torch.equal(d, small[1])
+    a, b = tb.render_both_device(*big)
+    assert torch.equal(a, ref_rgba) and torch.equal(b, ref_depth)
