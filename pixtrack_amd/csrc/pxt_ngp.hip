@@ -1054,6 +1054,8 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
 template <int MODE, bool INLINE = false>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
+  // (the late rounds hold fewer groups than the grid has waves: those workgroups leave before copying the weights)
+  if (PXT_NGP_LDS_LEVELS == 0 && blockIdx.x > 0 && blockIdx.x * 32 >= Wk.counters[round * kCtrStride] + 7) return;
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
   __shared__ unsigned s_feat[INLINE ? 4 * 8 * 64 : 1];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
