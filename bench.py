@@ -256,8 +256,10 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
     torch.cuda.synchronize()
     if ws > 1:
         torch.distributed.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, coll_dev)
+    own = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(own, coll_dev)
     gc.enable()
+    report = rank_report(rank, dev.index, dev, numa_node, len(mine), own, coll_dev)
     records = parallel.pack_pose_records(tracker.pose_history, [names[i] for i in mine])
     gathered = parallel.gather_pose_records(records.to(coll_dev), coll_dev)
     video = parallel.stitch_segments(gathered, segs_all, n_total)
@@ -288,8 +290,55 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
         "mean_trans_err_vs_gt": round(float(np.mean(tra)), 6) if tra else None,
         "roofline": None, "cpu_baseline": {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                            "sample": "reported with the frames640 workload only"},
+        **report,
     }
     print(json.dumps(out), flush=True)
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run with
+    N ranks on this node (one per GPU; rendezvous on 127.0.0.1, a free port) and return its exit code.
+    With RCCL as the backend a node with fewer than N GPUs is refused HERE, before anything is spawned -
+    a 1-GPU run must never come back labelled n_gpus = N."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("PXT_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and n_dev < n:
+        print(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible on this node; RCCL needs one GPU per rank "
+              "(PXT_DIST_BACKEND=gloo rehearses the control flow with ranks sharing devices)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               PXT_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def rank_report(rank, local_rank, dev, numa_node, frames, seconds, coll_dev):
+    """What the collective layer saw: every rank's id, device, PCI bus, NUMA node and own frames/s, all-gathered
+    (RCCL for backend nccl).  `ranks_seen` in the JSON line is the sorted list of rank ids that answered."""
+    from pixtrack_amd import parallel
+
+    p = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{dev.index}", "name": p.name,
+            "pci_bus": f"{int(getattr(p, 'pci_domain_id', 0)):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}",
+            "numa_node": numa_node, "frames": frames, "frames_per_s": round(frames / seconds, 3) if seconds > 0 else None,
+            "pid": os.getpid()}
+    reports = parallel.gather_objects(mine)
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    try:
+        v = torch.cuda.nccl.version()
+        rccl = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        rccl = None
+    return {"ranks_seen": sorted(r["rank"] for r in reports), "ranks": sorted(reports, key=lambda r: r["rank"]),
+            "dist_backend": backend, "rccl_version": rccl, "self_launched": os.environ.get("PXT_SELF_LAUNCHED") == "1",
+            "distinct_devices": len({r["pci_bus"] for r in reports})}
 
 
 def main():
@@ -302,7 +351,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra passes (two renders, host frames, K=200)")
     ap.add_argument("--config", choices=["frames640", "objects8", "hd"], default="frames640")
+    ap.add_argument("--object-index", type=int, default=0,
+                    help="objects8: rank r tracks object (object-index + r) mod 8 of config/*.sh (default: object r)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: spawn the N ranks ourselves
 
     from pixtrack_amd import parallel
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
@@ -313,7 +366,10 @@ def main():
     # fewer GPUs than ranks: the ranks then share devices and the collectives run on host tensors.
     backend = os.environ.get("PXT_DIST_BACKEND", "nccl")
     rank, ws, local_rank = parallel.init_from_env(backend)
-    assert ws == max(1, args.gpus) or ws == 1, (ws, args.gpus)
+    if ws != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={ws}: the number would be labelled with "
+                         "the wrong GPU count (launch with torch.distributed.run --nproc-per-node N, or plain "
+                         "`python bench.py --gpus N`, which spawns its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback for the product path)")
     n_dev = torch.cuda.device_count()
@@ -337,7 +393,7 @@ def main():
     obj = None
     if args.config == "objects8":  # BASELINE configs[3]: one object of the reference's config/*.sh per rank
         objs = parallel.load_object_configs()
-        obj = objs[unit % len(objs)]
+        obj = objs[(args.object_index + unit) % len(objs)]
         assets = make_tracking_assets(seed=1002 + unit, width=args.width, height=args.height, n_frames=n_frames,
                                       aabb=obj["aabb"])
     else:
@@ -388,7 +444,9 @@ def main():
     frame_ms = np.diff(np.array([t0] + frame_t)) * 1e3
     tracker.testbed.timing_enable(0)
     enc_ms, enc_launches = tracker.testbed.timing_read()
+    own_elapsed = elapsed
     elapsed = parallel.max_over_ranks(elapsed, coll_dev)
+    report = rank_report(rank, local_rank, dev, numa_node, args.steps, own_elapsed, coll_dev)
     stats = tracker.testbed.stats_accum.cpu().tolist()
     n_renders = tracker.testbed.n_renders - n_renders0
     # Two untimed passes over the next frames of the same sequence.
@@ -495,7 +553,7 @@ def main():
         "data": "synthetic (seeded hash-grid NeRF, He-init UNet, NeRF-rendered query frames + noise)",
         "config": {"workload": ("configs[1]: premier_protein-style object, 640x480, full NeRF render + UNet + LM loop, "
                                 "1 sequence per GPU" if obj is None else
-                                f"configs[3]: one object of config/*.sh per GPU (rank 0: {obj['name']}, OBJ_AABB {obj['OBJ_AABB']}), "
+                                f"configs[3]: one object of config/*.sh per GPU (rank {rank}: {obj['name']}, OBJ_AABB {obj['OBJ_AABB']}), "
                                 "640x480, full loop"), "width": args.width, "height": args.height, "spp": 8,
                    "n_points_per_reference": int(tracker.localizer.refiner._points_of(tracker.reference_ids)[1].shape[0]),
                    "parallelism": f"{ws} independent sequence(s), 1 process/GPU, final RCCL all_gather of poses",
@@ -512,6 +570,7 @@ def main():
                      "max": round(float(frame_ms.max()), 4), "argmax": int(frame_ms.argmax())},
         "stage_ms_note": f"HIP-event times of a separate untimed pass over the next {n_diag // 2} frames",
         "roofline": roofline,
+        **report,
     }
     # other kernels' utilisation from the committed rocprofv3 SQ counter pass of this command
     # (profiles/r02_pmc_sq.json; scripts/pmc_sq_summary.py): matrix-pipe busy of the UNet convolutions,

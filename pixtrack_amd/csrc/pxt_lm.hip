@@ -778,6 +778,22 @@ extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_
   int grid = conf->n_workgroups;
   if (grid <= 0) grid = 128;  // scripts/bench_lm.py: 8.7 us per iteration at 128, 9.9 at 64, 10.2 at 256
   if (grid > kLmMaxGrid) grid = kLmMaxGrid;
+  // every workgroup spins until every granule of the epoch is tagged, so all of them must be resident at
+  // once: never more workgroups than the device (or the partition / CU mask this process sees) can hold.
+  // Several trackers of one process may run their LM kernels side by side (tests: three), so a tracker takes
+  // at most half of the resident slots.
+  static thread_local int resident_cap[16] = {0};
+  int dev_id = 0;
+  PXT_HIP_CHECK(hipGetDevice(&dev_id));
+  if (dev_id >= 0 && dev_id < 16) {
+    if (resident_cap[dev_id] == 0) {
+      int per_cu = 0, cus = 0;
+      PXT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lm_refine_kernel, kLmBlock, 0));
+      PXT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
+      resident_cap[dev_id] = per_cu * cus > 1 ? per_cu * cus / 2 : 1;
+    }
+    if (grid > resident_cap[dev_id]) grid = resident_cap[dev_id];
+  }
   hipStream_t s = (hipStream_t)stream;
   // every polled word is zeroed before every launch (tags count from 1 within the call): the granules of
   // the `grid` workgroups in both areas, and the error word

@@ -250,6 +250,11 @@ class Camera(TensorWrapper):
             hit = memo[key] = self.__class__(data)
         return hit
 
+    def __getstate__(self):
+        # the memo of scaled copies is a cache of this process, not part of the camera (poses.pkl stays as small as
+        # the reference's)
+        return {k: v for k, v in self.__dict__.items() if k != "_scaled"}
+
     def in_image(self, p2d: torch.Tensor) -> torch.Tensor:
         size = self.size.unsqueeze(-2)
         return torch.all((p2d >= 0) & (p2d <= (size - 1)), -1)

@@ -239,8 +239,13 @@ def _training_lens_k1(meta0: Dict) -> float:
     if "params" in cd:
         prm = list(cd["params"]) or [0.0]
         mode = cd.get("mode", 1)
-        undistorted = mode in (0, "0", "Perspective", "perspective", None) and not any(float(x) != 0.0 for x in prm)
-        return 0.0 if undistorted else float(prm[0])
+        if mode in (0, "0", "Perspective", "perspective", None):
+            return 0.0
+        if mode in (1, "1", "OpenCV", "opencv"):
+            return float(prm[0])
+        # instant-ngp's other lens modes (LatLong, OpenCVFisheye, Equirectangular, ...) are not radial-k1 lenses
+        raise _lib.PxtError(f"the snapshot's lens mode {mode!r} is not modelled by this renderer "
+                            "(perspective and OpenCV radial k1 are)")
     if not cd:
         return 0.0
     raise _lib.PxtError(f"snapshot lens record has none of the known keys (k1 / params): {sorted(map(str, cd))}")
@@ -324,6 +329,20 @@ class Testbed:
         self._stats = None
         self.stats_accum = None
         self.n_renders = 0
+        self._cam_ring = None  # pinned camera records of pose-driven renders (see _next_cam_out)
+        self._cam_next = 0
+
+    def _next_cam_out(self) -> torch.Tensor:
+        """A pinned 16-float record for the camera kernel of a pose-driven render.  The kernel receives the raw
+        pointer, so torch's host allocator cannot know when the block is free again; the records therefore live
+        as long as the testbed and are recycled round-robin - eight of them, at most two are written per frame and
+        a frame's kernels have finished (its LM result was read) long before eight more renders are queued."""
+        if self._cam_ring is None:
+            self._cam_ring = [torch.zeros(16, dtype=torch.float32).pin_memory() for _ in range(8)]
+        buf = self._cam_ring[self._cam_next]
+        self._cam_next = (self._cam_next + 1) % len(self._cam_ring)
+        buf.zero_()
+        return buf
 
     # class-attribute style access used by pixtrack: testbed.render_mode.Depth
     RenderMode = RenderMode
@@ -425,7 +444,7 @@ class Testbed:
             raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
         rgba = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
         depth = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
-        cam_out = torch.zeros(16, dtype=torch.float32).pin_memory()
+        cam_out = self._next_cam_out()
         ops.ngp_render_both_from_pose(self._ctx_int(), self._view_for(width, height), pose_record, conv, int(width),
                                       int(height), int(spp), 0, rgba, depth, cam_out, self.stats_accum)
         self.n_renders += 1
@@ -438,7 +457,7 @@ class Testbed:
         if not self.snap_to_pixel_centers:
             raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
         out = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
-        cam_out = torch.zeros(16, dtype=torch.float32).pin_memory()
+        cam_out = self._next_cam_out()
         ops.ngp_render_both_from_pose(self._ctx_int(), self._view_for(width, height), pose_record, conv, int(width),
                                       int(height), int(spp), int(self.render_mode), out, None, cam_out, self.stats_accum)
         self.n_renders += 1

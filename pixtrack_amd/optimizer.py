@@ -321,8 +321,9 @@ class PixTrackOptimizer:
         T_prev = Pose(T_init.as12().detach().cpu().float())
         for i in range(n):
             T = Pose(lg[i, 8:20].clone())
-            self.logging_fn(i=i, T_init=T_init, T=T, T_delta=T @ T_prev.inv(), cost=lg[i, 0:1].clone(),
-                            valid=torch.ones(1), n_valid=int(lg[i, 1]))
+            self.logging_fn(i=i, T_init=T_init, T=T, T_delta=T @ T_prev.inv(),
+                            cost=lg[i, 0:1].clone().reshape(1, 1),  # [batch 1, one already-averaged entry]
+                            valid=torch.ones(1, 1), n_valid=int(lg[i, 1]))
             T_prev = T
 
 

@@ -99,6 +99,16 @@ def gather_pose_records(records: torch.Tensor, device=None) -> List[torch.Tensor
     return [o[: int(k)].cpu() for o, k in zip(outs, ns)]
 
 
+def gather_objects(obj) -> list:
+    """Every rank receives every rank's (small, picklable) record, in rank order."""
+    rank, ws = world()
+    if ws == 1:
+        return [obj]
+    out = [None] * ws
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def max_over_ranks(value: float, device=None) -> float:
     rank, ws = world()
     if ws == 1:

@@ -129,6 +129,9 @@ class PixLocPoseTrackerR9(PoseTracker):
         self._ahead = None       # the render queued behind the last LM launch
         self._ahead_ok = None    # ... once verified: (pose object it is valid for, mask, uint8 reference image)
         self.renders_ahead_used = 0
+        self.renders_ahead_dropped = 0   # camera record never arrived within the poll bound
+        self.renders_ahead_rejected = 0  # host and device disagree on a camera bit
+        self.renders_ahead_stale = 0     # view settings changed between enqueue and use
 
     # ------------------------------------------------------------------ per-variant set-up
     def _initial_reference_ids(self, assets):
@@ -261,11 +264,16 @@ class PixLocPoseTrackerR9(PoseTracker):
     def get_mask(self, pose) -> torch.Tensor:
         """uint8 [H,W] on the device: depth render != 0, erode 5x5 x1, dilate 5x5 x5."""
         if self._ahead_ok is not None and self._ahead_ok[0] is pose:
-            _, mask, ref_u8 = self._ahead_ok
+            _, mask, ref_u8, views = self._ahead_ok
             self._ahead_ok = None
-            self._fused_reference = (pose, ref_u8)
-            self.renders_ahead_used += 1
-            return mask
+            # the queued render also baked in focal length, size, spp, lens, render box, background and minimum
+            # transmittance as they were when it was enqueued: it stands in for this frame's render only if
+            # they are what this frame would use
+            if views == self._ahead_views_now():
+                self._fused_reference = (pose, ref_u8)
+                self.renders_ahead_used += 1
+                return mask
+            self.renders_ahead_stale += 1
         self._ahead_ok = None
         if self._views_coincide():
             import math
@@ -297,24 +305,51 @@ class PixLocPoseTrackerR9(PoseTracker):
             w, h = (int(v) for v in cam.size)
             return w, h, math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
 
+        spp = int(self.spp)
         if self._views_coincide():  # one march yields the mask's depth and the reference image
             width, height, fl_x = self._coincide_cache[2]
             self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
-            rgba, depth, cam_out = self.testbed.render_both_from_pose_device(width, height, self.spp, pending.buf, conv)
+            views = [self._ahead_view_key(width, height, spp)]
+            rgba, depth, cam_out = self.testbed.render_both_from_pose_device(width, height, spp, pending.buf, conv)
+            cams = [cam_out]
         else:  # two renders: Depth with the query camera, Shade with SfM camera 1 x reference_scale (:145-152, :207-214)
             width, height, self.testbed.fov = fov_of(self.camera)
+            views = [self._ahead_view_key(width, height, spp)]
             self.testbed.render_mode = self.testbed.render_mode.Depth
             try:
-                depth, cam_out = self.testbed.render_from_pose_device(width, height, self.spp, pending.buf, conv)
+                depth, cam_out = self.testbed.render_from_pose_device(width, height, spp, pending.buf, conv)
             finally:
                 self.testbed.render_mode = self.testbed.render_mode.Shade
             rw, rh, self.testbed.fov = fov_of(self._reference_camera())
-            rgba, _ = self.testbed.render_from_pose_device(rw, rh, self.spp, pending.buf, conv)
+            views.append(self._ahead_view_key(rw, rh, spp))
+            rgba, cam_ref = self.testbed.render_from_pose_device(rw, rh, spp, pending.buf, conv)
+            cams = [cam_out, cam_ref]  # both records stay referenced until their kernels have been observed
         ref_u8 = rgba_to_u8(rgba, 0.0)
         mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
         tmp = torch.empty(2 * height * width, dtype=torch.uint8, device=self.device)
         ops.depth_mask(depth, 1, 5, mask, tmp)
-        self._ahead = (cam_out, mask, ref_u8)
+        self._ahead = (cams, mask, ref_u8, views)
+
+    def _ahead_view_key(self, width, height, spp):
+        """Everything a queued render baked in besides the camera pose: focal length, lens, render box, background,
+        minimum transmittance (floats 12.. of the view record), image size and spp."""
+        return (tuple(self.testbed._view_for(width, height)[12:]), int(width), int(height), int(spp))
+
+    def _ahead_views_now(self):
+        """The view keys get_mask / get_reference_image would render with right now."""
+        import math
+
+        spp = int(self.spp)
+        fov0 = self.testbed.fov
+        try:
+            keys = []
+            for cam in ([self.camera] if self._views_coincide() else [self.camera, self._reference_camera()]):
+                w, h = (int(v) for v in cam.size)
+                self.testbed.fov = math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
+                keys.append(self._ahead_view_key(w, h, spp))
+            return keys
+        finally:
+            self.testbed.fov = fov0
 
     def _verify_render_ahead(self, success: bool):
         """The render queued behind the LM launch is kept for the next frame only if the pose was accepted and the
@@ -323,17 +358,21 @@ class PixLocPoseTrackerR9(PoseTracker):
         self._ahead_ok = None
         if ahead is None or not success:
             return
-        cam_out, mask, ref_u8 = ahead
+        cams, mask, ref_u8, views = ahead
         self.testbed.set_nerf_camera_matrix(np.asarray(self._nerf_pose(self.pose))[:3, :])
         want = np.asarray(self.testbed._cam_ngp, np.float32).reshape(-1)
-        got = cam_out.numpy()
-        for _ in range(200000):  # the camera kernel runs right behind the LM kernel whose result is already here
-            if got[12] != 0.0:
-                break
-        else:
-            return
-        if np.array_equal(want.view(np.uint32), got[:12].view(np.uint32)):
-            self._ahead_ok = (self.pose, mask, ref_u8)
+        for cam_out in cams:
+            got = cam_out.numpy()
+            for _ in range(200000):  # the camera kernel runs right behind the LM kernel whose result is already here
+                if got[12] != 0.0:
+                    break
+            else:  # never arrived: the queued render is dropped (and counted), the frame renders as usual
+                self.renders_ahead_dropped += 1
+                return
+            if not np.array_equal(want.view(np.uint32), got[:12].view(np.uint32)):
+                self.renders_ahead_rejected += 1
+                return
+        self._ahead_ok = (self.pose, mask, ref_u8, views)
 
     # ------------------------------------------------------------------ one frame
     def refine(self, query):
@@ -354,8 +393,8 @@ class PixLocPoseTrackerR9(PoseTracker):
             refiner.feature_extractor.stage(query_image, 1, refiner.query_mask, True)
         else:
             refiner.feature_extractor.unstage()
-        # one refinement, at full scale, of a tracked frame whose two views coincide: its LM launch can carry the
-        # next frame's render behind it
+        # one refinement, at full scale, of a tracked frame: its LM launch can carry the next frame's render(s)
+        # behind it (one march when mask and reference views coincide, two renders otherwise)
         steady = (not self.cold_start and self.success and refiner.query_mask is not None
                   and refiner.conf.multiscale == [1] and len(self.reference_ids) == 1)
         self._ahead = None

@@ -86,9 +86,9 @@ class DebugTracker(BaseTracker):
             self.T.append(T_init.cpu())
         w = valid.to(cost.dtype)
         masked_mean = (w * cost).sum(-1) / w.sum(-1)
-        self.costs[-1].append(masked_mean.cpu().numpy())
+        self.costs[-1].append(np.atleast_1d(masked_mean.cpu().numpy()))  # (1,) per iteration, as record_level
         self.T.append(T.cpu())
-        self.dt.append(T_delta.magnitude()[1].cpu().numpy())
+        self.dt.append(np.atleast_1d(T_delta.magnitude()[1].cpu().numpy()))
         self.num_iters[-1] = i + 1
 
     # -- debug >= 2 extras ------------------------------------------------------------------------

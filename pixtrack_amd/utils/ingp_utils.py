@@ -30,8 +30,10 @@ def initialize_ingp(snapshot_path, aabb, background=None, device=None):
     testbed.nerf.rendering_min_transmittance = 1e-7
     testbed.fov_axis = 0
     testbed.shall_train = False
-    testbed.render_aabb.min = aabb[0]
-    testbed.render_aabb.max = aabb[1]
+    # config/motor_core.sh writes its y bounds max-first; a box with min > max on an axis contains no point, so
+    # instant-ngp would render background only.  The corners are sorted per axis here (builder's decision).
+    testbed.render_aabb.min = [min(float(a), float(b)) for a, b in zip(aabb[0], aabb[1])]
+    testbed.render_aabb.max = [max(float(a), float(b)) for a, b in zip(aabb[0], aabb[1])]
     testbed.exposure = 0.0
     return testbed
 

@@ -83,13 +83,53 @@ def test_rccl_world_size_one_gather(device):
     assert out.returncode == 0 and "RCCL" in out.stdout, out.stderr[-3000:]
 
 
-def test_two_rank_control_flow_rehearsal(device):
+def test_two_ranks_self_launched_and_reported(device):
+    """`python bench.py --gpus 2` with NO launcher spawns its own two ranks (gloo rehearsal: the ranks share
+    cuda:0) and the line says what the collective layer saw."""
     env = dict(os.environ, PXT_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)  # rank 0 only prints
-    assert d["n_gpus"] == 2 and d["frames_total"] == 20 and d["tracked_ok"] == 20
+    assert d["n_gpus"] == 2 == len(d["ranks_seen"]) and d["ranks_seen"] == [0, 1]
+    assert d["self_launched"] is True and d["dist_backend"] == "gloo"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and len({r["pid"] for r in d["ranks"]}) == 2
+    for r in d["ranks"]:
+        assert r["frames"] == 10 and r["frames_per_s"] > 10.0 and r["device"].startswith("cuda:") and r["pci_bus"]
+    assert d["frames_total"] == 20 and d["tracked_ok"] == 20
     assert abs(d["value"] - 20 / (10 * d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["value"] <= sum(r["frames_per_s"] for r in d["ranks"]) * 1.001  # max-over-ranks time
     assert d["cpu_baseline"]["value"] is None  # timed on rank 0 at N = 1 only
+
+
+def test_launcher_shape_still_works_and_a_wrong_world_size_is_refused(device):
+    """The driver's N > 1 command (torch.distributed.run) keeps working; a world size that differs from --gpus
+    is an error, never a silently mislabelled number."""
+    env = dict(os.environ, PXT_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+           "--config", "objects8", "--object-index", "6"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["ranks_seen"] == [0, 1] and d["self_launched"] is False and d["frames_total"] == 12 == d["tracked_ok"]
+    assert "roncelli_blankk" in d["config"]["workload"]  # rank 0 = object 6 (the thin slab), rank 1 = object 7
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=300, cwd=str(ROOT), env=env2)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_more_gpus_than_the_node_has_is_refused(device):
+    """RCCL needs one GPU per rank: `--gpus 8` on a 1-GPU box exits non-zero with a clear message and no JSON."""
+    import torch
+
+    n = torch.cuda.device_count() + 7
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PXT_DIST_BACKEND")}
+    for cfg in ("frames640", "objects8", "hd"):
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "2",
+                              "--config", cfg], capture_output=True, text=True, timeout=300, cwd=str(ROOT), env=env)
+        assert out.returncode != 0, cfg
+        assert "GPU(s) visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

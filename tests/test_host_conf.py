@@ -72,6 +72,9 @@ def test_debug_tracker_bulk_record_equals_the_per_iteration_hook():
     assert np.allclose(np.ravel(a.costs[0]), np.ravel(b.costs[0]))
     assert len(a.T) == len(b.T) == 5
     assert np.allclose(np.ravel(a.dt), np.ravel(b.dt), atol=1e-6)
+    # same element layout whichever path filled the record (trackers.pkl must not depend on it)
+    assert {np.shape(x) for x in a.costs[0]} == {np.shape(x) for x in b.costs[0]} == {(1,)}
+    assert {np.shape(x) for x in a.dt} == {np.shape(x) for x in b.dt} == {(1,)}
     # the refiner's optimizers report to the LAST tracker attached (pixloc BaseTracker behaviour)
     ref = _Refiner()
     t1 = DebugTracker(ref, 1)

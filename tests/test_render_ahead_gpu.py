@@ -72,6 +72,32 @@ def test_tracking_is_identical_with_and_without_render_ahead(device, fused):
     assert np.array_equal(hist[False], hist[True])
 
 
+def test_a_queued_render_is_not_used_after_the_view_settings_changed(device):
+    """The render queued behind frame N's LM launch baked in spp / render box / background as they were during
+    frame N; if the user changes one before frame N+1, the tracker must render afresh (and count it), and the
+    poses must be those of a tracker that never rendered ahead."""
+    n = 8
+    assets = make_tracking_assets(seed=1002, width=160, height=120, n_frames=n)
+    hist, counters = {}, {}
+    for ahead in (False, True):
+        tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+        tr.render_ahead = ahead
+        tr.spp = 4
+        frames = render_query_frames(assets, tr.testbed)
+        for i in range(n):
+            if i == 4:
+                tr.spp = 2  # between two steady frames
+            if i == 6:
+                tr.testbed.nerf.rendering_min_transmittance = 0.02
+            tr.run_single_frame((f"{i:06d}.png", frames[i]))
+        hist[ahead] = np.stack([np.concatenate([a.ravel() for a in tr.pose_history[f"{i:06d}.png"]["T_refined"].numpy()])
+                                for i in range(n)])
+        counters[ahead] = (tr.renders_ahead_used, tr.renders_ahead_stale, tr.renders_ahead_dropped)
+    assert counters[False] == (0, 0, 0)
+    assert counters[True][1] == 2 and counters[True][0] >= 2 and counters[True][2] == 0, counters
+    assert np.array_equal(hist[False], hist[True])
+
+
 def test_one_pipeline_render_with_the_box_filling_the_view(device):
     """A render below 2^19 rays runs as ONE pipeline over all rays: its buffers must hold every ray (a camera
     close to the box sees it in nearly every pixel; the first layout sized a pipeline for half the rays)."""
