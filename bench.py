@@ -40,8 +40,8 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
 # the dominant kernel: gathers + both MLPs of a round's samples (Shade + Depth of the same rays: MODE 2)
-GATHER_KERNEL = "ngp_shade_kernel<2, true> (hash-grid gathers + MLPs of its own samples)"
-GATHER_KERNEL_PMC = "pxt::ngp_shade_kernel<2, true>"
+GATHER_KERNEL = "ngp_shade_kernel<2> (hash-grid gathers + MLPs of its own samples)"
+GATHER_KERNEL_PMC = "pxt::ngp_shade_kernel<2>"
 
 
 class StageTimer:
@@ -491,9 +491,8 @@ def main():
     if rank != 0:
         return
     stage = timer.totals_ms()
-    # dominant kernel: the round's gather kernel - ngp_shade_kernel<MODE, true>, which gathers the hash-grid features
-    # of its own samples and runs both MLPs on them (PXT_NGP_INLINE_FROM=5: the separate level-major
-    # ngp_encode_kernel of the first half of round 2); kRounds launches per render and pipeline.
+    # dominant kernel: the round's gather kernel - ngp_shade_kernel<MODE>, which gathers the hash-grid features
+    # of its own samples, runs both MLPs on them and composites; kRounds launches per render and pipeline.
     # ALGORITHMIC bytes per launch = composited samples per launch x 512 B; samples the
     # rounds evaluate past a ray's termination are waste and are not credited.
     enc_avg_ms = enc_ms / max(enc_launches, 1)          # over the timed (sampled) launches

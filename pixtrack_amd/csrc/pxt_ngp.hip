@@ -178,11 +178,8 @@ __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, c
   return pack_h2(f0, f1);
 }
 
-#ifndef PXT_NGP_PAIR  // experiment 16 (profiles/r02_ngp_experiments.md): bit-exact, no gain; off
-#define PXT_NGP_PAIR 0
-#endif
 typedef __attribute__((ext_vector_type(2))) unsigned uint2_t;
-// The same level, for a caller whose level is wave-uniform (the level-major encoder): identical indices and
+// The same level, for a caller whose level is wave-uniform (the shade kernel's rolled level loop): identical indices and
 // arithmetic, with the integer work pared down - the two y and two z hash products (or row / plane
 // offsets) are formed once and shared by the 8 corners (v_mul_lo_u32 is quarter rate), and the gathers
 // are buffer loads with a 32-bit byte offset and the level's base as the scalar offset instead of 64-bit
@@ -199,45 +196,11 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
     const unsigned mask = Lv.size - 1u;
     const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
     const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
-#if PXT_NGP_PAIR
-    // The x-neighbours of an even gx hash to idx and idx ^ 1 (the x term enters the hash unmultiplied): one
-    // 8-byte load of the aligned pair serves both corners.  An odd gx needs its +1 corners separately; for an
-    // even gx those four loads carry an offset beyond the buffer's range, which the address unit drops
-    // (returns 0, no cache access; PXT_NGP_PAIR=2 masks them with the exec mask instead): 6 L1 lookups per level
-    // instead of 8.  Measured: render unchanged - the encoder is not bound by lookups per lane either.
-    const bool odd = (gx & 1u) != 0;
-    uint2_t pr[4];
-    unsigned single[4] = {0u, 0u, 0u, 0u};
-    unsigned i0s[4], i1s[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const unsigned h = hy[c & 1] ^ hz[(c >> 1) & 1];
-      i0s[c] = (gx ^ h) & mask;
-      i1s[c] = ((gx + 1u) ^ h) & mask;
-      pr[c] = __builtin_bit_cast(uint2_t, __builtin_amdgcn_raw_buffer_load_b64(grid, (int)((i0s[c] & ~1u) << 2), base, 0));
-    }
-#if PXT_NGP_PAIR == 2
-    if (odd) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) single[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(i1s[c] << 2), base, 0);
-    }
-#else
-#pragma unroll
-    for (int c = 0; c < 4; ++c) single[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, odd ? (int)(i1s[c] << 2) : (int)0xfffffff0u, base, 0);
-#endif
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bool hi = (i0s[c] & 1u) != 0;
-      vals[2 * c] = hi ? pr[c].y : pr[c].x;
-      vals[2 * c + 1] = odd ? single[c] : (hi ? pr[c].x : pr[c].y);
-    }
-#else
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const unsigned idx = ((gx + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask;
       vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
     }
-#endif
   } else {
     const unsigned r2 = Lv.res * Lv.res;
     const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
@@ -256,35 +219,6 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
     w = w * ((c & 2) ? ay : (1.0f - ay));
     w = w * ((c & 4) ? az : (1.0f - az));
     const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
-    f0 += w * (float)hv[0];
-    f1 += w * (float)hv[1];
-  }
-  return pack_h2(f0, f1);
-}
-
-// The LDS variant north_star names: the first PXT_NGP_LDS_LEVELS dense levels are
-// copied into LDS by every shade workgroup and evaluated there, sample by sample, instead of being
-// gathered by the encoder and round-tripped through feat[].  Same indices, same arithmetic, same results.
-#ifndef PXT_NGP_LDS_LEVELS
-#define PXT_NGP_LDS_LEVELS 0
-#endif
-__device__ inline unsigned ngp_encode_level_lds(const unsigned* tab, const NgpLevel& Lv, float ux, float uy, float uz) {
-  const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
-  const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-  const float ax = qx - fx, ay = qy - fy, az = qz - fz;
-  const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
-  const unsigned r2 = Lv.res * Lv.res;
-  const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
-  const unsigned rz[2] = {gz * r2, gz * r2 + r2};
-  float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned idx = min((gx + (c & 1)) + ry[(c >> 1) & 1] + rz[(c >> 2) & 1], Lv.size - 1u);
-    float w = 1.0f;
-    w = w * ((c & 1) ? ax : (1.0f - ax));
-    w = w * ((c & 2) ? ay : (1.0f - ay));
-    w = w * ((c & 4) ? az : (1.0f - az));
-    const half2_t hv = __builtin_bit_cast(half2_t, tab[idx]);
     f0 += w * (float)hv[0];
     f1 += w * (float)hv[1];
   }
@@ -416,16 +350,16 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // round-tripped through feat[level][sample]) because its first all-levels-per-wave kernel, at one wave per SIMD and
 // without the ray order below, re-fetched ~3 KB of lines per 512 algorithmic bytes (7 ms per render).  With
 // sample-fastest ray order, four waves per SIMD and the lanes transposed for the gathers, the all-levels-per-wave
-// kernel is the faster one again (0.92 -> 0.68 ms per render); PXT_NGP_INLINE_FROM=5 keeps the level-major path.
+// kernel is the faster one again (0.92 -> 0.68 ms per render).  The level-major path, the dense levels in LDS
+// (north_star's variant: measured slower, experiment #6) and the x-pair gathers were removed in round 3 (git history).
 //
 // Every ray performs exactly the arithmetic of oracle/ngp_oracle.py on exactly the same
 // samples; samples a round evaluates past a ray's termination point are discarded.
 // ===========================================================================
 constexpr int kK = 8;          // samples per ray per round
-#ifndef PXT_NGP_ROUNDS
-#define PXT_NGP_ROUNDS 5  // 3 / 4 / 6 measured: 1.08 / 1.02 / 1.01 ms per render against 1.00 (profiles/r02_ngp_experiments.md)
-#endif
-constexpr int kRounds = PXT_NGP_ROUNDS;  // wavefront rounds before the tail kernel
+// wavefront rounds before the tail kernel (3 / 4 / 6 measured: 1.08 / 1.02 / 1.01 ms per render against 1.00,
+// profiles/r02_ngp_experiments.md)
+constexpr int kRounds = 5;
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {
@@ -574,13 +508,11 @@ struct NgpWork {
   int* counters;       // [(kRounds + 2) * kCtrStride]: live rays entering round r
   float4* spos;        // [slot * kK + k] = (x, y, z, dt); dt == 0 marks "no sample"
   float* st_t;         // t of each sample (depth mode)
-  unsigned* feat;      // [level][sample] packed fp16 pair
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
   uint8_t* keep[2];    // [round & 1] per slot: the ray continues into the next round (written by shade)
   float4* raydir;      // [pixel * spp + s] = (unit direction, d . camera z): what shading needs of a ray
   float4* sppbuf;      // [pixel][spp] finished rays
   float* sppbuf_d;     // mode 2: finished rays' depth
-  size_t feat_stride;  // samples per level plane
 };
 
 __device__ inline void sh_fragments(const float* d, unsigned* shB0, unsigned* shB1) {
@@ -879,29 +811,6 @@ __global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams 
   }
 }
 
-// Level-major encode: work item = (level, chunk of 256 samples), items ordered by level.
-__global__ __launch_bounds__(256) void ngp_encode_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  const int n = Wk.counters[round * kCtrStride];
-  const long long ns = (long long)n * kK;
-  const long long chunks = (ns + 255) / 256;
-  if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)ns);
-  const float half_s = P.aabb_scale * 0.5f;
-  const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
-  const __amdgpu_buffer_rsrc_t grid = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
-#if PXT_EXP_ENC_LEVELS  // timing experiment (scripts/enc_levels.sh): only levels [lo, hi) are encoded, the image is wrong
-  for (long long item = blockIdx.x + chunks * (PXT_EXP_ENC_LEVELS >> 8); item < chunks * (PXT_EXP_ENC_LEVELS & 255); item += gridDim.x) {
-#else
-  for (long long item = blockIdx.x + chunks * PXT_NGP_LDS_LEVELS; item < chunks * P.n_levels; item += gridDim.x) {
-#endif
-    const int l = (int)(item / chunks);
-    const long long s = (item % chunks) * 256 + threadIdx.x;
-    if (s >= ns) continue;
-    const float4 sp = Wk.spos[s];
-    if (sp.w == 0.f) continue;  // no sample in this slot: shade never reads its features
-    Wk.feat[(size_t)l * Wk.feat_stride + s] = ngp_encode_level_uniform(
-        grid, P.lv[l], (sp.x - scene_lo) * inv_s, (sp.y - scene_lo) * inv_s, (sp.z - scene_lo) * inv_s);
-  }
-}
 
 // Shared by the shade and tail kernels: close a finished ray.
 __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, bool terminated) {
@@ -911,24 +820,17 @@ __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, b
   Wk.sppbuf[rid] = acc;
 }
 
-#ifndef PXT_NGP_GATHER_TRANSPOSE
-#define PXT_NGP_GATHER_TRANSPOSE 1
-#endif
-#ifndef PXT_NGP_INLINE_GROUP
-#define PXT_NGP_INLINE_GROUP 4
-#endif
-// INLINE (the product path, rounds >= PXT_NGP_INLINE_FROM = 0): the wave gathers the hash-grid features of its own
-// 64 samples (all levels, same function as the level-major encoder: same bits) and feeds them to the MLPs - no
-// encoder launch, no feature round trip through HBM (16 x 4 B written and read back per sample), and the gathers of
-// one wave overlap the matrix work of the others.  Render 0.92 -> 0.715 ms.  The level loop stays rolled (unrolled,
-// all 128 gathers are hoisted: 256 VGPRs, one wave per SIMD) and runs in two halves of 8 levels through an 8-KB LDS
-// staging area, which keeps Flo / Fhi on static register indices at 4 waves per SIMD.
-// One group of 8 rays x 8 samples (this wave's 64 lanes): features (gathered here when INLINE, else read from
-// feat[]), both MLPs, in-order compositing, termination; lane (rlane, k) handles sample k of the ray in `slot`.
-// A ray's result does not depend on which rays share its group.
-template <int MODE, bool INLINE>
+// One group of 8 rays x 8 samples (this wave's 64 lanes): the wave gathers the hash-grid features of its own 64
+// samples (all levels) and feeds them to the MLPs - no encoder launch, no feature round trip through HBM (16 x 4 B
+// written and read back per sample in the level-major design of round 1), and the gathers of one wave overlap the
+// matrix work of the others.  Render 0.92 -> 0.715 ms.  The level loop stays rolled (unrolled, all 128 gathers are
+// hoisted: 256 VGPRs, one wave per SIMD) and runs in two halves of 8 levels through an 8-KB LDS staging area, which
+// keeps Flo / Fhi on static register indices at 4 waves per SIMD.  Then both MLPs, in-order compositing,
+// termination; lane (rlane, k) handles sample k of the ray in `slot`.  A ray's result does not depend on which
+// rays share its group.
+template <int MODE>
 __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
-                                                const half8* s_w, unsigned* s_feat, const unsigned* s_tab,
+                                                const half8* s_w, unsigned* s_feat,
                                                 const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
                                                 int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -944,51 +846,32 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
   unsigned shB0[4], shB1[4];
   sh_fragments(rdir, shB0, shB1);
   unsigned Flo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Fhi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  if (!INLINE) {
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-      if (l >= PXT_NGP_LDS_LEVELS) Flo[l] = valid ? Wk.feat[(size_t)l * Wk.feat_stride + si] : 0u;
-      Fhi[l] = valid ? Wk.feat[(size_t)(l + 8) * Wk.feat_stride + si] : 0u;
-    }
-  }
-#if PXT_NGP_LDS_LEVELS > 0
-#pragma unroll
-  for (int l = 0; l < PXT_NGP_LDS_LEVELS; ++l)
-    Flo[l] = valid ? ngp_encode_level_lds(s_tab + P.lv[l].offset, P.lv[l], (sp.x - enc_lo) * enc_inv,
-                                          (sp.y - enc_lo) * enc_inv, (sp.z - enc_lo) * enc_inv)
-                   : 0u;
-#endif
   float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
   // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
   // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
   if (__any(valid)) {
-    if (INLINE) {  // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
-      float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
-      // the features pass through the lane's own LDS column (see the kernel's header)
-      unsigned* col = s_feat + wave * (8 * 64) + lane;
-#if PXT_NGP_GATHER_TRANSPOSE
-      // gather in ray-fastest lane order: lane 8 a + b fetches the sample of lane 8 b + a, so that adjacent lanes hold
-      // the same step of neighbouring rays (the passes of one pixel: positions a fraction of a step apart on one line)
-      // instead of consecutive steps of one ray: the address unit merges the lanes of a quad that share a line.
-      // Render 0.713 -> 0.676 ms.  (Rays ranked by distance within a step on top of that: 0.688, the ranking costs more.)
-      const int tl = ((lane & 7) << 3) | (lane >> 3);
-      ux = __shfl(ux, tl, 64); uy = __shfl(uy, tl, 64); uz = __shfl(uz, tl, 64);
-      unsigned* wcol = s_feat + wave * (8 * 64) + tl;
-#else
-      unsigned* wcol = col;
-#endif
-#pragma unroll PXT_NGP_INLINE_GROUP
-      for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
-      __builtin_amdgcn_wave_barrier();
+    // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
+    float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
+    // the features pass through the lane's own LDS column
+    unsigned* col = s_feat + wave * (8 * 64) + lane;
+    // gather in ray-fastest lane order: lane 8 a + b fetches the sample of lane 8 b + a, so that adjacent lanes hold
+    // the same step of neighbouring rays (the passes of one pixel: positions a fraction of a step apart on one line)
+    // instead of consecutive steps of one ray: the address unit merges the lanes of a quad that share a line.
+    // Render 0.713 -> 0.676 ms.  (Rays ranked by distance within a step on top of that: 0.688, the ranking costs more.)
+    const int tl = ((lane & 7) << 3) | (lane >> 3);
+    ux = __shfl(ux, tl, 64); uy = __shfl(uy, tl, 64); uz = __shfl(uz, tl, 64);
+    unsigned* wcol = s_feat + wave * (8 * 64) + tl;
+#pragma unroll 4
+    for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll PXT_NGP_INLINE_GROUP
-      for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
-      __builtin_amdgcn_wave_barrier();
+    for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
-    }
+    for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
     ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
   }
   // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
@@ -1051,25 +934,18 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
   }
 }
 
-template <int MODE, bool INLINE = false>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
+template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
 __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   // (the late rounds hold fewer groups than the grid has waves: those workgroups leave before copying the weights)
-  if (PXT_NGP_LDS_LEVELS == 0 && blockIdx.x > 0 && blockIdx.x * 32 >= Wk.counters[round * kCtrStride] + 7) return;
+  if (blockIdx.x > 0 && blockIdx.x * 32 >= Wk.counters[round * kCtrStride] + 7) return;
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
-  __shared__ unsigned s_feat[INLINE ? 4 * 8 * 64 : 1];
+  __shared__ unsigned s_feat[4 * 8 * 64];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
-#if PXT_NGP_LDS_LEVELS > 0
-  extern __shared__ unsigned s_tab[];  // the first dense levels, back to back
-  {
-    const unsigned n_tab = P.lv[PXT_NGP_LDS_LEVELS - 1].offset + P.lv[PXT_NGP_LDS_LEVELS - 1].size;
-    for (unsigned i = threadIdx.x; i < n_tab; i += 256) s_tab[i] = P.grid[i];
-  }
-#endif
   __syncthreads();
   const int n = Wk.counters[round * kCtrStride];
-  if (INLINE && P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)n * kK);
+  if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)n * kK);
   const RayState& S = Wk.st[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rlane = lane >> 3;
@@ -1077,12 +953,7 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   const int n_groups = (n + 7) / 8;
   for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
     const int slot = g * 8 + rlane;
-#if PXT_NGP_LDS_LEVELS > 0
-    const unsigned* tab = s_tab;
-#else
-    const unsigned* tab = nullptr;
-#endif
-    ngp_shade_group<MODE, INLINE>(P, Wk, S, Wk.keep[round & 1], s_w, s_feat, tab, grid_rsrc, enc_lo, enc_inv, slot, slot < n, 0, n_samples);
+    ngp_shade_group<MODE>(P, Wk, S, Wk.keep[round & 1], s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, slot < n, 0, n_samples);
   }
   if (P.stats) {  // one atomic per workgroup: a single counter word sustains ~90 atomics/us
     __shared__ unsigned long long s_cnt[4];
@@ -1463,13 +1334,6 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
 // the largest slice.  (The first version sized them for half the rays whatever the number of pipelines: a
 // one-pipeline render - any render below 2^19 rays - whose camera sees the box in more than half of its pixels
 // wrote past them.)
-// First round whose shade kernel gathers its own features (0: all of them, the product; kRounds: the level-major
-// encoder + feature planes of the first half of round 2, kept for A/B and tests/test_variants_gpu.py).
-static int ngp_inline_from() {
-  static const int v = [] { const char* e = getenv("PXT_NGP_INLINE_FROM"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
   size_t cap = (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile;
   if (ctx->scratch && ctx->scratch_rays >= rays && ctx->scratch_cap >= cap && ctx->scratch_pipes >= n_pipe) return PXT_OK;
@@ -1491,7 +1355,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
   struct Offs {
-    size_t rid[2], t[2], T[2], acc[2], accd[2], cnt, spos, stt, feat, exh, keep;
+    size_t rid[2], t[2], T[2], acc[2], accd[2], cnt, spos, stt, exh, keep;
   } o[pxt_ngp::kMaxPipes];
   for (int w = 0; w < kP; ++w) {
     for (int i = 0; i < 2; ++i) {
@@ -1500,8 +1364,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
     }
     o[w].cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
     o[w].spos = take(samples * 16); o[w].stt = take(samples * 4);
-    // feat[]: only the level-major encoder path (PXT_NGP_INLINE_FROM > 0) round-trips features through memory
-    o[w].feat = take(ngp_inline_from() > 0 ? samples * 4 * kMaxLevels : 256); o[w].exh = take(half); o[w].keep = take(2 * al(half));
+    o[w].exh = take(half); o[w].keep = take(2 * al(half));
   }
   const size_t o_sppd = take(rays * 4), o_spp = take(rays * 16), o_rdir = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
@@ -1517,14 +1380,12 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
     W.counters = (int*)(b + o[w].cnt);
     W.spos = (float4*)(b + o[w].spos);
     W.st_t = (float*)(b + o[w].stt);
-    W.feat = (unsigned*)(b + o[w].feat);
     W.exhausted = (uint8_t*)(b + o[w].exh);
     W.keep[0] = (uint8_t*)(b + o[w].keep);
     W.keep[1] = W.keep[0] + al(half);
     W.sppbuf = (float4*)(b + o_spp);
     W.sppbuf_d = (float*)(b + o_sppd);
     W.raydir = (float4*)(b + o_rdir);
-    W.feat_stride = samples;
   }
   ctx->scratch_rays = rays;
   ctx->scratch_cap = cap;
@@ -1593,21 +1454,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));  // the side streams start after the caller's earlier work
     for (int w = 1; w < n_pipe; ++w) PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side[w], ctx->ev_fork, 0));
   }
-  const int wide = 2048, enc_grid = 4096, cmp_grid = 1024;  // grid-stride kernels: full grids measured best
-#if PXT_NGP_LDS_LEVELS > 0
-  const size_t shade_lds = (size_t)(ctx->lv[PXT_NGP_LDS_LEVELS - 1].offset + ctx->lv[PXT_NGP_LDS_LEVELS - 1].size) * 4;
-  static const int shade_grid = [] { const char* e = getenv("PXT_NGP_SHADE_GRID"); return e ? atoi(e) : 768; }();
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
-    (void)hipFuncSetAttribute((const void*)ngp_shade_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shade_lds);
-    (void)hipFuncSetAttribute((const void*)ngp_shade_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shade_lds);
-    (void)hipFuncSetAttribute((const void*)ngp_shade_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shade_lds);
-  }
-#else
-  const size_t shade_lds = 0;
+  const int wide = 2048, cmp_grid = 1024;  // grid-stride kernels: full grids measured best
   static const int shade_grid = [] { const char* e = getenv("PXT_NGP_SHADE_GRID"); return e ? atoi(e) : 2048; }();
-#endif
   static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
   // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
   // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)
@@ -1623,14 +1471,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
       hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
-  const int inline_from = ngp_inline_from();
   for (int r = 0; r < kRounds; ++r) {
-    const bool inl = r >= inline_from;  // the shade kernel encodes its own samples: no encoder launch
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
         hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-    // the round's gather kernel (the encoder, or the shade kernel that encodes its own samples) is the one the
-    // timing events bracket (bench.py's roofline)
+    // the round's shade kernel (gathers + MLPs + compositing) is the one the timing events bracket (bench.py's roofline)
     for (int w = 0; w < n_pipe; ++w) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timed) {
@@ -1644,27 +1489,17 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
         }
         PXT_HIP_CHECK(hipEventRecord(e0, st[w]));
       }
-      if (!inl) {
-        hipLaunchKernelGGL(ngp_encode_kernel, dim3(enc_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-      } else if (mode == 1) {
-        hipLaunchKernelGGL((ngp_shade_kernel<1, true>), dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
+      if (mode == 1) {
+        hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(shade_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
       } else if (mode == 2) {
-        hipLaunchKernelGGL((ngp_shade_kernel<2, true>), dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
+        hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(shade_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
       } else {
-        hipLaunchKernelGGL((ngp_shade_kernel<0, true>), dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
+        hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(shade_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
       }
       if (timed) {
         PXT_HIP_CHECK(hipEventRecord(e1, st[w]));
         ctx->events.emplace_back(e0, e1);
       }
-    }
-    for (int w = 0; w < n_pipe && !inl; ++w) {
-      if (mode == 1)
-        hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
-      else if (mode == 2)
-        hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
-      else
-        hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(shade_grid), dim3(256), shade_lds, st[w], Pp[w], ctx->work[w], r);
     }
     for (int w = 0; w < n_pipe; ++w) {
       if (fuse_cm && r + 1 < kRounds)  // compaction of round r + march of round r + 1 in one launch
