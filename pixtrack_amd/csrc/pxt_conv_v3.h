@@ -1,0 +1,325 @@
+// 3x3 convolution (pad 1), NHWC fp16 -> NHWC fp16, MFMA implicit GEMM -- third generation (round 3).
+// Included by pxt_unet.hip after pxt_conv_v2.h (shares ConvArgs, static_for, opaque, PXT_STAMP).
+//
+// What the second kernel's counters and timelines said: its loop ran the matrix pipe at ~66 %, the
+// missing third being the filter fragments every wave fetched for itself straight from L2 (with PBW = 2 tiles that
+// stream alone is 64 B/clk/CU = the whole L1 path; a wave that cannot issue its load cannot issue its MFMAs either),
+// and every MFMA read a fresh pixel fragment from LDS.  This kernel changes the dataflow of a (k-step, kx) GROUP:
+//  * PIXEL FRAGMENTS ARE SHARED BY THE THREE VERTICAL TAPS.  A wave's 32-pixel block p is {row p, row p + PBW} x 16
+//    columns of its 2*PBW-row strip, so the fragment block p needs for tap ky is "rows (p + ky, p + ky + PBW) at column
+//    shift kx" = fragment index p + ky: a group reads PBW + 2 fragments for its 3 * PBW * CW MFMAs instead of 3 * PBW.
+//  * THE FILTER FRAGMENTS OF A GROUP GO THROUGH LDS, ONCE PER WORKGROUP.  They are packed [chunk][s][kx][ky][cout
+//    block][lane][8], so a group's taps for the workgroup's cout blocks are three contiguous runs; the workgroup
+//    copies them (plain 16-B loads one group ahead, ds_write at the end of the group, double buffered) and every wave
+//    reads its fragments with conflict-free ds_read_b128: 1-3 vector-memory instructions per thread and group instead
+//    of 3 * CW per wave, the L1 path is left to the halo.
+//  * one barrier per group; two workgroups per CU (<= 80 KB of LDS, <= 256 registers) fill each other's barrier and
+//    epilogue gaps.
+//  * KC = 16-channel chunks (32-B pixel records) halve the halo buffers for the 64- / 32-channel layers whose
+//    workgroup tile is 32 rows high.
+#pragma once
+
+namespace pxt {
+
+template <int KC>
+struct V3Geo {
+  static constexpr int kPix = KC * 2;               // bytes of a pixel record in LDS
+  static constexpr int kNP = KC / 8;                // 16-B pieces per pixel
+  static constexpr int kRow = 20 * kPix;            // row pitch: 18 records used
+  static constexpr int kPixPerBankRow = 256 / kPix; // pixels per 256-B bank row
+  __device__ static inline int swz(int col) {       // piece-index XOR that spreads 16 consecutive columns over 16 slots
+    return kPixPerBankRow == 4 ? ((col >> 2) & 3) : ((col >> 3) & 1);
+  }
+};
+
+// packed index of element (cout, tap = ky * 3 + kx, cin) in the v3 layout
+__host__ __device__ inline size_t packed_weight_index_v3(int cout, int tap, int cin, int Cout) {
+  const int ky = tap / 3, kx = tap % 3;
+  const int k = cin & 31, s = k >> 4, lane = (cout & 31) + 32 * ((k & 15) >> 3), j = k & 7;
+  const size_t group = (size_t)(cin >> 5) * 6 + s * 3 + kx;
+  return ((group * 3 + ky) * (size_t)(Cout >> 5) + (cout >> 5)) * 512 + lane * 8 + j;
+}
+
+__global__ void pack_conv_weights_v3_kernel(const half_t* __restrict__ w /* [Cout][9][Cin] */, int Cin, int Cout,
+                                            half_t* __restrict__ packed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Cout * 9 * Cin) return;
+  const int cin = (int)(i % Cin);
+  const int tap = (int)((i / Cin) % 9);
+  const int cout = (int)(i / ((long long)Cin * 9));
+  packed[packed_weight_index_v3(cout, tap, cin, Cout)] = w[i];
+}
+
+// packed fp16 pair max
+__device__ inline unsigned pk_max(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2v, a), __builtin_bit_cast(half2v, b)));
+}
+
+constexpr int v3_lds_bytes(int CW, int PBW, int WC, int WP, int KC) {
+  return 2 * (2 * PBW * WP + 2) * (20 * KC * 2) + 2 * 3 * CW * WC * 1024 + 32 * CW * WC * 4;
+}
+
+template <int CW, int PBW, int WC, int WP, int KC>
+__global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
+  static_assert(WC * WP == 4, "four waves per workgroup");
+  static_assert(KC == 16 || KC == 32, "chunk of 16 or 32 input channels");
+  using G = V3Geo<KC>;
+  constexpr int TH = 2 * PBW * WP, HR = TH + 2;
+  constexpr int NCB = CW * WC, BNC = 32 * NCB;
+  constexpr int NG = 3 * (KC / 16);                 // (k-step, kx) groups per chunk
+  constexpr int kBuf = HR * G::kRow;
+  constexpr int kABuf = 3 * NCB * 1024;
+  constexpr int kElems = HR * kV2Cols * G::kNP;     // 16-B pieces of one halo chunk
+  constexpr int KH = (kElems + 255) / 256;
+  constexpr int kAElems = 3 * NCB * 64;             // 16-B pieces of one group's filter fragments
+  constexpr int KA = (kAElems + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const s_halo = smem;
+  char* const s_a = smem + 2 * kBuf;
+  float* const s_bias = (float*)(smem + 2 * kBuf + 2 * kABuf);
+
+  PXT_STAMP(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave / WP, wp = wave % WP;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int tiles_x = (W + 15) >> 4;
+  const int tiles_per = tiles_x * ((H + TH - 1) / TH);
+  const int img = blockIdx.x / tiles_per, tile = blockIdx.x % tiles_per;
+  const int n_img = gridDim.x / tiles_per;
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * 16;
+  const int co0 = blockIdx.y * BNC;
+  const half_t* in = a.in + (size_t)img * H * W * Cin;
+
+  if (tid < BNC) s_bias[tid] = a.bias[co0 + tid];
+
+  f32x16 acc[CW][PBW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c)
+#pragma unroll
+    for (int p = 0; p < PBW; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][p][r] = 0.f;
+
+  const int r31 = lane & 31, khalf = lane >> 5;
+  // this lane's pixel of a block: halo row (block index j added as an immediate) and column
+  const int lrow = 2 * PBW * wp + (r31 >> 4) * PBW, lcol = r31 & 15;
+
+  // K range of this workgroup (split-K over gridDim.z), in chunks of KC channels
+  const int n_chunks = Cin / KC;
+  const int per_z = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int ch_begin = (int)blockIdx.z * per_z, ch_end = min(n_chunks, ch_begin + per_z);
+  const int n_groups = (ch_end - ch_begin) * NG;
+
+  // ---- filter staging: group gg (global index) = three runs of NCB KiB --------------------------
+  const size_t a_group = (size_t)3 * (Cout >> 5) * 512;  // halves per group
+  const half_t* const wbase = a.wpk + (size_t)ch_begin * NG * a_group + (size_t)(co0 >> 5) * 512;
+  unsigned a_src[KA];  // halves offset inside a group
+#pragma unroll
+  for (int k = 0; k < KA; ++k) {
+    const int i = min(tid + 256 * k, kAElems - 1);
+    const int ky = i / (NCB * 64), rem = i % (NCB * 64);
+    a_src[k] = (unsigned)(ky * (Cout >> 5) * 512 + rem * 8);
+  }
+  half8 r_a[KA];
+  auto a_issue = [&](int gg) {  // gg clamped by the caller
+    const half_t* src = wbase + (size_t)gg * a_group;
+#pragma unroll
+    for (int k = 0; k < KA; ++k) r_a[k] = *(const half8*)(src + a_src[k]);
+  };
+  auto a_write = [&](int buf) {
+    const int t_ = opaque(tid);
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+      const int i = t_ + 256 * k;
+      if (i < kAElems) *(half8*)(s_a + buf * kABuf + i * 16) = r_a[k];
+    }
+  };
+
+  // ---- halo staging (as in the second kernel: unconditional bounds-checked buffer loads) ----------
+  half8 r_in[KH];
+  unsigned goff[KH];
+#pragma unroll
+  for (int k = 0; k < KH; ++k) {
+    const int i = tid + 256 * k;
+    const int pix = i / G::kNP, seg = i % G::kNP;
+    const int gy = ty0 + pix / kV2Cols - 1, gx = tx0 + pix % kV2Cols - 1;
+    const bool ok = i < kElems && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    goff[k] = ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)(seg * 8)) * 2u : 0x80000000u;
+  }
+  const __amdgpu_buffer_rsrc_t in_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((size_t)H * W * Cin * 2), 0x00020000);
+  auto halo_issue = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < KH; ++k)
+      r_in[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(goff[k] + (unsigned)(c0 * 2)), 0, 0));
+  };
+  auto halo_write = [&](int buf) {
+    const int t_ = opaque(tid);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int i = t_ + 256 * k;
+      const int pix = i / G::kNP, seg = i % G::kNP;
+      const int hy = pix / kV2Cols, hx = pix % kV2Cols;
+      if (i < kElems) *(half8*)(s_halo + buf * kBuf + hy * G::kRow + hx * G::kPix + ((seg ^ G::swz(hx)) << 4)) = r_in[k];
+    }
+  };
+
+  if (n_groups > 0) {  // first chunk and first group: staged synchronously
+    halo_issue(ch_begin * KC);
+    a_issue(0);
+    halo_write(0);
+    a_write(0);
+  }
+  PXT_STAMP(1);
+
+  int gg = 0;  // running group index inside this workgroup's K range
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const bool more = ch + 1 < ch_end;
+    const int hbuf = (ch - ch_begin) & 1;
+    static_for<0, NG>([&](auto g_c) {
+      constexpr int g = decltype(g_c)::value;
+      constexpr int s = KC == 32 ? g / 3 : 0, kx = g % 3;
+      __syncthreads();  // this group's filter fragments (and, for g = 0, this chunk's halo) are complete
+      const int abuf = gg & 1;
+      a_issue(min(gg + 1, n_groups - 1));
+      if (more) {
+        if constexpr (g == 0) halo_issue((ch + 1) * KC);
+      }
+      // fragments of this group: PBW + 2 pixel fragments shared by the three vertical taps, 3 * CW filter fragments
+      half8 bq[PBW + 2], aq[3][CW];
+      {
+        const int col = lcol + kx;
+        const char* bp = s_halo + hbuf * kBuf + lrow * G::kRow + col * G::kPix +
+                         ((((KC == 32 ? 2 * s : 0) + khalf) ^ G::swz(col)) << 4);
+#pragma unroll
+        for (int j = 0; j < PBW + 2; ++j) bq[j] = *(const half8*)(bp + j * G::kRow);
+        const char* ap = s_a + abuf * kABuf + (CW * wc * 64 + lane) * 16;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int c = 0; c < CW; ++c) aq[ky][c] = *(const half8*)(ap + (ky * NCB + c) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the staging loads above stay above the MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int p = 0; p < PBW; ++p)
+#pragma unroll
+          for (int c = 0; c < CW; ++c)
+            acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[ky][c], bq[p + ky], acc[c][p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a_write(abuf ^ 1);
+      if (more) {
+        if constexpr (g == NG - 2) halo_write(hbuf ^ 1);
+      }
+      ++gg;
+    });
+    if (ch - ch_begin < 10) PXT_STAMP(4 + ch - ch_begin);
+  }
+  PXT_STAMP(2);
+
+  // ---- epilogue: D[row = cout][col = pixel]; lane: pixel r31 of block p, channels (r&3) + 8*(r>>2) + 4*khalf
+  __syncthreads();  // every wave is done with the LDS buffers: the output tile is staged there
+  PXT_STAMP(12);
+  const int cw0 = co0 + 32 * CW * wc;
+  half_t* out = a.out + (size_t)img * H * W * Cout;
+  constexpr int kPitch = CW * 64 + 16;
+  char* const stage = smem + wave * (32 * kPitch);
+  static_assert(4 * 32 * kPitch <= 2 * kBuf, "the output staging area fits in the halo buffers");
+  const int row0 = ty0 + 2 * PBW * wp;
+  if (gridDim.z > 1) {
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) {
+      const int gy = row0 + p + (r31 >> 4) * PBW, gx = tx0 + lcol;
+      if (!(gy < H && gx < W)) continue;
+      float* pd = a.partial + ((((size_t)blockIdx.z * n_img + img) * H + gy) * W + gx) * Cout + cw0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *(float4*)(pd + 32 * c + 8 * g4 + 4 * khalf) =
+              make_float4(acc[c][p][4 * g4 + 0], acc[c][p][4 * g4 + 1], acc[c][p][4 * g4 + 2], acc[c][p][4 * g4 + 3]);
+    }
+    PXT_STAMP(3);
+    return;
+  }
+  const bool do_pool = a.pool != nullptr && (PBW % 2 == 0);
+  // bias + ReLU + fp16 of block p: 8 * CW packed dwords per lane, [c][g4][2]
+  auto pack_block = [&](int p, unsigned (&o)[CW][4][2]) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 bv = *(const float4*)(s_bias + 32 * (CW * wc + c) + 8 * g4 + 4 * khalf);
+        float v0 = acc[c][p][4 * g4 + 0] + bv.x, v1 = acc[c][p][4 * g4 + 1] + bv.y;
+        float v2 = acc[c][p][4 * g4 + 2] + bv.z, v3 = acc[c][p][4 * g4 + 3] + bv.w;
+        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        half4 h;
+        h[0] = (half_t)v0; h[1] = (half_t)v1; h[2] = (half_t)v2; h[3] = (half_t)v3;
+        o[c][g4][0] = ((const unsigned*)&h)[0];
+        o[c][g4][1] = ((const unsigned*)&h)[1];
+      }
+  };
+  // the tile leaves through LDS so that 4 * CW consecutive lanes store one pixel's 64 * CW contiguous bytes
+  auto store_block = [&](int p, unsigned (&o)[CW][4][2]) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4 += 2) {
+        // lanes 0-31 (khalf 0) end up with channels 8 g4 .. 8 g4 + 7, lanes 32-63 with 8 (g4 + 1) .. + 7
+        auto s0 = __builtin_amdgcn_permlane32_swap(o[c][g4][0], o[c][g4 + 1][0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(o[c][g4][1], o[c][g4 + 1][1], false, false);
+        *(uint4*)(stage + r31 * kPitch + (32 * c + 8 * (g4 + khalf)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int kLpp = 4 * CW;  // lanes per pixel (16 B each)
+#pragma unroll
+    for (int it = 0; it < 2 * CW; ++it) {
+      const int pix = it * (64 / kLpp) + lane / kLpp, piece = lane % kLpp;
+      const uint4 v = *(const uint4*)(stage + pix * kPitch + piece * 16);
+      const int oy = row0 + p + (pix >> 4) * PBW, ox = tx0 + (pix & 15);
+      if (oy < H && ox < W) *(uint4*)(out + ((size_t)oy * W + ox) * Cout + cw0 + piece * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();  // the next block overwrites the stage
+  };
+  if (do_pool) {  // rows p and p + 1 (p even) are a pooling pair held by the same lane; the column pair comes by DPP
+#pragma unroll
+    for (int p = 0; p < PBW - (PBW % 2); p += 2) {
+      unsigned o0[CW][4][2], o1[CW][4][2];
+      pack_block(p, o0);
+      pack_block(p + 1, o1);
+      const int gy = row0 + p + (r31 >> 4) * PBW, gx = tx0 + lcol;
+      const bool pool_lane = (lcol & 1) == 0 && (gy >> 1) < (H >> 1) && (gx >> 1) < (W >> 1);
+      half_t* pdst = a.pool + (((size_t)img * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * Cout + cw0;
+#pragma unroll
+      for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          unsigned m[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const unsigned v = pk_max(o0[c][g4][h], o1[c][g4][h]);
+            const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+            m[h] = pk_max(v, nb);
+          }
+          if (pool_lane) *(uint2*)(pdst + 32 * c + 8 * g4 + 4 * khalf) = make_uint2(m[0], m[1]);
+        }
+      store_block(p, o0);
+      store_block(p + 1, o1);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) {
+      unsigned o[CW][4][2];
+      pack_block(p, o);
+      store_block(p, o);
+    }
+  }
+  PXT_STAMP(3);
+}
+
+}  // namespace pxt

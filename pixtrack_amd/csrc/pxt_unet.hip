@@ -160,6 +160,7 @@ struct UpSrc {
 
 }  // namespace pxt
 #include "pxt_conv_v2.h"
+#include "pxt_conv_v3.h"
 namespace pxt {
 
 // Split-K epilogue: out = relu(sum_z partial[z] + bias) -> fp16, 4 channels per thread.
@@ -323,14 +324,26 @@ namespace {
 // ---- launch plan of one 3x3 layer ------------------------------------------------------------
 // Tile configurations of conv3x3_v2_kernel<CW, PBW, WC, WP>: a workgroup (4 waves, WC x WP) covers
 // TH = 2*PBW*WP rows x 16 columns of pixels and BNC = 32*CW*WC output channels.
-struct V2Cfg { int CW, PBW, WC, WP; };
-constexpr V2Cfg kV2Cfgs[7] = {{0, 0, 0, 0},
-                              {2, 4, 2, 2},   // 1: 16x16 px x 128 ch  (wave: 64 ch x 128 px)
-                              {2, 2, 1, 4},   // 2: 16x16 px x  64 ch  (wave: 64 ch x  64 px)
-                              {2, 4, 1, 4},   // 3: 32x16 px x  64 ch  (measured slower everywhere: not instantiated)
-                              {2, 2, 2, 2},   // 4:  8x16 px x 128 ch
-                              {1, 4, 1, 4},   // 5: 32x16 px x  32 ch  (not instantiated)
-                              {1, 2, 1, 4}};  // 6: 16x16 px x  32 ch
+struct V2Cfg { int CW, PBW, WC, WP, KC; };
+constexpr int kNumCfgs = 17;
+constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
+                                     {2, 4, 2, 2, 32},   // 1: 16x16 px x 128 ch  (wave: 64 ch x 128 px)
+                                     {2, 2, 1, 4, 32},   // 2: 16x16 px x  64 ch  (wave: 64 ch x  64 px)
+                                     {0, 0, 0, 0, 0},    // 3: (32x16 px x 64 ch: measured slower everywhere, removed)
+                                     {2, 2, 2, 2, 32},   // 4:  8x16 px x 128 ch
+                                     {0, 0, 0, 0, 0},    // 5: (32x16 px x 32 ch: removed)
+                                     {1, 2, 1, 4, 32},   // 6: 16x16 px x  32 ch
+                                     {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0},
+                                     // conv3x3_v3_kernel (pxt_conv_v3.h): pixel fragments shared by the vertical taps,
+                                     // filter fragments through LDS
+                                     {2, 4, 2, 2, 32},   // 11: 16x16 px x 128 ch
+                                     {0, 0, 0, 0, 0},
+                                     {2, 4, 1, 4, 16},   // 13: 32x16 px x  64 ch, 16-channel chunks
+                                     {2, 2, 2, 2, 32},   // 14:  8x16 px x 128 ch
+                                     {2, 3, 2, 2, 32},   // 15: 12x16 px x 128 ch (no fused pool: odd block count)
+                                     {1, 4, 1, 4, 16}};  // 16: 32x16 px x  32 ch, 16-channel chunks
+inline bool cfg_valid(int cfg) { return cfg >= 1 && cfg < kNumCfgs && kV2Cfgs[cfg].CW != 0; }
+inline bool cfg_v3(int cfg) { return cfg >= 11; }
 inline int cfg_th(int cfg) { return 2 * kV2Cfgs[cfg].PBW * kV2Cfgs[cfg].WP; }
 inline int cfg_bnc(int cfg) { return 32 * kV2Cfgs[cfg].CW * kV2Cfgs[cfg].WC; }
 
@@ -360,7 +373,7 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
     return g_conv_peers * n_img * ((H + th - 1) / th) * ((W + 15) / 16) * (cout / cfg_bnc(cfg));
   };
   int cfg = force_cfg;
-  if (cfg < 1 || cfg > 6 || cfg == 3 || cfg == 5 || cout % cfg_bnc(cfg) != 0) {
+  if (!cfg_valid(cfg) || cout % cfg_bnc(cfg) != 0) {
     // measured per layer of the 640x480 pyramid (scripts/bench_conv.py --all-cfgs, profiles/r02_conv_cfgs.log):
     // the 8-row x 128-channel tile wins while it yields >= 2 workgroups per CU, the 16-row one below
     if (cout % 128 == 0) cfg = wgs_of(4) >= 512 ? 4 : 1;
@@ -437,7 +450,29 @@ void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>), grid, dim3(256), lds, s, a);
 }
 
+template <int CW, int PBW, int WC, int WP, int KC>
+void launch_v3(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int lds = v3_lds_bytes(CW, PBW, WC, WP, KC);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CW, PBW, WC, WP, KC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_v3_kernel<CW, PBW, WC, WP, KC>), grid, dim3(256), lds, s, a);
+}
+
 void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_t s) {
+  if (cfg_v3(cfg) && !upcat) {
+    switch (cfg) {
+      case 11: launch_v3<2, 4, 2, 2, 32>(a, grid, s); break;
+      case 13: launch_v3<2, 4, 1, 4, 16>(a, grid, s); break;
+      case 14: launch_v3<2, 2, 2, 2, 32>(a, grid, s); break;
+      case 15: launch_v3<2, 3, 2, 2, 32>(a, grid, s); break;
+      default: launch_v3<1, 4, 1, 4, 16>(a, grid, s); break;
+    }
+    return;
+  }
   if (upcat) {
     // decoder layers (bilinear x2 + concat formed in the staging): the 16x16-pixel tiles.  (Keep every
     // variant free of scratch: one build whose 18-step loop was not unrolled indexed its offset table
@@ -472,10 +507,11 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   if (up) force_cfg = cout % 64 == 0 ? 2 : 6;
   const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr);
   ConvArgs a;
-  a.in = in; a.H = H; a.W = W; a.Cin = cin; a.wpk = wpk; a.bias = bias; a.Cout = cout; a.relu = relu;
+  // (the packed buffer holds the second kernel's layout, then the third's: pxt_conv3x3_packed_bytes)
+  a.in = in; a.H = H; a.W = W; a.Cin = cin; a.wpk = cfg_v3(cp.cfg) ? wpk + (size_t)cout * 9 * cin : wpk; a.bias = bias; a.Cout = cout; a.relu = relu;
   a.out = out; a.partial = partial;
   a.up = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
-  a.pool = cp.splits == 1 ? pool_out : nullptr;
+  a.pool = (cp.splits == 1 && !(cfg_v3(cp.cfg) && (kV2Cfgs[cp.cfg].PBW & 1))) ? pool_out : nullptr;
   std::memset(&a.head, 0, sizeof(a.head));
   if (head) {
     if (cout != 32 || cp.splits != 1 || cfg_bnc(cp.cfg) != 32) return PXT_E_ARG;
@@ -498,7 +534,10 @@ void pack_conv_weights_host(const half_t* w, int cin, int cout, half_t* packed) 
   for (int co = 0; co < cout; ++co)
     for (int t = 0; t < 9; ++t) {
       const half_t* src = w + ((size_t)co * 9 + t) * cin;
-      for (int ci = 0; ci < cin; ++ci) packed[packed_weight_index(co, t, ci, cout)] = src[ci];
+      for (int ci = 0; ci < cin; ++ci) {
+        packed[packed_weight_index(co, t, ci, cout)] = src[ci];
+        packed[(size_t)cout * 9 * cin + packed_weight_index_v3(co, t, ci, cout)] = src[ci];
+      }
     }
 }
 
@@ -550,7 +589,7 @@ extern "C" int pxt_unet_create(const void* weights_host, int64_t n_bytes, pxt_un
   {
     size_t total = 0;
     size_t offs[kNumConv];
-    for (int i = 1; i < n_conv; ++i) { offs[i] = total; total += (size_t)ctx->conv[i].cout * 9 * ctx->conv[i].cin; }
+    for (int i = 1; i < n_conv; ++i) { offs[i] = total; total += (size_t)2 * ctx->conv[i].cout * 9 * ctx->conv[i].cin; }  // both layouts
     std::vector<half_t> hp(total);
     for (int i = 1; i < n_conv; ++i)
       pack_conv_weights_host((const half_t*)(p + table[4 * i]), ctx->conv[i].cin, ctx->conv[i].cout, hp.data() + offs[i]);
@@ -835,7 +874,7 @@ extern "C" int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_
 
 extern "C" int64_t pxt_conv3x3_packed_bytes(int32_t Cin, int32_t Cout) {
   if (Cin < 32 || Cout < 32 || Cin % 32 != 0 || Cout % 32 != 0) return PXT_E_ARG;
-  return (int64_t)Cout * 9 * Cin * (int64_t)sizeof(half_t);
+  return (int64_t)2 * Cout * 9 * Cin * (int64_t)sizeof(half_t);  // the second kernel's layout, then the third's
 }
 
 extern "C" int pxt_conv3x3_pack_weights(const void* weights, int32_t Cin, int32_t Cout, void* packed, void* stream) {
@@ -843,6 +882,8 @@ extern "C" int pxt_conv3x3_pack_weights(const void* weights, int32_t Cin, int32_
   const long long n = (long long)Cout * 9 * Cin;
   hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)weights, Cin, Cout, (half_t*)packed);
+  hipLaunchKernelGGL(pack_conv_weights_v3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)weights, Cin, Cout, (half_t*)packed + n);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }
@@ -854,7 +895,7 @@ extern "C" int pxt_conv3x3_packed(const void* in, int32_t H, int32_t W, int32_t 
   if (!in || !packed || !bias || !out || H < 1 || W < 1) return PXT_E_ARG;
   if (splits > 1 && (!splitk_ws || splitk_ws_bytes < (int64_t)splits * H * W * Cout * (int64_t)sizeof(float)))
     return PXT_E_ARG;
-  if (cfg == 3 || cfg == 5 || (cfg >= 1 && cfg <= 6 && Cout % cfg_bnc(cfg) != 0)) return PXT_E_ARG;
+  if (cfg != 0 && (!cfg_valid(cfg) || Cout % cfg_bnc(cfg) != 0)) return PXT_E_ARG;
   int rc = launch_conv(Cin, Cout, (const half_t*)packed, bias, (const half_t*)in, H, W, (half_t*)out,
                        (hipStream_t)stream, relu, splits > 1 ? (float*)splitk_ws : nullptr, 1, nullptr,
                        (half_t*)pool_out, nullptr, cfg, splits > 1 ? splits : 0);

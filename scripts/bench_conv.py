@@ -9,9 +9,10 @@ from pixtrack_amd import _lib
 
 dev = torch.device("cuda:0")
 L = _lib.lib()
-CFG = {1: (16, 128), 2: (16, 64), 4: (8, 128), 6: (16, 32)}  # rows, channels per WG
+CFG = {1: (16, 128), 2: (16, 64), 4: (8, 128), 6: (16, 32),  # rows, channels per WG
+       11: (16, 128), 13: (32, 64), 14: (8, 128), 15: (12, 128), 16: (32, 32)}  # third kernel (pxt_conv_v3.h)
 # (H, W, Cin, Cout, images): the probe shape, then the 640x480 pyramid's plain layers (two images per pass)
-shapes = [(256, 256, 256, 128, 1), (256, 256, 128, 128, 1), (480, 640, 64, 64, 2), (240, 320, 64, 128, 2),
+shapes = [(256, 256, 256, 128, 1), (256, 512, 256, 128, 1), (256, 256, 128, 128, 1), (480, 640, 64, 64, 2), (240, 320, 64, 128, 2),
           (240, 320, 128, 128, 2), (120, 160, 128, 256, 2), (120, 160, 256, 256, 2), (60, 80, 256, 512, 2),
           (60, 80, 512, 512, 2), (30, 40, 512, 512, 2)]
 all_cfgs = "--all-cfgs" in sys.argv
@@ -56,7 +57,7 @@ for (H, W, Cin, Cout, n) in shapes:
     for c in cfgs:
         bench(H, W, Cin, Cout, n, c)
     if all_cfgs and H <= 60:
-        for c in (1, 2):
+        for c in (1, 2, 11):
             for sp in (2, 4, 8):
                 if sp <= Cin // 32:
                     bench(H, W, Cin, Cout, n, c, splits=sp)

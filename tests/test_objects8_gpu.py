@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 OBJECTS = parallel.load_object_configs()
 # (the cold start refines at image scale 4 first: below ~128 x 96 that level is a 16 x 12 image and no point is valid)
-SIZES = [(128, 96), (160, 120), (192, 144), (224, 168), (256, 192), (288, 216), (320, 240), (352, 264)]
+# (and the bottle, 0.49 high x 0.18 wide, needs more than 128 x 96 pixels to pin the rotation about its long axis)
+SIZES = [(352, 264), (160, 120), (192, 144), (224, 168), (256, 192), (288, 216), (320, 240), (128, 96)]
 
 
 def test_object_table_is_the_references():

@@ -161,12 +161,12 @@ def _packed_conv(device, x, w, b, relu, cfg=0, splits=1, pool=False):
     return out.float().cpu().permute(2, 0, 1), (pl.float().cpu().permute(2, 0, 1) if pool else None)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 4, 6])
+@pytest.mark.parametrize("cfg", [1, 2, 4, 6, 11, 13, 14, 15, 16])
 @pytest.mark.parametrize("H,W,Cin,Cout", [(37, 50, 64, 128), (64, 48, 96, 256), (9, 130, 32, 128)])
 def test_conv3x3_every_tile_configuration(device, cfg, H, W, Cin, Cout):
-    """All six workgroup tilings (16x16/32x16/8x16 pixels x 128/64/32 channels) give the same layer,
-    on ragged sizes (partial tiles in both directions), with and without the fused 2x2 max-pool and
-    with split-K."""
+    """Every workgroup tiling of the second kernel (1-6) and of the third (11-16: shared pixel fragments, filter
+    fragments through LDS, 16- or 32-channel chunks) gives the same layer, on ragged sizes (partial tiles in both
+    directions), with and without the fused 2x2 max-pool and with split-K."""
     g = torch.Generator().manual_seed(cfg * 7919 + H * 1000 + W + Cin)
     x = torch.randn(Cin, H, W, generator=g).half()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).half()
@@ -177,7 +177,8 @@ def test_conv3x3_every_tile_configuration(device, cfg, H, W, Cin, Cout):
     assert torch.isfinite(got).all() and (got - ref).abs().max().item() < tol
     # the pooled copy is the max-pool of the fp16 output itself: exact
     want_pool = F.max_pool2d(got[None], 2)[0]
-    assert torch.isfinite(pooled).all() and torch.equal(pooled, want_pool)
+    if cfg != 15:  # (12-row tiles hold an odd number of row blocks per wave: no fused pool, the pyramid pools separately)
+        assert torch.isfinite(pooled).all() and torch.equal(pooled, want_pool)
     got2, _ = _packed_conv(device, x, w, b, 1, cfg=cfg, splits=min(3, Cin // 32))
     assert (got2 - ref).abs().max().item() < tol
     # without ReLU / without pool: same numbers as the pooled run where positive
