@@ -167,3 +167,59 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
     cost = float(np.mean([c[-1] for c in log.costs if len(c)])) if log.costs else float("nan")
     return dict(success=ret["success"], R=ret.get("R"), t=ret.get("t"), cost=cost, mask=mask, iters=log.num_iters,
                 n_points=len(ids), log=log)
+
+
+def nearest_reference(model3d, covis, curr_ref: int, R_qry: np.ndarray, n_shared: int = 50) -> int:
+    """update_reference_ids (pixloc_tracker_r9.py:120-143): the current reference and its covisible images
+    (> 50 shared points) ranked by the geodesic distance of their rotation to the current pose; K = 1."""
+    def gdist(Ra, Rb):
+        c = (np.trace(Ra @ Rb.T) - 1.0) / 2.0
+        return float(np.arccos(np.clip(c, -1.0, 1.0)))
+
+    cand = {curr_ref: gdist(R_qry, model3d.dbs[curr_ref].qvec2rotmat())}
+    for k, v in covis[curr_ref].items():
+        if v > n_shared:
+            cand[k] = gdist(R_qry, model3d.dbs[k].qvec2rotmat())
+    return sorted(cand, key=lambda r: cand[r])[0]
+
+
+def track_sequence(assets: Dict, frames, spp: int = 8, covis=None, lm_conf: Optional[LO.LMConf] = None,
+                   keep_masks: bool = True):
+    """PixLocPoseTrackerR9.refine over CONSECUTIVE frames (pixloc_tracker_r9.py:216-275): what is carried from one
+    frame to the next is the pose (updated only by an accepted frame, :258-265), the success flag (a failed frame
+    makes the next one run UNMASKED at the scales last set, :218-225), the cost threshold (1.1 x the first frame's
+    cost, frozen, :251-256) and the reference id (:120-143; here it must not change - the features of a frame are
+    extracted for the reference ids in force BEFORE the update, :160-203, a case the frame fixtures leave out).
+    ``frames``: float32 HWC 0..255.  Returns one record per frame."""
+    model3d = assets["model3d"]
+    ref_id = model3d.name2id[assets["upright_ref_img"]]
+    im = model3d.dbs[ref_id]
+    R, t = im.qvec2rotmat(), np.asarray(im.tvec, np.float64)  # relocalize(): the upright reference pose (:95-106)
+    cold, success, thr, multiscale = True, True, None, (1,)
+    out = []
+    for i, frame in enumerate(frames):
+        use_mask = False
+        if cold:
+            multiscale, cold = (4, 1), False
+        elif success:
+            multiscale, use_mask = (1,), True
+        if i > 0 and covis is not None:
+            assert nearest_reference(model3d, covis, ref_id, np.asarray(R)) == ref_id, "reference switch: not covered"
+        keep = {}
+        res = track_frame(assets, R, t, np.asarray(frame, np.float32), ref_id, multiscale=multiscale, use_mask=use_mask,
+                          lm_conf=lm_conf, spp=spp, keep=keep)
+        cost = res["cost"]
+        if thr is None:
+            thr = cost + 0.1 * cost
+        ok = bool(res["success"] and cost <= thr)
+        rec = dict(frame=i, multiscale=tuple(multiscale), masked=use_mask, lm_success=bool(res["success"]), success=ok,
+                   cost=cost, cost_threshold=thr, R_start=np.asarray(R, np.float64).copy(),
+                   t_start=np.asarray(t, np.float64).copy(), iters=list(res["iters"]), n_points=res["n_points"],
+                   R=res["R"].numpy() if res["R"] is not None else None,
+                   t=res["t"].numpy() if res["t"] is not None else None,
+                   mask=res["mask"] if keep_masks else None, depth_rgba=keep.get("depth_rgba"))
+        out.append(rec)
+        if ok:
+            R, t = res["R"].numpy().astype(np.float64), res["t"].numpy().astype(np.float64)
+        success = ok
+    return out

@@ -123,18 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
     a_src[k] = (unsigned)(ky * (Cout >> 5) * 512 + rem * 8);
   }
   half8 r_a[KA];
-  auto a_issue = [&](int gg) {  // gg clamped by the caller
-    const half_t* src = wbase + (size_t)gg * a_group;
-#pragma unroll
-    for (int k = 0; k < KA; ++k) r_a[k] = *(const half8*)(src + a_src[k]);
+  const half_t* a_next = wbase;  // group whose fragments the next a_issue fetches
+  auto a_issue_piece = [&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    r_a[k] = *(const half8*)(a_next + a_src[k]);
   };
-  auto a_write = [&](int buf) {
-    const int t_ = opaque(tid);
-#pragma unroll
-    for (int k = 0; k < KA; ++k) {
-      const int i = t_ + 256 * k;
-      if (i < kAElems) *(half8*)(s_a + buf * kABuf + i * 16) = r_a[k];
-    }
+  auto a_write_piece = [&](auto k_c, int buf) {
+    constexpr int k = decltype(k_c)::value;
+    const int i = opaque(tid) + 256 * k;
+    if (i < kAElems) *(half8*)(s_a + buf * kABuf + i * 16) = r_a[k];
   };
 
   // ---- halo staging (as in the second kernel: unconditional bounds-checked buffer loads) ----------
@@ -150,70 +147,131 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   }
   const __amdgpu_buffer_rsrc_t in_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((size_t)H * W * Cin * 2), 0x00020000);
-  auto halo_issue = [&](int c0) {
-#pragma unroll
-    for (int k = 0; k < KH; ++k)
-      r_in[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(goff[k] + (unsigned)(c0 * 2)), 0, 0));
+  auto halo_issue_piece = [&](auto k_c, int c0) {
+    constexpr int k = decltype(k_c)::value;
+    r_in[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(goff[k] + (unsigned)(c0 * 2)), 0, 0));
   };
-  auto halo_write = [&](int buf) {
-    const int t_ = opaque(tid);
-#pragma unroll
-    for (int k = 0; k < KH; ++k) {
-      const int i = t_ + 256 * k;
-      const int pix = i / G::kNP, seg = i % G::kNP;
-      const int hy = pix / kV2Cols, hx = pix % kV2Cols;
-      if (i < kElems) *(half8*)(s_halo + buf * kBuf + hy * G::kRow + hx * G::kPix + ((seg ^ G::swz(hx)) << 4)) = r_in[k];
-    }
+  auto halo_write_piece = [&](auto k_c, int buf) {
+    constexpr int k = decltype(k_c)::value;
+    const int i = opaque(tid) + 256 * k;
+    const int pix = i / G::kNP, seg = i % G::kNP;
+    const int hy = pix / kV2Cols, hx = pix % kV2Cols;
+    if (i < kElems) *(half8*)(s_halo + buf * kBuf + hy * G::kRow + hx * G::kPix + ((seg ^ G::swz(hx)) << 4)) = r_in[k];
   };
 
+  // ---- fragment reads ------------------------------------------------------------------------
+  // pixel fragment j (halo rows lrow + j) of a group with horizontal tap kx and k-step s
+  auto b_ptr = [&](int hb, int s, int kx) {
+    const int col = lcol + kx;
+    return s_halo + hb * kBuf + lrow * G::kRow + col * G::kPix + ((((KC == 32 ? 2 * s : 0) + khalf) ^ G::swz(col)) << 4);
+  };
+  auto a_ptr = [&](int ab) { return s_a + ab * kABuf + (CW * wc * 64 + lane) * 16; };
+
+  // Software pipeline over the (k-step, kx) groups.  A group's 3 * PBW * CW MFMAs run as three phases (ky = 0, 1, 2);
+  // its operands arrive in two halves: the HEAD (filter fragments of ky = 0, pixel fragments 0 .. PBW-1) is read during
+  // the PREVIOUS group's last phase, the TAIL (ky = 1, 2; pixel fragments PBW, PBW + 1) during its own first phase -
+  // into the registers the finished phases free, so 12 fragments stay live.  The workgroup barrier sits between
+  // phases 1 and 2: every wave wrote the next group's filter fragments a phase earlier, nobody waits there, and the
+  // reads that follow are covered by phase 2.  Staging instructions (one per MFMA) ride between the MFMAs of phases
+  // 0 and 1.  The barrier is the raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also drain the vector
+  // loads issued a phase ago (cdna_hip_programming.md "Pipelining across barriers").
+  half8 hA[CW], hB[PBW];
   if (n_groups > 0) {  // first chunk and first group: staged synchronously
-    halo_issue(ch_begin * KC);
-    a_issue(0);
-    halo_write(0);
-    a_write(0);
+    static_for<0, KH>([&](auto k) { halo_issue_piece(k, ch_begin * KC); });
+    static_for<0, KA>([&](auto k) { a_issue_piece(k); });
+    static_for<0, KH>([&](auto k) { halo_write_piece(k, 0); });
+    static_for<0, KA>([&](auto k) { a_write_piece(k, 0); });
+    a_next = wbase + (size_t)min(1, n_groups - 1) * a_group;
+    static_for<0, KA>([&](auto k) { a_issue_piece(k); });
+    __syncthreads();
+    const char* bp = b_ptr(0, 0, 0);
+    const char* ap = a_ptr(0);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) hA[c] = *(const half8*)(ap + c * 1024);
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) hB[p] = *(const half8*)(bp + p * G::kRow);
   }
   PXT_STAMP(1);
 
+  constexpr int NM = PBW * CW;                       // MFMAs per phase
+  constexpr int TO = 2 * KA + KH;                    // staging instructions of a group (at most)
+  constexpr int OPM = (TO + 2 * NM - 1) / (2 * NM);  // ... per MFMA of phases 0 and 1
   int gg = 0;  // running group index inside this workgroup's K range
   for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const bool more = ch + 1 < ch_end;
     const int hbuf = (ch - ch_begin) & 1;
+    const int c_next = min(ch + 1, ch_end - 1) * KC;  // (the last chunk re-stages itself into the idle buffer: no branch)
     static_for<0, NG>([&](auto g_c) {
       constexpr int g = decltype(g_c)::value;
       constexpr int s = KC == 32 ? g / 3 : 0, kx = g % 3;
-      __syncthreads();  // this group's filter fragments (and, for g = 0, this chunk's halo) are complete
+      constexpr int gn = (g + 1) % NG;
+      constexpr int sn = KC == 32 ? gn / 3 : 0, kxn = gn % 3;
       const int abuf = gg & 1;
-      a_issue(min(gg + 1, n_groups - 1));
-      if (more) {
-        if constexpr (g == 0) halo_issue((ch + 1) * KC);
-      }
-      // fragments of this group: PBW + 2 pixel fragments shared by the three vertical taps, 3 * CW filter fragments
-      half8 bq[PBW + 2], aq[3][CW];
+      // tail of this group
+      half8 tA[2][CW], tB[2];
       {
-        const int col = lcol + kx;
-        const char* bp = s_halo + hbuf * kBuf + lrow * G::kRow + col * G::kPix +
-                         ((((KC == 32 ? 2 * s : 0) + khalf) ^ G::swz(col)) << 4);
+        const char* bp = b_ptr(hbuf, s, kx);
+        const char* ap = a_ptr(abuf);
 #pragma unroll
-        for (int j = 0; j < PBW + 2; ++j) bq[j] = *(const half8*)(bp + j * G::kRow);
-        const char* ap = s_a + abuf * kABuf + (CW * wc * 64 + lane) * 16;
+        for (int ky = 1; ky < 3; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int c = 0; c < CW; ++c) aq[ky][c] = *(const half8*)(ap + (ky * NCB + c) * 1024);
+          for (int c = 0; c < CW; ++c) tA[ky - 1][c] = *(const half8*)(ap + (ky * NCB + c) * 1024);
+        tB[0] = *(const half8*)(bp + PBW * G::kRow);
+        tB[1] = *(const half8*)(bp + (PBW + 1) * G::kRow);
       }
-      __builtin_amdgcn_sched_barrier(0);  // the staging loads above stay above the MFMAs (hipcc sinks them otherwise)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int p = 0; p < PBW; ++p)
-#pragma unroll
-          for (int c = 0; c < CW; ++c)
-            acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[ky][c], bq[p + ky], acc[c][p], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      a_write(abuf ^ 1);
-      if (more) {
-        if constexpr (g == NG - 2) halo_write(hbuf ^ 1);
+      // staging instruction number `op` of this group: write the next group's filter fragments (fetched a group ago),
+      // fetch the ones after that, and move the next chunk's halo (fetch in the first group, write in the last but one)
+      auto stage_op = [&](auto op_c) {
+        constexpr int op = decltype(op_c)::value;
+        if constexpr (op < KA) {
+          a_write_piece(std::integral_constant<int, op>{}, abuf ^ 1);
+        } else if constexpr (op < 2 * KA) {
+          if constexpr (op == KA) a_next = wbase + (size_t)min(gg + 2, n_groups - 1) * a_group;
+          a_issue_piece(std::integral_constant<int, op - KA>{});
+        } else if constexpr (op < TO) {
+          if constexpr (g == 0) halo_issue_piece(std::integral_constant<int, op - 2 * KA>{}, c_next);
+          if constexpr (g == NG - 2) halo_write_piece(std::integral_constant<int, op - 2 * KA>{}, hbuf ^ 1);
+        }
+      };
+      // phases 0 and 1, one MFMA + its staging instructions at a time
+      static_for<0, 2 * NM>([&](auto m_c) {
+        constexpr int m = decltype(m_c)::value;
+        constexpr int ky = m / NM, p = (m % NM) / CW, c = m % CW;
+        const half8 av = ky == 0 ? hA[c] : tA[0][c];
+        const half8 bv = (p + ky < PBW) ? hB[(p + ky < PBW) ? p + ky : 0] : tB[0];
+        acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[c][p], 0, 0, 0);
+        static_for<m * OPM, (m + 1) * OPM>([&](auto op_c) { stage_op(op_c); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // every wave's staging writes are complete and visible behind this barrier
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // head of the next group (the next chunk's halo buffer after a chunk's last group)
+      half8 nA[CW], nB[PBW];
+      {
+        const char* bp = b_ptr(g == NG - 1 ? hbuf ^ 1 : hbuf, sn, kxn);
+        const char* ap = a_ptr(abuf ^ 1);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) nA[c] = *(const half8*)(ap + c * 1024);
+#pragma unroll
+        for (int p = 0; p < PBW; ++p) nB[p] = *(const half8*)(bp + p * G::kRow);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 2
+#pragma unroll
+      for (int p = 0; p < PBW; ++p)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          const half8 bv = (p + 2 < PBW) ? hB[(p + 2 < PBW) ? p + 2 : 0] : tB[(p + 2 < PBW) ? 0 : p + 2 - PBW];
+          acc[c][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tA[1][c], bv, acc[c][p], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) hA[c] = nA[c];
+#pragma unroll
+      for (int p = 0; p < PBW; ++p) hB[p] = nB[p];
       ++gg;
     });
     if (ch - ch_begin < 10) PXT_STAMP(4 + ch - ch_begin);

@@ -366,7 +366,7 @@ int choose_splits(int wgs, int n_chunks, bool upcat) {
 }
 
 ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split, int force_cfg = 0,
-                   int force_splits = 0, bool upcat = false) {
+                   int force_splits = 0, bool upcat = false, bool wants_pool = false) {
   ConvPlan P;
   auto wgs_of = [&](int cfg) {
     const int th = cfg_th(cfg);
@@ -376,7 +376,15 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   if (!cfg_valid(cfg) || cout % cfg_bnc(cfg) != 0) {
     // measured per layer of the 640x480 pyramid (scripts/bench_conv.py --all-cfgs, profiles/r02_conv_cfgs.log):
     // the 8-row x 128-channel tile wins while it yields >= 2 workgroups per CU, the 16-row one below
-    if (cout % 128 == 0) cfg = wgs_of(4) >= 512 ? 4 : 1;
+    if (cout % 128 == 0) {
+      cfg = wgs_of(4) >= 512 ? 4 : 1;
+      // round 3 (profiles/r03_conv_cfgs.log): the third kernel's 12-row tile wins wherever it brings the layer
+      // under ONE resident round of workgroups (two per CU) without starving it - the 120x160 and 60x80 layers:
+      // 777 / 910 / 713 / 813 TFLOP/s against 705 / 800 / 686 / 808.  It has no fused max-pool (odd block count
+      // per wave), so a layer whose output is pooled keeps the 8- / 16-row tile.
+      const int w15 = wgs_of(15);
+      if (!wants_pool && w15 >= 192 && w15 <= 512) cfg = 15;
+    }
     else if (cout % 64 == 0) cfg = 2;
     else cfg = 6;
   }
@@ -505,7 +513,7 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
   if (up) force_cfg = cout % 64 == 0 ? 2 : 6;
-  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr);
+  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr, pool_out != nullptr);
   ConvArgs a;
   // (the packed buffer holds the second kernel's layout, then the third's: pxt_conv3x3_packed_bytes)
   a.in = in; a.H = H; a.W = W; a.Cin = cin; a.wpk = cfg_v3(cp.cfg) ? wpk + (size_t)cout * 9 * cin : wpk; a.bias = bias; a.Cout = cout; a.relu = relu;

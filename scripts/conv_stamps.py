@@ -25,11 +25,12 @@ fn = L.pxt_debug_read_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 st = np.zeros((8192, 16), np.uint64)
 assert fn(st.ctypes.data, st.nbytes) == 0
-rows = {1: 16, 2: 16, 4: 8, 6: 16}[cfg]; ch = {1: 128, 2: 64, 4: 128, 6: 32}[cfg]
+rows = {1: 16, 2: 16, 4: 8, 6: 16, 11: 16, 13: 32, 14: 8, 15: 12, 16: 32}[cfg]
+ch = {1: 128, 2: 64, 4: 128, 6: 32, 11: 128, 13: 64, 14: 128, 15: 128, 16: 32}[cfg]
 n = ((H + rows - 1) // rows) * ((W + 15) // 16) * (Cout // ch)
 st = st[:min(n, 8192)].astype(np.int64)
 t0 = st[:, 0].min()
-nch = Cin // 32
+nch = Cin // (16 if cfg in (13, 16) else 32)
 print(f"{n} workgroups; stamps in s_memtime ticks (shader clock): kernel span {st[:, 3].max() - t0}")
 rel = st - t0
 def q(v): return "min %7d  med %7d  max %7d" % (v.min(), np.median(v), v.max())

