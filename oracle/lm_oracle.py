@@ -386,8 +386,11 @@ def refine_pose_using_features(
     mask: Optional[torch.Tensor] = None,
     log: Optional[LMLog] = None,
     dtype=torch.float32,
+    levels: Optional[Sequence[int]] = None,
 ):
     """pixloc BaseRefiner.refine_pose_using_features.
+    ``levels`` (not in pixloc): keep only these pyramid levels, still coarse -> fine - the builder-defined stress
+    plan of BASELINE configs[4] ({image scale 4: [2], scale 1: [2, 1, 0]}) runs through the same loop.
 
     features_query[l]: (C_l+1) x h x w with the confidence as LAST channel
     (dense_feature_extraction's cat); features_ref[l]: N x (C_l+1).
@@ -398,6 +401,8 @@ def refine_pose_using_features(
     R, t = R_init.to(dtype), t_init.to(dtype)
     p3d = p3d.to(dtype)
     for level in reversed(range(L)):
+        if levels is not None and level not in levels:
+            continue
         fr = features_ref[level].to(dtype)
         F_ref, W_ref = fr[:, :-1], fr[:, -1:]
         F_ref = l2_normalize(F_ref, dim=1)

@@ -287,20 +287,24 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
       const int i = t_ + 256 * k;
       const int pix = i >> 2, seg = i & 3;
       const int hy = pix / kV2Cols, hx = pix % kV2Cols;
-      const unsigned f = up_src[UPCAT ? k : 0];
+      const unsigned f = (unsigned)opaque((int)up_src[UPCAT ? k : 0]);  // (not hoisted: the weights are re-derived per chunk)
       const char* src = patch + (f >> 8);
       const int dx = (f & 1u) ? 64 : 0, dy = (f & 2u) ? PW * 64 : 0;
       const float ax = (f & 4u) ? 0.25f : (f & 8u) ? 0.75f : 0.f;
       const float ay = (f & 16u) ? 0.25f : (f & 32u) ? 0.75f : 0.f;
       const half8 p00 = *(const half8*)(src), p01 = *(const half8*)(src + dx);
       const half8 p10 = *(const half8*)(src + dy), p11 = *(const half8*)(src + dy + dx);
-      half8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float top = (float)p00[j] * (1.f - ax) + (float)p01[j] * ax;
-        const float bot = (float)p10[j] * (1.f - ax) + (float)p11[j] * ax;
-        v[j] = (f & 64u) ? (half_t)(top * (1.f - ay) + bot * ay) : (half_t)0.f;
-      }
+      // the four bilinear weights are products of {0, 1/4, 3/4, 1}: exact in fp16.  Packed-fp16 multiply-adds (one
+      // v_pk_mul + three v_pk_fma per channel pair): the fp32 version of this blend (4 conversions in, 6 FMAs, one
+      // conversion out per channel = ~90 VALU instructions per piece) cost the decoder layers as much issue time as
+      // their MFMAs (round-3 timeline: 86 us per 640x480 image for the last layer's 22.6 GFLOP).
+      const bool ok_ = (f & 64u) != 0;
+      const half_t wa = (half_t)(ok_ ? (1.f - ax) * (1.f - ay) : 0.f), wb = (half_t)(ok_ ? ax * (1.f - ay) : 0.f);
+      const half_t wc = (half_t)(ok_ ? (1.f - ax) * ay : 0.f), wd = (half_t)(ok_ ? ax * ay : 0.f);
+      half8 v = p00 * wa;
+      v = p01 * wb + v;
+      v = p10 * wc + v;
+      v = p11 * wd + v;
       if (i < kElems)
         *(half8*)(smem + buf * kBuf + hy * kV2RowBytes + hx * 64 + ((seg ^ ((hx >> 2) & 3)) << 4)) = v;
       __builtin_amdgcn_sched_barrier(0);  // one piece's four taps live at a time (register budget)

@@ -55,11 +55,14 @@ __device__ inline unsigned pk_max(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2v, a), __builtin_bit_cast(half2v, b)));
 }
 
-constexpr int v3_lds_bytes(int CW, int PBW, int WC, int WP, int KC) {
-  return 2 * (2 * PBW * WP + 2) * (20 * KC * 2) + 2 * 3 * CW * WC * 1024 + 32 * CW * WC * 4;
+constexpr int v3_lds_bytes(int CW, int PBW, int WC, int WP, int KC, bool upcat = false) {
+  return 2 * (2 * PBW * WP + 2) * (20 * KC * 2) + 2 * 3 * CW * WC * 1024 + 32 * CW * WC * 4 +
+         (upcat ? (PBW * WP + 2) * 10 * KC * 2 : 0);
 }
 
-template <int CW, int PBW, int WC, int WP, int KC>
+// UPCAT (decoder layers): the conv input is concat(bilinear x2 upsample of `prev`, skip); channels below Cp are formed
+// in the staging from the low-resolution patch under the tile's halo, exactly as in the second kernel.
+template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   static_assert(WC * WP == 4, "four waves per workgroup");
   static_assert(KC == 16 || KC == 32, "chunk of 16 or 32 input channels");
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   char* const s_halo = smem;
   char* const s_a = smem + 2 * kBuf;
   float* const s_bias = (float*)(smem + 2 * kBuf + 2 * kABuf);
+  char* const patch = smem + 2 * kBuf + 2 * kABuf + BNC * 4;  // UPCAT: the low-resolution patch of one chunk
 
   PXT_STAMP(0);
   const int tid = threadIdx.x;
@@ -90,7 +94,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   const int n_img = gridDim.x / tiles_per;
   const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * 16;
   const int co0 = blockIdx.y * BNC;
-  const half_t* in = a.in + (size_t)img * H * W * Cin;
+  const int Cs = UPCAT ? Cin - a.up.Cp : Cin;  // channels of the tensor behind `in` (UPCAT: the skip tensor)
+  const int in_w = UPCAT ? a.up.Ws : W;
+  const int cp0 = UPCAT ? a.up.Cp : 0;         // channels [0, cp0) of the conv input come from `prev`
+  const half_t* in = a.in + (size_t)img * (UPCAT ? a.up.Hs : H) * in_w * Cs;
+  const half_t* prev = UPCAT ? a.up.prev + (size_t)img * a.up.Hp * a.up.Wp * a.up.Cp : nullptr;
 
   if (tid < BNC) s_bias[tid] = a.bias[co0 + tid];
 
@@ -143,13 +151,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
     const int pix = i / G::kNP, seg = i % G::kNP;
     const int gy = ty0 + pix / kV2Cols - 1, gx = tx0 + pix % kV2Cols - 1;
     const bool ok = i < kElems && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    goff[k] = ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)(seg * 8)) * 2u : 0x80000000u;
+    goff[k] = ok ? ((unsigned)(gy * in_w + gx) * (unsigned)Cs + (unsigned)(seg * 8)) * 2u : 0x80000000u;
   }
-  const __amdgpu_buffer_rsrc_t in_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((size_t)H * W * Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)in, 0, (int)((size_t)(UPCAT ? a.up.Hs : H) * in_w * Cs * 2), 0x00020000);
   auto halo_issue_piece = [&](auto k_c, int c0) {
     constexpr int k = decltype(k_c)::value;
-    r_in[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(goff[k] + (unsigned)(c0 * 2)), 0, 0));
+    r_in[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(goff[k] + (unsigned)((c0 - cp0) * 2)), 0, 0));
   };
   auto halo_write_piece = [&](auto k_c, int buf) {
     constexpr int k = decltype(k_c)::value;
@@ -157,6 +165,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
     const int pix = i / G::kNP, seg = i % G::kNP;
     const int hy = pix / kV2Cols, hx = pix % kV2Cols;
     if (i < kElems) *(half8*)(s_halo + buf * kBuf + hy * G::kRow + hx * G::kPix + ((seg ^ G::swz(hx)) << 4)) = r_in[k];
+  };
+
+  // ---- UPCAT, channels below Cp: the low-resolution patch under this tile's halo ((TH/2 + 2) x 10 pixels of `prev`,
+  // one chunk) is copied raw into LDS, then every thread forms its halo pieces from it with the bilinear x2 weights
+  // (exactly 0, 1/4, 3/4; align_corners = False): each low-resolution pixel is fetched once.
+  constexpr int PH = TH / 2 + 2, PW = 10;
+  constexpr int kPatchElems = PH * PW * G::kNP, KP = (kPatchElems + 255) / 256;
+  static_assert(!UPCAT || KP <= KH, "the patch pieces reuse the halo staging registers");
+  unsigned poff[UPCAT ? KP : 1], up_src[UPCAT ? KH : 1];
+  if constexpr (UPCAT) {
+    const int py0 = (ty0 >> 1) - 1, px0 = (tx0 >> 1) - 1;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      const int i = min(tid + 256 * kp, kPatchElems - 1);
+      const int pp = i / G::kNP, seg = i % G::kNP;
+      const int sy = min(max(py0 + pp / PW, 0), a.up.Hp - 1), sx = min(max(px0 + pp % PW, 0), a.up.Wp - 1);
+      poff[kp] = (unsigned)(sy * a.up.Wp + sx) * (unsigned)a.up.Cp + (unsigned)(seg * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int i = tid + 256 * k;
+      const int pix = i / G::kNP, seg = i % G::kNP;
+      const int gy = ty0 + pix / kV2Cols - 1, gx = tx0 + pix % kV2Cols - 1;
+      const bool ok = i < kElems && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float sy = fmaxf(((float)gy + 0.5f) * 0.5f - 0.5f, 0.f);
+      const float sx = fmaxf(((float)gx + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int y0 = min((int)sy, a.up.Hp - 1), x0 = min((int)sx, a.up.Wp - 1);
+      const int y1 = min(y0 + 1, a.up.Hp - 1), x1 = min(x0 + 1, a.up.Wp - 1);
+      const float ay = sy - (float)y0, ax = sx - (float)x0;  // exactly 0, 0.25 or 0.75 inside the image
+      const int pidx = ok ? (y0 - py0) * PW + (x0 - px0) : 0;
+      up_src[k] = ((unsigned)(pidx * G::kPix + seg * 16) << 8) | (ok ? 64u : 0u) | (x1 != x0 ? 1u : 0u) | (y1 != y0 ? 2u : 0u) |
+                  (ax == 0.25f ? 4u : ax == 0.75f ? 8u : 0u) | (ay == 0.25f ? 16u : ay == 0.75f ? 32u : 0u);
+    }
+  }
+  auto patch_issue_piece = [&](auto k_c, int c0) {
+    constexpr int k = decltype(k_c)::value;
+    if constexpr (UPCAT && k < KP) r_in[k] = *(const half8*)(prev + (poff[k] + (unsigned)c0));
+  };
+  auto patch_write_piece = [&](auto k_c) {
+    constexpr int k = decltype(k_c)::value;
+    if constexpr (UPCAT && k < KP) {
+      const int i = opaque(tid) + 256 * k;
+      if (i < kPatchElems) *(half8*)(patch + i * 16) = r_in[k];
+    }
+  };
+  auto patch_interp_piece = [&](auto k_c, int buf) {
+    constexpr int k = decltype(k_c)::value;
+    if constexpr (UPCAT) {
+      const int i = opaque(tid) + 256 * k;
+      const int pix = i / G::kNP, seg = i % G::kNP;
+      const int hy = pix / kV2Cols, hx = pix % kV2Cols;
+      const unsigned f = (unsigned)opaque((int)up_src[k]);  // (not hoisted: the weights are re-derived per chunk)
+      const char* src = patch + (f >> 8);
+      const int dx = (f & 1u) ? G::kPix : 0, dy = (f & 2u) ? PW * G::kPix : 0;
+      const float ax = (f & 4u) ? 0.25f : (f & 8u) ? 0.75f : 0.f;
+      const float ay = (f & 16u) ? 0.25f : (f & 32u) ? 0.75f : 0.f;
+      const half8 p00 = *(const half8*)(src), p01 = *(const half8*)(src + dx);
+      const half8 p10 = *(const half8*)(src + dy), p11 = *(const half8*)(src + dy + dx);
+      // the four bilinear weights are products of {0, 1/4, 3/4, 1}: exact in fp16.  Packed-fp16 multiply-adds (one
+      // v_pk_mul + three v_pk_fma per channel pair): the fp32 version of this blend (4 conversions in, 6 FMAs, one
+      // conversion out per channel = ~90 VALU instructions per piece) cost the decoder layers as much issue time as
+      // their MFMAs (round-3 timeline: 86 us per 640x480 image for the last layer's 22.6 GFLOP).
+      const bool ok_ = (f & 64u) != 0;
+      const half_t wa = (half_t)(ok_ ? (1.f - ax) * (1.f - ay) : 0.f), wb = (half_t)(ok_ ? ax * (1.f - ay) : 0.f);
+      const half_t wc = (half_t)(ok_ ? (1.f - ax) * ay : 0.f), wd = (half_t)(ok_ ? ax * ay : 0.f);
+      half8 v = p00 * wa;
+      v = p01 * wb + v;
+      v = p10 * wc + v;
+      v = p11 * wd + v;
+      if (i < kElems) *(half8*)(s_halo + buf * kBuf + hy * G::kRow + hx * G::kPix + ((seg ^ G::swz(hx)) << 4)) = v;
+    }
   };
 
   // ---- fragment reads ------------------------------------------------------------------------
@@ -177,9 +256,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   // loads issued a phase ago (cdna_hip_programming.md "Pipelining across barriers").
   half8 hA[CW], hB[PBW];
   if (n_groups > 0) {  // first chunk and first group: staged synchronously
-    static_for<0, KH>([&](auto k) { halo_issue_piece(k, ch_begin * KC); });
-    static_for<0, KA>([&](auto k) { a_issue_piece(k); });
-    static_for<0, KH>([&](auto k) { halo_write_piece(k, 0); });
+    if (UPCAT && ch_begin * KC < cp0) {
+      static_for<0, KP>([&](auto k) { patch_issue_piece(k, ch_begin * KC); });
+      static_for<0, KA>([&](auto k) { a_issue_piece(k); });
+      static_for<0, KP>([&](auto k) { patch_write_piece(k); });
+      __syncthreads();
+      static_for<0, KH>([&](auto k) { patch_interp_piece(k, 0); });
+    } else {
+      static_for<0, KH>([&](auto k) { halo_issue_piece(k, ch_begin * KC); });
+      static_for<0, KA>([&](auto k) { a_issue_piece(k); });
+      static_for<0, KH>([&](auto k) { halo_write_piece(k, 0); });
+    }
     static_for<0, KA>([&](auto k) { a_write_piece(k, 0); });
     a_next = wbase + (size_t)min(1, n_groups - 1) * a_group;
     static_for<0, KA>([&](auto k) { a_issue_piece(k); });
@@ -229,8 +316,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
           if constexpr (op == KA) a_next = wbase + (size_t)min(gg + 2, n_groups - 1) * a_group;
           a_issue_piece(std::integral_constant<int, op - KA>{});
         } else if constexpr (op < TO) {
-          if constexpr (g == 0) halo_issue_piece(std::integral_constant<int, op - 2 * KA>{}, c_next);
-          if constexpr (g == NG - 2) halo_write_piece(std::integral_constant<int, op - 2 * KA>{}, hbuf ^ 1);
+          constexpr int k = op - 2 * KA;
+          if (UPCAT && c_next < cp0) {  // (workgroup-uniform) the next chunk is upsampled from `prev`
+            if constexpr (g == 0) patch_issue_piece(std::integral_constant<int, k>{}, c_next);
+            if constexpr (g == 1) patch_write_piece(std::integral_constant<int, k>{});  // visible behind group 1's barrier
+            if constexpr (g >= 2 && (k % (NG - 2)) == g - 2) patch_interp_piece(std::integral_constant<int, k>{}, hbuf ^ 1);
+          } else {
+            if constexpr (g == 0) halo_issue_piece(std::integral_constant<int, k>{}, c_next);
+            if constexpr (g == NG - 2) halo_write_piece(std::integral_constant<int, k>{}, hbuf ^ 1);
+          }
         }
       };
       // phases 0 and 1, one MFMA + its staging instructions at a time
@@ -299,6 +393,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
         for (int g4 = 0; g4 < 4; ++g4)
           *(float4*)(pd + 32 * c + 8 * g4 + 4 * khalf) =
               make_float4(acc[c][p][4 * g4 + 0], acc[c][p][4 * g4 + 1], acc[c][p][4 * g4 + 2], acc[c][p][4 * g4 + 3]);
+    }
+    PXT_STAMP(3);
+    return;
+  }
+  if (CW == 1 && a.head.enabled) {  // workgroup-uniform: the fine 1x1 head fused into the last decoder layer (FusedHead)
+#pragma unroll
+    for (int p = 0; p < PBW; ++p) {
+      const int gy = row0 + p + (r31 >> 4) * PBW, gx = tx0 + lcol;
+      const bool inside = gy < H && gx < W;
+      // bias + ReLU + fp16: the 16 accumulator registers ARE the two B fragments of the head's GEMM (its weight
+      // columns were permuted to this register order when the context was created)
+      half8 hb[2];
+      float cdot = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int chn = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const half_t hv = (half_t)fmaxf(acc[0][p][r] + a.bias[chn], 0.f);
+        hb[r >> 3][r & 7] = hv;
+        cdot += (float)hv * a.head.conf_w[chn];
+      }
+      f32x16 hd = {0};
+      hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.head.wfrag[lane], hb[0], hd, 0, 0, 0);
+      hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.head.wfrag[64 + lane], hb[1], hd, 0, 0, 0);
+      float ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        hd[r] += a.head.bias[(r & 3) + 8 * (r >> 2) + 4 * khalf];
+        ss += hd[r] * hd[r];
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      cdot += __shfl_xor(cdot, 32, 64);
+      const float inv = a.head.normalize[img] ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+      if (inside) {
+        float* o = a.head.out[img] + ((size_t)gy * W + gx) * a.head.cstride;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *(float4*)(o + 8 * g4 + 4 * khalf) = make_float4(hd[4 * g4] * inv, hd[4 * g4 + 1] * inv, hd[4 * g4 + 2] * inv, hd[4 * g4 + 3] * inv);
+        if (khalf == 0) *(float4*)(o + 32) = make_float4(1.f / (1.f + expf(cdot + a.head.bias[32])), 0.f, 0.f, 0.f);
+      }
     }
     PXT_STAMP(3);
     return;

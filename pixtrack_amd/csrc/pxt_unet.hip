@@ -17,6 +17,8 @@
 #include "pxt_common.h"
 
 #include <algorithm>
+#include <array>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -325,7 +327,7 @@ namespace {
 // Tile configurations of conv3x3_v2_kernel<CW, PBW, WC, WP>: a workgroup (4 waves, WC x WP) covers
 // TH = 2*PBW*WP rows x 16 columns of pixels and BNC = 32*CW*WC output channels.
 struct V2Cfg { int CW, PBW, WC, WP, KC; };
-constexpr int kNumCfgs = 17;
+constexpr int kNumCfgs = 18;
 constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
                                      {2, 4, 2, 2, 32},   // 1: 16x16 px x 128 ch  (wave: 64 ch x 128 px)
                                      {2, 2, 1, 4, 32},   // 2: 16x16 px x  64 ch  (wave: 64 ch x  64 px)
@@ -341,7 +343,9 @@ constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
                                      {2, 4, 1, 4, 16},   // 13: 32x16 px x  64 ch, 16-channel chunks
                                      {2, 2, 2, 2, 32},   // 14:  8x16 px x 128 ch
                                      {2, 3, 2, 2, 32},   // 15: 12x16 px x 128 ch (no fused pool: odd block count)
-                                     {1, 4, 1, 4, 16}};  // 16: 32x16 px x  32 ch, 16-channel chunks
+                                     {1, 4, 1, 4, 16},   // 16: 32x16 px x  32 ch, 16-channel chunks
+                                     {2, 3, 1, 4, 16}};  // 17: 24x16 px x  64 ch, 16-channel chunks (the decoder's 64-channel
+                                                         //     layers: the 32-row tile + the upsampling staging spills)
 inline bool cfg_valid(int cfg) { return cfg >= 1 && cfg < kNumCfgs && kV2Cfgs[cfg].CW != 0; }
 inline bool cfg_v3(int cfg) { return cfg >= 11; }
 inline int cfg_th(int cfg) { return 2 * kV2Cfgs[cfg].PBW * kV2Cfgs[cfg].WP; }
@@ -354,6 +358,7 @@ struct ConvPlan { int cfg, tiles, nb, splits; };
 // 120x160 layer has 160-300 workgroups and would take the one-wave-per-SIMD configuration, two of those do not
 // share a CU.
 thread_local int g_conv_peers = 1;
+thread_local int g_conv_layer = 0;  // index of the pyramid layer being launched (0: a stand-alone call)
 
 // Split-K factor: only the smallest maps (conv5: 12 tiles per image pair) leave most of the 256 CUs
 // without a workgroup; measured on the 60x80 layers (160 workgroups) every split loses to no split.
@@ -458,25 +463,33 @@ void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>), grid, dim3(256), lds, s, a);
 }
 
-template <int CW, int PBW, int WC, int WP, int KC>
+template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false>
 void launch_v3(const ConvArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = v3_lds_bytes(CW, PBW, WC, WP, KC);
+  constexpr int lds = v3_lds_bytes(CW, PBW, WC, WP, KC, UPCAT);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CW, PBW, WC, WP, KC>,
+    (void)hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CW, PBW, WC, WP, KC, UPCAT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_v3_kernel<CW, PBW, WC, WP, KC>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_v3_kernel<CW, PBW, WC, WP, KC, UPCAT>), grid, dim3(256), lds, s, a);
 }
 
 void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_t s) {
-  if (cfg_v3(cfg) && !upcat) {
+  if (cfg_v3(cfg) && upcat) {
+    switch (cfg) {
+      case 17: launch_v3<2, 3, 1, 4, 16, true>(a, grid, s); break;
+      default: launch_v3<1, 4, 1, 4, 16, true>(a, grid, s); break;  // 16
+    }
+    return;
+  }
+  if (cfg_v3(cfg)) {
     switch (cfg) {
       case 11: launch_v3<2, 4, 2, 2, 32>(a, grid, s); break;
       case 13: launch_v3<2, 4, 1, 4, 16>(a, grid, s); break;
       case 14: launch_v3<2, 2, 2, 2, 32>(a, grid, s); break;
       case 15: launch_v3<2, 3, 2, 2, 32>(a, grid, s); break;
+      case 17: launch_v3<2, 3, 1, 4, 16>(a, grid, s); break;
       default: launch_v3<1, 4, 1, 4, 16>(a, grid, s); break;
     }
     return;
@@ -512,7 +525,30 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
-  if (up) force_cfg = cout % 64 == 0 ? 2 : 6;
+  // Experiment knob: PXT_CONV_PLAN="layer:cfg:splits;..." overrides the tile configuration / split-K factor of the
+  // pyramid's convolution `layer` (1..16 in pxt_unet's order; 0 in a field = keep the default).
+  {
+    static const std::vector<std::array<int, 3>> plan = [] {
+      std::vector<std::array<int, 3>> v;
+      const char* e = getenv("PXT_CONV_PLAN");
+      while (e && *e) {
+        std::array<int, 3> t = {0, 0, 0};
+        if (sscanf(e, "%d:%d:%d", &t[0], &t[1], &t[2]) >= 2) v.push_back(t);
+        e = strchr(e, ';');
+        if (e) ++e;
+      }
+      return v;
+    }();
+    for (const auto& t : plan)
+      if (t[0] == g_conv_layer && g_conv_layer > 0) {
+        if (t[1] > 0) force_cfg = t[1];
+        if (t[2] > 0) force_splits = t[2];
+      }
+  }
+  if (up) {  // decoder layers: 2 / 13 (64 channels), 6 / 16 (32 channels)
+    const bool ok = cout % 64 == 0 ? (force_cfg == 2 || force_cfg == 17) : (force_cfg == 6 || force_cfg == 16);
+    if (!ok) force_cfg = cout % 64 == 0 ? 2 : 6;
+  }
   const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr, pool_out != nullptr);
   ConvArgs a;
   // (the packed buffer holds the second kernel's layout, then the third's: pxt_conv3x3_packed_bytes)
@@ -528,6 +564,10 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   }
   if (pooled) *pooled = a.pool != nullptr;
   const dim3 grid(cp.tiles, cp.nb, cp.splits);
+  static const bool debug_plan = getenv("PXT_CONV_DEBUG") != nullptr;
+  if (debug_plan)
+    fprintf(stderr, "conv layer %2d %4d->%4d @%dx%d x%d  cfg %2d  grid (%d, %d, %d)%s%s\n", g_conv_layer, cin, cout, W, H, n_img,
+            cp.cfg, cp.tiles, cp.nb, cp.splits, up ? "  upcat" : "", a.pool ? "  +pool" : "");
   launch_v2_cfg(cp.cfg, up != nullptr, a, grid, s);
   if (cp.splits > 1) {
     const long long n4 = (long long)n_img * H * W * cout / 4;
@@ -779,6 +819,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       half_t* o = last ? buf(P.enc_out[b]) : buf(P.enc_tmp[b][i & 1]);
       // the block's last conv also writes the next block's pooled input (epilogue fusion)
       half_t* pool_to = (last && b < 4) ? buf(P.enc_pool[b + 1]) : nullptr;
+      g_conv_layer = li;
       int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
                            1, (float*)(ws + P.splitk), B, nullptr, pool_to, pool_to ? &pooled_by_conv : nullptr);
       if (rc != PXT_OK) return rc;
@@ -814,6 +855,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       fh.enabled = 1;
       head0_fused = true;
     }
+    g_conv_layer = 13 + d;
     int rc = launch_conv(L.cin, L.cout, ctx->conv_packed[13 + d], L.b, skip[sb], P.dh[d], P.dw[d], o, s, 1,
                          fuse_head ? nullptr : (float*)(ws + P.splitk), B, &up, nullptr, nullptr, 0, 0,
                          fuse_head ? &fh : nullptr);
@@ -827,6 +869,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       launch_head(1, ss.side);
     }
   }
+  g_conv_layer = 0;
   // (the heads were launched above: the two coarse ones on the side stream as soon as their input
   // existed, the fine one here)
   if (!head0_fused) launch_head(0, s);

@@ -102,3 +102,28 @@ def test_the_timing_instrument_build_still_compiles(tmp_path):
     for f in list(_build.CSRC.glob("*.hip")) + list(_build.CSRC.glob("*.h")):
         left |= set(re.findall(r"#\s*if(?:n?def)?\s+(PXT_[A-Z_0-9]+)", f.read_text()))
     assert left <= {"PXT_EXP_STAMPS"}, left
+
+
+def test_no_convolution_kernel_uses_scratch(tmp_path):
+    """A conv3x3 instantiation that spills to scratch costs milliseconds per launch (scratch set-up) - it has happened
+    twice (round 2: an un-unrolled step loop; round 3: hoisted blend weights).  The assembly's kernel descriptors
+    are checked here so that a spill fails the CPU suite, not the frame rate."""
+    import re
+    import shutil
+    import subprocess
+
+    from pixtrack_amd import _build
+
+    if shutil.which(_build.HIPCC) is None:
+        import pytest
+
+        pytest.skip("no hipcc")
+    src = _build.CSRC / "pxt_unet.hip"
+    cmd = [_build.HIPCC, *_build.FLAGS, "-save-temps", "-c", str(src), "-o", str(tmp_path / "u.o")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    asm = next(tmp_path.glob("*gfx950*.s")).read_text()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", asm)
+    conv = {n: int(sz) for n, sz in kernels if "conv3x3" in n or "conv_first" in n or "head_mfma" in n}
+    assert len(conv) >= 10, sorted(conv)
+    assert all(sz == 0 for sz in conv.values()), {n: sz for n, sz in conv.items() if sz}

@@ -212,6 +212,48 @@ def test_config5_sized_problem(device):
     assert float((res.T.t.double() - ref["t"]).norm()) < TRANS_TOL
 
 
+def test_hd_four_stage_plan_matches_oracle(device):
+    """BASELINE configs[4]'s LM work on its own: the 4-stage plan {image scale 4: level [2]; image scale 1: levels
+    [2, 1, 0]} (bench.py --config hd; builder-defined, the reference has 3 levels per image scale) at N = 10 000
+    points against the pyramids of a 1920x1080 query after the extractor's resize (1024x576, and 256x144 at image
+    scale 4), HIP kernel vs the oracle's loop over the same level lists, stage by stage."""
+    s4 = make_lm_scene(seed=1009, width=256, height=144, n_points=10000, sigma_px=2.0)
+    s1 = make_lm_scene(seed=1009, width=1024, height=576, n_points=10000, sigma_px=2.0)
+    assert np.array_equal(s4.p3d, s1.p3d) and np.array_equal(s4.R_init, s1.R_init) and np.array_equal(s4.t_gt, s1.t_gt)
+    lam = lambdas(CONSTS)
+    conf = O.LMConf()
+    p3d_o = torch.from_numpy(s1.p3d)
+    log = O.LMLog()
+    ra = O.refine_pose_using_features(s4.feats_query, s4.scales, s4.camera._data, torch.from_numpy(s4.R_init),
+                                      torch.from_numpy(s4.t_init), s4.feats_ref, p3d_o, lam, conf, log=log, levels=[2])
+    assert ra["success"]
+    rb = O.refine_pose_using_features(s1.feats_query, s1.scales, s1.camera._data, ra["R"], ra["t"], s1.feats_ref, p3d_o,
+                                      lam, conf, log=log, levels=[2, 1, 0])
+    assert rb["success"] and len(log.num_iters) == 4
+
+    opt = PixTrackOptimizer(dict(num_iters=conf.num_iters, pad=conf.pad))
+    p3d = torch.from_numpy(s1.p3d).float().to(device)
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+
+    def packs_of(sc, levels):
+        out = []
+        for level in levels:
+            fmap, fref, Cc, cam = pack_level(sc, level, device, sc.camera)
+            out.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+        return out
+
+    res_a = PixTrackOptimizer.refine_levels(p3d, packs_of(s4, [2]), s4.T_init, opt.native_conf(), ws).result()
+    assert not res_a.failed and len([n for n in res_a.iters if n]) == 1
+    assert O.rotation_angle_rad(res_a.T.R.double(), ra["R"]) < ROT_TOL
+    assert float((res_a.T.t.double() - ra["t"]).norm()) < TRANS_TOL
+    res_b = PixTrackOptimizer.refine_levels(p3d, packs_of(s1, [2, 1, 0]), res_a.T, opt.native_conf(), ws).result()
+    assert not res_b.failed and len([n for n in res_b.iters if n]) == 3
+    rot = O.rotation_angle_rad(res_b.T.R.double(), rb["R"])
+    tra = float((res_b.T.t.double() - rb["t"]).norm())
+    assert rot < ROT_TOL and tra < TRANS_TOL, (rot, tra, res_a.iters, res_b.iters, log.num_iters)
+    assert O.rotation_angle_rad(res_b.T.R.double(), torch.from_numpy(s1.R_gt)) < 5e-3  # and towards the ground truth
+
+
 def test_dirty_workspace_and_back_to_back_launches(device):
     """The inter-workgroup exchange polls tagged granules in the workspace: every polled word is zeroed by the
     launch's own memset, so a workspace full of garbage (or of the previous launch's tags) changes nothing, and
