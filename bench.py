@@ -20,7 +20,14 @@ The timed loop carries only the roofline's instrumentation (HIP events around th
 kernel's launches of every 4th render, one sample-count atomic per workgroup); per-stage times
 and the dominant kernel's isolated timing come from a separate untimed pass over the next 20
 frames.  The per-frame cost varies along the synthetic orbit (more samples per render as the
-object turns), so `value` depends on K: ~410 frames/s at the default K = 60, ~350 at K = 200.
+object turns), so `value` depends on K: ~630-640 frames/s at the driver's K = 20, ~550 over the
+200 frames that follow (`extras.value_k200`); `extras.value_two_renders` (~500) is the real-asset
+case in which the mask and the reference image need two renders.
+
+N > 1 without a launcher (`python bench.py --gpus 8`) spawns its own N ranks under
+torch.distributed.run; a world size that differs from --gpus, or fewer GPUs than ranks with the
+RCCL backend, is an error.  The line carries what the collective layer saw: `ranks_seen`, per-rank
+device / PCI bus / NUMA node / own frames/s, `rccl_version`.
 """
 from __future__ import annotations
 
@@ -103,18 +110,24 @@ def cpu_baseline(assets, frames, start_pose, ref_id):
     w = assets["weights"]
     Rt, tt = torch.from_numpy(np.asarray(R, np.float64)), torch.from_numpy(np.asarray(t, np.float64))
     lambdas = [LO.damping_lambda(w[f"optimizer.{i}.dampingnet.const"].float()) for i in range(3)]
-    per_frame = []
+    per_frame, stage_s = [], {"unet_x2": 0.0, "sample": 0.0, "lm": 0.0}
     for k in range(4):  # frame 0 = warm-up (thread pools, allocator), 3 timed
         img = frames[1 + k].cpu().numpy()
         t0 = time.perf_counter()
         f_ref, sc_ref, c_ref = UO.extractor_call(w, img, 1)  # reference image: same size, same cost
         f_q, sc_q, c_q = UO.extractor_call(w, img, 1)
+        t1 = time.perf_counter()
         maps_ref = [torch.cat([f, c], 0) for f, c in zip(f_ref, c_ref)]
         maps_q = [torch.cat([f, c], 0) for f, c in zip(f_q, c_q)]
         obs, valid = LO.interp_sparse_observations(maps_ref, sc_ref, ref_cam_full, 0.5, Rt.float(), tt.float(), p3d, 1)
+        t2 = time.perf_counter()
         LO.refine_pose_using_features(maps_q, sc_q, qcam, Rt, tt, obs, p3d, lambdas, LO.LMConf(), mask=valid)
+        t3 = time.perf_counter()
         if k > 0:
-            per_frame.append(time.perf_counter() - t0)
+            per_frame.append(t3 - t0)
+            stage_s["unet_x2"] += (t1 - t0) / 3
+            stage_s["sample"] += (t2 - t1) / 3
+            stage_s["lm"] += (t3 - t2) / 3
     t_rest = float(np.mean(per_frame))
     model = ""
     try:
@@ -125,9 +138,12 @@ def cpu_baseline(assets, frames, start_pose, ref_id):
     return {
         "value": round(1.0 / (t_nerf + t_rest), 5), "unit": "frames/s", "cores": n_threads, "kind": "port",
         "host_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(), "host_cpu": model,
-        "sample": (f"full 640x480 frame: NeRF depth + RGB renders at full size, spp 8, once = {t_nerf:.1f}s (numpy oracle, "
-                   f"1 thread + BLAS); UNet x2 + sparse sampling + LM = {t_rest:.2f}s/frame (mean of 3 frames after 1 "
-                   f"warm-up, {n_threads} torch threads of {os.cpu_count()} host CPUs); no extrapolation"),
+        "stage_seconds": {"nerf_depth_plus_rgb": round(t_nerf, 2), **{k: round(v, 3) for k, v in stage_s.items()}},
+        "sample": (f"ONE full 640x480 frame's work, no extrapolation.  NeRF leg: 1-thread numpy, ONCE (depth + RGB "
+                   f"renders at full size, spp 8 = {t_nerf:.1f}s - it dominates the figure and is a single run, not a mean); "
+                   f"UNet x2 + sparse sampling + LM = {t_rest:.2f}s/frame (mean of 3 frames after 1 warm-up, {n_threads} "
+                   f"torch threads of {os.cpu_count()} host CPUs).  BASELINE.md 3 asks for >= 20 frames: at ~100 s per "
+                   "frame that is half an hour of CPU, so the sample is bounded as the bench contract requires"),
     }
 
 
@@ -514,16 +530,36 @@ def main():
     # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes of this command
     # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be taken live here)
     traffic, traffic_src = None, None
-    pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
-    if pmc.exists():
+    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (3, 2)) if q.exists()), None)
+    if pmc is not None:
         recs = json.loads(pmc.read_text())
-        rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
+        rec = (recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
+               or recs.get("void pxt::ngp_shade_kernel<2, true>"))  # (the round-2 name of the same kernel)
         if rec:
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
-            traffic_src = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
+            traffic_src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
     iso_avg_ms = iso_ms / max(iso_launches, 1)
     iso_spl = iso_samples / max(iso_renders * 5, 1)  # one pipeline: 5 launches per render
     iso_achieved = iso_spl * NERF_BYTES_PER_SAMPLE / (iso_avg_ms * 1e-3) / 1e9 if iso_avg_ms > 0 else 0.0
+    # What actually binds the kernel (rocprofv3 TCP / TCC counter passes of this command, scripts/collect_profiles.sh):
+    # not HBM bytes - the fabric side moves ~0.35 x the algorithmic bytes - but the L1's miss path: requests to the L2
+    # x their latency.  `l2` prices the kernel against the L2's own peak as well.
+    l2 = None
+    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (3,)) if q.exists()), None)
+    if l2f is not None:
+        recs = json.loads(l2f.read_text())
+        rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
+        if rec and rec.get("TCP_TCC_READ_REQ_sum") and enc_avg_ms > 0:
+            req = rec["TCP_TCC_READ_REQ_sum"]
+            tbs = req * 64.0 / (enc_avg_ms * 1e-3) / 1e12
+            l2 = {"what": "L1 -> L2 read requests of the same kernel (64 B each) per launch over the live launch time",
+                  "requests_per_launch": round(req, 1), "achieved": round(tbs, 3), "peak": 34.5, "unit": "TB/s",
+                  "frac": round(tbs / 34.5, 4),
+                  "mean_request_latency_cycles": (round(rec["TCP_TCC_READ_REQ_LATENCY_sum"] / req, 1)
+                                                  if rec.get("TCP_TCC_READ_REQ_LATENCY_sum") else None),
+                  "l2_hit_rate": (round(rec["TCC_HIT_sum"] / max(rec["TCC_HIT_sum"] + rec.get("TCC_MISS_sum", 0.0), 1.0), 3)
+                                  if rec.get("TCC_HIT_sum") else None),
+                  "source": f"profiles/{l2f.name}"}
     roofline = {"kernel": GATHER_KERNEL, "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_unit": "MB per launch", "traffic_source": traffic_src,
@@ -533,6 +569,11 @@ def main():
                 "samples_per_render": round(stats[0] / max(n_renders, 1), 1),
                 "note": ("timed region: the render runs as two overlapping pipelines, so a launch shares the chip "
                          "with the other slice's march/shade and its duration is not the kernel's isolated speed"),
+                "binding_resource": ("the L1 miss path (requests to L2 x ~300 cycles of latency, L1 busy ~89 %), NOT HBM "
+                                     "bytes: `bound` keeps the contract's hbm|mfma vocabulary and prices the ALGORITHMIC "
+                                     "gather bytes against the HBM peak; `traffic` (fabric side) is ~0.35 x that, `l2` "
+                                     "prices the L2 requests against the L2's peak"),
+                "l2": l2,
                 "isolated": {"what": f"same kernel, one pipeline, untimed pass over {n_diag - n_diag // 2} further frames",
                              "achieved": round(iso_achieved, 2), "frac": round(iso_achieved / HBM_PEAK_GBS, 5),
                              "avg_launch_ms": round(iso_avg_ms, 5), "launches": iso_launches,
@@ -574,15 +615,15 @@ def main():
     # other kernels' utilisation from the committed rocprofv3 SQ counter pass of this command
     # (profiles/r02_pmc_sq.json; scripts/pmc_sq_summary.py): matrix-pipe busy of the UNet convolutions,
     # VALU busy of the march (a serial DDA per ray: latency- and tail-bound, not VALU-bound)
-    sq = ROOT / "profiles" / "r02_pmc_sq.json"
-    if sq.exists():
+    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (3, 2)) if q.exists()), None)
+    if sq is not None:
         rec = json.loads(sq.read_text())
         pick = {}
         for name, r in rec.items():
-            if "conv3x3_v2_kernel" in name or "ngp_march" in name or "ngp_shade" in name or "ngp_encode" in name:
+            if "conv3x3_v" in name or "ngp_compact_march" in name or "ngp_shade" in name or "lm_refine" in name:
                 pick[name.replace("void pxt::", "").replace("pxt::", "")] = {
                     k: round(r[k], 4) for k in ("mfma_busy", "valu_busy", "mean_waves_per_simd") if k in r}
-        out["kernel_utilisation"] = {"source": "profiles/r02_pmc_sq.json (rocprofv3 --pmc SQ_*, same command)", "kernels": pick}
+        out["kernel_utilisation"] = {"source": f"profiles/{sq.name} (rocprofv3 --pmc SQ_*, same command)", "kernels": pick}
     if extras is not None:
         out["extras"] = extras
     if not args.no_cpu_baseline and ws == 1:

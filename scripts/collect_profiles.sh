@@ -2,14 +2,14 @@
 # Collects everything profiles/ holds for a round, each in its own rocprofv3 run (kernel trace, then one --pmc pass per
 # counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), and writes the summaries under
 # gpurun_out/<rNN>/ (copy the ones to be judged into profiles/).
-r=${1:-r02}
+r=${1:-r03}
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(pwd)
 out=$root/gpurun_out/$r; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 cmd="python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- $cmd > $out/${r}_bench_under_rocprof.log 2>&1
 python $root/scripts/rocpd_summary.py $out/kt/kt_results.db > $out/${r}_kernel_stats.csv
-python $root/scripts/unet_timeline.py $out/kt/kt_results.db > $out/${r}_unet_timeline.txt
+python $root/scripts/unet_timeline.py $out/kt/kt_results.db > $out/${r}_unet_timeline.txt 2>&1
 python $root/scripts/ngp_timeline.py $out/kt/kt_results.db > $out/${r}_ngp_timeline.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pf -o pf -- $cmd > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pw -o pw -- $cmd > $out/pmc_write.log 2>&1
@@ -17,6 +17,10 @@ python $root/scripts/pmc_summary.py $out/pf/pf_results.db $out/pw/pw_results.db 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS \
   --kernel-trace --output-format csv -d $out/psq -- $cmd > $out/pmc_sq.log 2>&1
 python $root/scripts/pmc_sq_summary.py $out/psq > $out/${r}_pmc_sq.json
+# L1 -> L2 requests / latency and L2 hits per kernel (two passes: TCP and TCC counters do not share a pass)
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $out/pl1 -- $cmd > $out/pmc_l1.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $out/pl2 -- $cmd > $out/pmc_l2.log 2>&1
+python $root/scripts/pmc_l2_summary.py $out/pl1 $out/pl2 > $out/${r}_pmc_l2.json
 cd $root
 python scripts/bench_conv.py --all-cfgs > $out/${r}_conv_cfgs.log 2>&1
 python bench.py > $out/${r}_bench.json 2> $out/${r}_bench.err

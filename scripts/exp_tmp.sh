@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT
-run() { printf "%-14s %-40s" "$1" "[$2]"; PIXTRACK_HIP_LIB=$GRAFT_REPO_ROOT/pixtrack_amd/$1 PXT_CONV_PLAN="$2" python scripts/unet_pass_timeline.py 2>&1 | grep "host ahead" | sed 's/two-image pass, host ahead://'; }
+python -m pytest tests/test_variants_gpu.py -q 2>&1 | tail -3
+b() { python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_frame'], d['roofline']['frac'], d['tracked_ok'])"; }
 for rep in 1 2 3; do
-run libpixtrack_hip.so ""
-run libpxt_oldinterp.so ""
-run libpixtrack_hip.so "13:17:0;14:17:0;15:17:0;16:16:0"
-run libpixtrack_hip.so "16:16:0"
+echo "== default"; b
+echo "== xcd bands"; PXT_NGP_XCD_BANDS=1 b
 done
-python -m pytest tests/test_unet_gpu.py -q 2>&1 | tail -3
