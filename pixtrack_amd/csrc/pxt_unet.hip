@@ -86,21 +86,32 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstImages imgs,
     }
   }
   __syncthreads();
-  // One wave per strip row (64 pixels = two 32-pixel MFMA column blocks), all 64 output channels:
-  // exact-f32 matrix FMAs v_mfma_f32_32x32x2_f32, K = 27 taps padded to 28 = 14 instructions per
-  // 32x32 tile.  The result is bit for bit the k-ordered fmaf chain acc = fma(in_k, w_k, acc), k = 0..26,
-  // started from the bias - what the scalar loop of the first version computed at a quarter of the rate
-  // (its 27 x 64 weights had to stream through the SGPR file).
+  // One wave per strip row (64 pixels = two 32-pixel MFMA column blocks), all 64 output channels, K = 27 taps padded
+  // to 32 = two k-steps of v_mfma_f32_32x32x16_f16.  The fp32 operands are split into fp16 halves, x = xh + xl and
+  // w = wh + wl (xh = fp16(x), xl = fp16(x - xh): 22 of the 24 mantissa bits), and the product is formed as
+  // wh xh + wl xh + wh xl with fp32 accumulation - three MFMAs at the fp16 rate instead of the exact-f32
+  // v_mfma_f32_32x32x2_f32 chain of round 2, which ran at the f32 VECTOR rate (1/16) and took 3.6k matrix cycles per
+  // 64 pixels: 52 us for both images.  The dropped wl xl term is < 2^-22 of a product: far below the fp16 rounding of
+  // the layer's output.
   static_assert(COUT == 64, "two 32-row blocks");
   const int lane = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const int r31 = lane & 31, khalf = lane >> 5;
-  float wa[14][2];  // A operand: row = output channel 32 cb + r31, k = 2 kp + khalf
+  half8 wh[2][2], wl[2][2];  // A operand: row = output channel 32 cb + r31, k = 16 s + 8 khalf + j
+  int koff[2][8];            // s_px offset (floats, relative to the pixel's window origin) of tap k; -1: padding
 #pragma unroll
-  for (int kp = 0; kp < 14; ++kp) {
-    const int k = 2 * kp + khalf;
+  for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) wa[kp][cb] = k < 27 ? wts[(size_t)(32 * cb + r31) * 27 + k] : 0.f;
-  }
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = 16 * s2 + 8 * khalf + jj;  // (ky, kx, c) = (k / 9, (k / 3) % 3, k % 3)
+      koff[s2][jj] = k < 27 ? ((k / 9) * (kFW + 2) + (k / 3) % 3) * 3 + k % 3 : -1;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const float w = k < 27 ? wts[(size_t)(32 * cb + r31) * 27 + k] : 0.f;
+        const half_t h = (half_t)w;
+        wh[cb][s2][jj] = h;
+        wl[cb][s2][jj] = (half_t)(w - (float)h);
+      }
+    }
   constexpr int kPieces = COUT / 8;
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
@@ -110,14 +121,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstImages imgs,
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[cb][r] = bias[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * khalf];
+    const float* win = s_px + (ly * (kFW + 2) + lx) * 3;
+    half8 xh[2], xl[2];
 #pragma unroll
-    for (int kp = 0; kp < 14; ++kp) {
-      const int k = 2 * kp + khalf;  // (ky, kx, c) = (k / 9, (k / 3) % 3, k % 3)
-      const int kk = k < 27 ? k : 0;
-      const float bv = s_px[((ly + kk / 9) * (kFW + 2) + lx + (kk / 3) % 3) * 3 + kk % 3];
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kp][cb], bv, acc[cb], 0, 0, 0);
-    }
+      for (int jj = 0; jj < 8; ++jj) {
+        const float v = koff[s2][jj] >= 0 ? win[koff[s2][jj]] : 0.f;
+        const half_t h = (half_t)v;
+        xh[s2][jj] = h;
+        xl[s2][jj] = (half_t)(v - (float)h);
+      }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cb][s2], xh[s2], acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[cb][s2], xh[s2], acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cb][s2], xl[s2], acc[cb], 0, 0, 0);
+      }
     // D[row = channel][col = pixel]: this lane holds pixel lx, channels (r&3) + 8 (r>>2) + 4 khalf of each block;
     // ReLU, fp16, into the pixel's record of the XOR-swizzled LDS tile (16-B pieces of 8 channels)
     const int t = ly * kFW + lx;

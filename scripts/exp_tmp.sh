@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_variants_gpu.py -q 2>&1 | tail -3
-b() { python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_frame'], d['roofline']['frac'], d['tracked_ok'])"; }
+python -m pytest tests/test_unet_gpu.py tests/test_fullsize_golden_gpu.py tests/test_sequence_golden_gpu.py -q 2>&1 | tail -3
+run() { printf "%-22s" "$1"; PIXTRACK_HIP_LIB=$GRAFT_REPO_ROOT/pixtrack_amd/$1 python scripts/unet_pass_timeline.py 2>&1 | grep "host ahead" | sed 's/two-image pass, host ahead://'; }
 for rep in 1 2 3; do
-echo "== default"; b
-echo "== xcd bands"; PXT_NGP_XCD_BANDS=1 b
+run libpixtrack_hip.so
+run libpxt_oldfirst.so
 done
