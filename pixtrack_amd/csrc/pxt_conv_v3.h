@@ -55,16 +55,20 @@ __device__ inline unsigned pk_max(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2v, a), __builtin_bit_cast(half2v, b)));
 }
 
-constexpr int v3_lds_bytes(int CW, int PBW, int WC, int WP, int KC, bool upcat = false) {
-  return 2 * (2 * PBW * WP + 2) * (20 * KC * 2) + 2 * 3 * CW * WC * 1024 + 32 * CW * WC * 4 +
+constexpr int v3_lds_bytes(int CW, int PBW, int WC, int WP, int KC, bool upcat = false, int KS = 1) {
+  return KS * (2 * (2 * PBW * WP + 2) * (20 * KC * 2) + 2 * 3 * CW * WC * 1024) + 32 * CW * WC * 4 +
          (upcat ? (PBW * WP + 2) * 10 * KC * 2 : 0);
 }
 
 // UPCAT (decoder layers): the conv input is concat(bilinear x2 upsample of `prev`, skip); channels below Cp are formed
 // in the staging from the low-resolution patch under the tile's halo, exactly as in the second kernel.
-template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
-  static_assert(WC * WP == 4, "four waves per workgroup");
+// KS = 2 (the layers whose grid leaves one workgroup per CU): the workgroup has EIGHT waves - two quartets that walk the
+// two halves of the K range with their own halo / filter buffers, side by side on the SIMDs (two waves per SIMD where
+// the four-wave workgroup left one), and add their accumulators through LDS before the epilogue.
+template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false, int KS = 1>
+__global__ __launch_bounds__(256 * KS, 2) void conv3x3_v3_kernel(const ConvArgs a) {
+  static_assert(WC * WP == 4, "four waves per quartet");
+  static_assert(KS == 1 || (KS == 2 && !UPCAT), "K split across two wave quartets: plain layers only");
   static_assert(KC == 16 || KC == 32, "chunk of 16 or 32 input channels");
   using G = V3Geo<KC>;
   constexpr int TH = 2 * PBW * WP, HR = TH + 2;
@@ -77,13 +81,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   constexpr int kAElems = 3 * NCB * 64;             // 16-B pieces of one group's filter fragments
   constexpr int KA = (kAElems + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const s_halo = smem;
-  char* const s_a = smem + 2 * kBuf;
-  float* const s_bias = (float*)(smem + 2 * kBuf + 2 * kABuf);
-  char* const patch = smem + 2 * kBuf + 2 * kABuf + BNC * 4;  // UPCAT: the low-resolution patch of one chunk
+  constexpr int kQuartet = 2 * kBuf + 2 * kABuf;  // LDS of one wave quartet
+  const int kh = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);  // which half of the K range
+  char* const s_halo = smem + kh * kQuartet;
+  char* const s_a = s_halo + 2 * kBuf;
+  float* const s_bias = (float*)(smem + KS * kQuartet);
+  char* const patch = smem + KS * kQuartet + BNC * 4;  // UPCAT: the low-resolution patch of one chunk
 
   PXT_STAMP(0);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;  // index inside the quartet
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave / WP, wp = wave % WP;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   const half_t* in = a.in + (size_t)img * (UPCAT ? a.up.Hs : H) * in_w * Cs;
   const half_t* prev = UPCAT ? a.up.prev + (size_t)img * a.up.Hp * a.up.Wp * a.up.Cp : nullptr;
 
-  if (tid < BNC) s_bias[tid] = a.bias[co0 + tid];
+  if ((int)threadIdx.x < BNC) s_bias[threadIdx.x] = a.bias[co0 + threadIdx.x];
 
   f32x16 acc[CW][PBW];
 #pragma unroll
@@ -117,7 +123,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   // K range of this workgroup (split-K over gridDim.z), in chunks of KC channels
   const int n_chunks = Cin / KC;
   const int per_z = (n_chunks + (int)gridDim.z - 1) / (int)gridDim.z;
-  const int ch_begin = (int)blockIdx.z * per_z, ch_end = min(n_chunks, ch_begin + per_z);
+  int ch_begin = (int)blockIdx.z * per_z, ch_end = min(n_chunks, ch_begin + per_z);
+  if (KS == 2) {  // (the host only picks KS = 2 for an even number of chunks: both quartets meet at the same barriers)
+    const int half = (ch_end - ch_begin) >> 1;
+    ch_begin += kh * half;
+    ch_end = ch_begin + half;
+  }
   const int n_groups = (ch_end - ch_begin) * NG;
 
   // ---- filter staging: group gg (global index) = three runs of NCB KiB --------------------------
@@ -372,8 +383,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_v3_kernel(const ConvArgs a) {
   }
   PXT_STAMP(2);
 
+  if constexpr (KS == 2) {  // the second quartet hands its accumulators over through LDS and leaves
+    __syncthreads();
+    float* const xch = (float*)smem + (size_t)wave * (CW * PBW * 16 * 64) + lane;
+    static_assert(4 * CW * PBW * 16 * 64 * 4 <= KS * kQuartet, "the accumulator exchange fits in the staging buffers");
+    if (kh == 1) {
+#pragma unroll
+      for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int p = 0; p < PBW; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xch[((c * PBW + p) * 16 + r) * 64] = acc[c][p][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int p = 0; p < PBW; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c][p][r] += xch[((c * PBW + p) * 16 + r) * 64];
+    }
+  }
   // ---- epilogue: D[row = cout][col = pixel]; lane: pixel r31 of block p, channels (r&3) + 8*(r>>2) + 4*khalf
   __syncthreads();  // every wave is done with the LDS buffers: the output tile is staged there
+  if (KS == 2 && kh == 1) return;
   PXT_STAMP(12);
   const int cw0 = co0 + 32 * CW * wc;
   half_t* out = a.out + (size_t)img * H * W * Cout;

@@ -348,8 +348,8 @@ namespace {
 // ---- launch plan of one 3x3 layer ------------------------------------------------------------
 // Tile configurations of conv3x3_v2_kernel<CW, PBW, WC, WP>: a workgroup (4 waves, WC x WP) covers
 // TH = 2*PBW*WP rows x 16 columns of pixels and BNC = 32*CW*WC output channels.
-struct V2Cfg { int CW, PBW, WC, WP, KC; };
-constexpr int kNumCfgs = 18;
+struct V2Cfg { int CW, PBW, WC, WP, KC, KS; };
+constexpr int kNumCfgs = 20;
 constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
                                      {2, 4, 2, 2, 32},   // 1: 16x16 px x 128 ch  (wave: 64 ch x 128 px)
                                      {2, 2, 1, 4, 32},   // 2: 16x16 px x  64 ch  (wave: 64 ch x  64 px)
@@ -366,8 +366,10 @@ constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
                                      {2, 2, 2, 2, 32},   // 14:  8x16 px x 128 ch
                                      {2, 3, 2, 2, 32},   // 15: 12x16 px x 128 ch (no fused pool: odd block count)
                                      {1, 4, 1, 4, 16},   // 16: 32x16 px x  32 ch, 16-channel chunks
-                                     {2, 3, 1, 4, 16}};  // 17: 24x16 px x  64 ch, 16-channel chunks (the decoder's 64-channel
+                                     {2, 3, 1, 4, 16},   // 17: 24x16 px x  64 ch, 16-channel chunks (the decoder's 64-channel
                                                          //     layers: the 32-row tile + the upsampling staging spills)
+                                     {2, 3, 2, 2, 32, 2},  // 18: as 15, eight waves: the K range split over two wave quartets
+                                     {2, 4, 2, 2, 32, 2}}; // 19: as 11, eight waves
 inline bool cfg_valid(int cfg) { return cfg >= 1 && cfg < kNumCfgs && kV2Cfgs[cfg].CW != 0; }
 inline bool cfg_v3(int cfg) { return cfg >= 11; }
 inline int cfg_th(int cfg) { return 2 * kV2Cfgs[cfg].PBW * kV2Cfgs[cfg].WP; }
@@ -411,15 +413,26 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
       // per wave), so a layer whose output is pooled keeps the 8- / 16-row tile.
       const int w15 = wgs_of(15);
       if (!wants_pool && w15 >= 192 && w15 <= 512) cfg = 15;
+      // ... and where even that leaves ONE four-wave workgroup per CU (the 60x80 layers), the eight-wave variants
+      // put a second wave on every SIMD by splitting the K range inside the workgroup: 914 / 784 TFLOP/s.
+      const bool even_k = (cin / 32) % 2 == 0;
+      if (cfg == 15 && w15 <= 256 && even_k) cfg = 18;
+      if (cfg == 1 && wgs_of(1) <= 256 && wgs_of(1) >= 128 && even_k) cfg = 19;
+      // the 30x40 layers (a handful of tiles, split-K): the same eight-wave tile, 4 splits of 2 + 2 chunks per quartet pair
+      if (cfg == 1 && allow_split && wgs_of(15) < 192 && (cin / 32) % 8 == 0) cfg = 18;
     }
     else if (cout % 64 == 0) cfg = 2;
     else cfg = 6;
   }
+  if (cfg_valid(cfg) && kV2Cfgs[cfg].KS == 2 && (upcat || (cin / 32) % 2 != 0)) cfg = cfg == 18 ? 15 : 11;
   P.cfg = cfg;
   const int th = cfg_th(cfg);
   P.tiles = n_img * ((H + th - 1) / th) * ((W + 15) / 16);
   P.nb = cout / cfg_bnc(cfg);
   P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(g_conv_peers * P.tiles * P.nb, cin / 32, upcat)) : 1;
+  if (kV2Cfgs[cfg].KS == 2) {  // every split must hold an even number of chunks: round the factor down to a divisor
+    while (P.splits > 1 && (cin / 32) % (2 * P.splits) != 0) --P.splits;
+  }
   return P;
 }
 
@@ -485,16 +498,16 @@ void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>), grid, dim3(256), lds, s, a);
 }
 
-template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false>
+template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false, int KS = 1>
 void launch_v3(const ConvArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = v3_lds_bytes(CW, PBW, WC, WP, KC, UPCAT);
+  constexpr int lds = v3_lds_bytes(CW, PBW, WC, WP, KC, UPCAT, KS);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CW, PBW, WC, WP, KC, UPCAT>,
+    (void)hipFuncSetAttribute((const void*)conv3x3_v3_kernel<CW, PBW, WC, WP, KC, UPCAT, KS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_v3_kernel<CW, PBW, WC, WP, KC, UPCAT>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_v3_kernel<CW, PBW, WC, WP, KC, UPCAT, KS>), grid, dim3(256 * KS), lds, s, a);
 }
 
 void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_t s) {
@@ -512,6 +525,8 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
       case 14: launch_v3<2, 2, 2, 2, 32>(a, grid, s); break;
       case 15: launch_v3<2, 3, 2, 2, 32>(a, grid, s); break;
       case 17: launch_v3<2, 3, 1, 4, 16>(a, grid, s); break;
+      case 18: launch_v3<2, 3, 2, 2, 32, false, 2>(a, grid, s); break;
+      case 19: launch_v3<2, 4, 2, 2, 32, false, 2>(a, grid, s); break;
       default: launch_v3<1, 4, 1, 4, 16>(a, grid, s); break;
     }
     return;
@@ -578,6 +593,7 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   a.out = out; a.partial = partial;
   a.up = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
   a.pool = (cp.splits == 1 && !(cfg_v3(cp.cfg) && (kV2Cfgs[cp.cfg].PBW & 1))) ? pool_out : nullptr;
+  if (kV2Cfgs[cp.cfg].KS == 2 && ((cin / 32) / cp.splits) % 2 != 0) return PXT_E_ARG;  // both quartets need equal K shares
   std::memset(&a.head, 0, sizeof(a.head));
   if (head) {
     if (cout != 32 || cp.splits != 1 || cfg_bnc(cp.cfg) != 32) return PXT_E_ARG;

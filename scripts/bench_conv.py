@@ -10,7 +10,8 @@ from pixtrack_amd import _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()
 CFG = {1: (16, 128), 2: (16, 64), 4: (8, 128), 6: (16, 32),  # rows, channels per WG
-       11: (16, 128), 13: (32, 64), 14: (8, 128), 15: (12, 128), 16: (32, 32)}  # third kernel (pxt_conv_v3.h)
+       11: (16, 128), 13: (32, 64), 14: (8, 128), 15: (12, 128), 16: (32, 32), 17: (24, 64),
+       18: (12, 128), 19: (16, 128)}  # third kernel (pxt_conv_v3.h); 18 / 19: eight waves, K split in the workgroup
 # (H, W, Cin, Cout, images): the probe shape, then the 640x480 pyramid's plain layers (two images per pass)
 shapes = [(256, 256, 256, 128, 1), (256, 512, 256, 128, 1), (256, 256, 128, 128, 1), (480, 640, 64, 64, 2), (240, 320, 64, 128, 2),
           (240, 320, 128, 128, 2), (120, 160, 128, 256, 2), (120, 160, 256, 256, 2), (60, 80, 256, 512, 2),
