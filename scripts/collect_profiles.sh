@@ -21,6 +21,10 @@ python $root/scripts/pmc_sq_summary.py $out/psq > $out/${r}_pmc_sq.json
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $out/pl1 -- $cmd > $out/pmc_l1.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $out/pl2 -- $cmd > $out/pmc_l2.log 2>&1
 python $root/scripts/pmc_l2_summary.py $out/pl1 $out/pl2 > $out/${r}_pmc_l2.json
+# the two-image UNet pass with the host AHEAD of the device (under the profiler the host otherwise falls behind and the
+# two streams stop overlapping): one pass's dispatches on both streams
+rocprofv3 --kernel-trace -d $out/ut -o ut -- python $root/scripts/unet_pass_timeline.py > $out/${r}_unet_pass.log 2>&1
+python $root/scripts/unet_timeline.py $out/ut/ut_results.db -1 > $out/${r}_unet_pass_timeline.txt 2>&1
 cd $root
 python scripts/bench_conv.py --all-cfgs > $out/${r}_conv_cfgs.log 2>&1
 python bench.py > $out/${r}_bench.json 2> $out/${r}_bench.err
