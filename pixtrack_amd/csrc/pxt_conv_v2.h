@@ -311,12 +311,39 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
     }
   };
 
+  // A K range of exactly TWO chunks (the 64-input-channel layers at 640x480 and 320x240): both halos are fetched in
+  // the prologue, back to back, so the workgroup pays ONE memory latency.  (Staged the usual way, chunk 1's loads had
+  // the five MFMA steps of chunk 0 - ~650 cycles - to arrive before their LDS write needed them; stamps: prologue 7.7 k
+  // + chunk 0 8.1 k + chunk 1 4.9 k cycles against 2.3 k of MFMA issue per chunk.)
+  const bool preload2 = !UPCAT && (ch_end - ch_begin) == 2;
   if (ch_begin < ch_end) {  // first chunk: staged synchronously
     if (UPCAT && ch_begin * 32 < cp0) {
       patch_issue(ch_begin * 32);
       patch_write();
       __syncthreads();
       patch_interp(0);
+    } else if (preload2) {
+      half8 r_nx[KH];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        halo_issue(ch_begin * 32, b);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+          const int k = b * KB + kk;
+          if (k < KH)
+            r_nx[k] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    in_rsrc, (int)(goff[k] + (unsigned)(((ch_begin + 1) * 32 - cp0) * 2)), 0, 0));
+        }
+        halo_write(0, b);
+      }
+      const int t_ = opaque(tid);
+#pragma unroll
+      for (int k = 0; k < KH; ++k) {
+        const int i = t_ + 256 * k;
+        const int pix = i >> 2, seg = i & 3;
+        const int hy = pix / kV2Cols, hx = pix % kV2Cols;
+        if (i < kElems) *(half8*)(smem + kBuf + hy * kV2RowBytes + hx * 64 + ((seg ^ ((hx >> 2) & 3)) << 4)) = r_nx[k];
+      }
     } else {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -344,7 +371,7 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   aptr += (size_t)(AR - 1) * a_step;
 
   for (int ch = ch_begin; ch < ch_end; ++ch) {
-    const bool more = ch + 1 < ch_end;
+    const bool more = ch + 1 < ch_end && !preload2;
     const char* sbuf = smem + ((ch - ch_begin) & 1) * kBuf;
     const int nbuf = ((ch - ch_begin) & 1) ^ 1;
     __syncthreads();  // this chunk's halo is complete; everyone is done reading the other buffer
