@@ -41,6 +41,19 @@ struct FusedHead {
   int cstride, enabled;
 };
 
+// Optional fused FIRST layer (conv 3 -> 64 of the pyramid) in front of the 64 -> 64 layer: the workgroup computes the
+// first layer's output for its own halo from the raw image window (normalisation, mask, fp16 hi / lo split MFMAs:
+// conv_first_kernel's arithmetic) straight into its two halo buffers - the 39 MB activation per image is neither
+// written nor read back, and the workgroup's prologue is a 5-KB load instead of a 41-KB one.
+struct FusedFirst {
+  const void* image[PXT_UNET_MAX_BATCH];   // HWC, 0..255, float or u8
+  const uint8_t* mask[PXT_UNET_MAX_BATCH];
+  int is_u8[PXT_UNET_MAX_BATCH];
+  const float* w;   // [64][27] fp32, k = (ky * 3 + kx) * 3 + c
+  const float* b;   // [64]
+  int enabled;
+};
+
 struct ConvArgs {
   const half_t* in;      // [n_img][H][W][Cin]  (UPCAT: the skip tensor [n_img][Hs][Ws][Cin - Cp])
   int H, W, Cin;
@@ -52,6 +65,7 @@ struct ConvArgs {
   UpSrc up;
   half_t* pool;          // optional [n_img][H/2][W/2][Cout]: 2x2 max-pool of `out` (gridDim.z == 1 only)
   FusedHead head;        // head.enabled: Cout == 32, gridDim.z == 1
+  FusedFirst first;      // first.enabled: Cin == 64, gridDim.z == 1, the FIRST kernel variant
 };
 
 // Host-side mirror of the packed layout: element (cout, tap, cin) lives at
@@ -130,8 +144,9 @@ __device__ unsigned long long pxt_stamps[8192 * 16];
 #else
 #define PXT_STAMP(k)
 #endif
-template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3>
+template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3, bool FIRST = false>
 __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const ConvArgs a) {
+  static_assert(!FIRST || !UPCAT, "the fused first layer feeds a plain layer");
   static_assert(18 % AR == 0, "the ring is indexed by the step modulo AR at compile time");
   static_assert(WC * WP == 4, "four waves per workgroup");
   constexpr int TH = 2 * PBW * WP, HR = TH + 2;
@@ -315,8 +330,95 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   // the prologue, back to back, so the workgroup pays ONE memory latency.  (Staged the usual way, chunk 1's loads had
   // the five MFMA steps of chunk 0 - ~650 cycles - to arrive before their LDS write needed them; stamps: prologue 7.7 k
   // + chunk 0 8.1 k + chunk 1 4.9 k cycles against 2.3 k of MFMA issue per chunk.)
-  const bool preload2 = !UPCAT && (ch_end - ch_begin) == 2;
-  if (ch_begin < ch_end) {  // first chunk: staged synchronously
+  const bool preload2 = FIRST || (!UPCAT && (ch_end - ch_begin) == 2);
+  if constexpr (FIRST) {
+    // ---- the pyramid's first layer, computed for this tile's halo ((TH + 2) x 18 pixels x 64 channels = both chunks)
+    constexpr int FW = 20;  // raw window: halo + 1 pixel on every side
+    float* const s_px = (float*)(smem + 2 * kBuf + 32 * CW * WC * 4);
+    {
+      const void* image = a.first.image[img];
+      const uint8_t* mask = a.first.mask[img];
+      const bool u8 = a.first.is_u8[img] != 0;
+      const float mean[3] = {0.485f, 0.456f, 0.406f};
+      const float istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+      for (int i = tid; i < (HR + 2) * FW; i += 256) {
+        const int yy = ty0 + i / FW - 2, xx = tx0 + i % FW - 2;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float m = 1.f;
+        if (ok && mask) m = (float)mask[(size_t)yy * W + xx];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float v = 0.f;
+          if (ok) {
+            const size_t idx = ((size_t)yy * W + xx) * 3 + c;
+            float raw = u8 ? (float)((const uint8_t*)image)[idx] : ((const float*)image)[idx];
+            if (mask) raw *= m;
+            v = (raw / 255.0f - mean[c]) * istd[c];
+          }
+          s_px[i * 3 + c] = v;
+        }
+      }
+    }
+    half8 wh[2][2], wl[2][2];  // A operand: row = first-layer channel 32 cb + r31, k = 16 s + 8 khalf + j
+    int koff[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int k = 16 * s2 + 8 * khalf + jj;  // (ky, kx, c) = (k / 9, (k / 3) % 3, k % 3)
+        koff[s2][jj] = k < 27 ? ((k / 9) * FW + (k / 3) % 3) * 3 + k % 3 : -1;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const float w = k < 27 ? a.first.w[(size_t)(32 * cb + r31) * 27 + k] : 0.f;
+          const half_t h = (half_t)w;
+          wh[cb][s2][jj] = h;
+          wl[cb][s2][jj] = (half_t)(w - (float)h);
+        }
+      }
+    __syncthreads();
+    constexpr int kHaloPix = HR * kV2Cols, kBlocks = (kHaloPix + 31) / 32;
+    for (int bi = wave; bi < kBlocks; bi += 4) {
+      const int q = 32 * bi + r31;
+      const bool live = q < kHaloPix;
+      const int qq = live ? q : 0;
+      const int hy = qq / kV2Cols, hx = qq % kV2Cols;
+      const float* win = s_px + (hy * FW + hx) * 3;  // the 3x3 window of halo pixel (hy, hx) starts one pixel up-left of it
+      half8 xh[2], xl[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float v = koff[s2][jj] >= 0 ? win[koff[s2][jj]] : 0.f;
+          const half_t h = (half_t)v;
+          xh[s2][jj] = h;
+          xl[s2][jj] = (half_t)(v - (float)h);
+        }
+      // the layer's zero padding: halo pixels outside the image are zeros, not the first layer's response to padding
+      const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        f32x16 fa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fa[r] = a.first.b[32 * cb + (r & 3) + 8 * (r >> 2) + 4 * khalf];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cb][s2], xh[s2], fa, 0, 0, 0);
+          fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[cb][s2], xh[s2], fa, 0, 0, 0);
+          fa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[cb][s2], xl[s2], fa, 0, 0, 0);
+        }
+        // chunk cb = channels 32 cb .. + 31: piece g holds channels 8 g .. + 7, this lane its half 4 khalf .. + 3
+        char* rec = smem + cb * kBuf + hy * kV2RowBytes + hx * 64 + khalf * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = inside ? (half_t)fmaxf(fa[4 * g + j], 0.f) : (half_t)0.f;
+          if (live) *(half4*)(rec + ((g ^ ((hx >> 2) & 3)) << 4)) = o;
+        }
+      }
+    }
+  } else if (ch_begin < ch_end) {  // first chunk: staged synchronously
     if (UPCAT && ch_begin * 32 < cp0) {
       patch_issue(ch_begin * 32);
       patch_write();

@@ -349,7 +349,7 @@ namespace {
 // Tile configurations of conv3x3_v2_kernel<CW, PBW, WC, WP>: a workgroup (4 waves, WC x WP) covers
 // TH = 2*PBW*WP rows x 16 columns of pixels and BNC = 32*CW*WC output channels.
 struct V2Cfg { int CW, PBW, WC, WP, KC, KS; };
-constexpr int kNumCfgs = 20;
+constexpr int kNumCfgs = 22;
 constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
                                      {2, 4, 2, 2, 32},   // 1: 16x16 px x 128 ch  (wave: 64 ch x 128 px)
                                      {2, 2, 1, 4, 32},   // 2: 16x16 px x  64 ch  (wave: 64 ch x  64 px)
@@ -369,7 +369,9 @@ constexpr V2Cfg kV2Cfgs[kNumCfgs] = {{0, 0, 0, 0, 0},
                                      {2, 3, 1, 4, 16},   // 17: 24x16 px x  64 ch, 16-channel chunks (the decoder's 64-channel
                                                          //     layers: the 32-row tile + the upsampling staging spills)
                                      {2, 3, 2, 2, 32, 2},  // 18: as 15, eight waves: the K range split over two wave quartets
-                                     {2, 4, 2, 2, 32, 2}}; // 19: as 11, eight waves
+                                     {2, 4, 2, 2, 32, 2},  // 19: as 11, eight waves
+                                     {1, 2, 1, 4, 16},     // 20: 16x16 px x 32 ch, 16-channel chunks: 33 KB of LDS, 4 workgroups per CU
+                                     {2, 2, 1, 4, 16}};    // 21: 16x16 px x 64 ch, 16-channel chunks
 inline bool cfg_valid(int cfg) { return cfg >= 1 && cfg < kNumCfgs && kV2Cfgs[cfg].CW != 0; }
 inline bool cfg_v3(int cfg) { return cfg >= 11; }
 inline int cfg_th(int cfg) { return 2 * kV2Cfgs[cfg].PBW * kV2Cfgs[cfg].WP; }
@@ -486,16 +488,17 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
   return true;
 }
 
-template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3>
+template <int CW, int PBW, int WC, int WP, bool UPCAT, int AR = 3, bool FIRST = false>
 void launch_v2(const ConvArgs& a, dim3 grid, hipStream_t s) {
-  constexpr int lds = 2 * (2 * PBW * WP + 2) * kV2RowBytes + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0) + 32 * CW * WC * 4;
+  constexpr int lds = 2 * (2 * PBW * WP + 2) * kV2RowBytes + (UPCAT ? (PBW * WP + 2) * 10 * 64 : 0) + 32 * CW * WC * 4 +
+                      (FIRST ? (2 * PBW * WP + 4) * 20 * 3 * 4 : 0);
   static bool attr_done = false;  // the double-buffered halo of the 32-row tiles exceeds the 64 KiB default
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>,
+    (void)hipFuncSetAttribute((const void*)conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR, FIRST>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_v2_kernel<CW, PBW, WC, WP, UPCAT, AR, FIRST>), grid, dim3(256), lds, s, a);
 }
 
 template <int CW, int PBW, int WC, int WP, int KC, bool UPCAT = false, int KS = 1>
@@ -514,6 +517,8 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
   if (cfg_v3(cfg) && upcat) {
     switch (cfg) {
       case 17: launch_v3<2, 3, 1, 4, 16, true>(a, grid, s); break;
+      case 20: launch_v3<1, 2, 1, 4, 16, true>(a, grid, s); break;
+      case 21: launch_v3<2, 2, 1, 4, 16, true>(a, grid, s); break;
       default: launch_v3<1, 4, 1, 4, 16, true>(a, grid, s); break;  // 16
     }
     return;
@@ -527,6 +532,8 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
       case 17: launch_v3<2, 3, 1, 4, 16>(a, grid, s); break;
       case 18: launch_v3<2, 3, 2, 2, 32, false, 2>(a, grid, s); break;
       case 19: launch_v3<2, 4, 2, 2, 32, false, 2>(a, grid, s); break;
+      case 20: launch_v3<1, 2, 1, 4, 16>(a, grid, s); break;
+      case 21: launch_v3<2, 2, 1, 4, 16>(a, grid, s); break;
       default: launch_v3<1, 4, 1, 4, 16>(a, grid, s); break;
     }
     return;
@@ -547,7 +554,10 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
       if (deep) launch_v2<2, 4, 2, 2, false, 9>(a, grid, s);
       else launch_v2<2, 4, 2, 2, false>(a, grid, s);
       break;
-    case 2: launch_v2<2, 2, 1, 4, false>(a, grid, s); break;
+    case 2:
+      if (a.first.enabled) launch_v2<2, 2, 1, 4, false, 3, true>(a, grid, s);
+      else launch_v2<2, 2, 1, 4, false>(a, grid, s);
+      break;
     case 4: launch_v2<2, 2, 2, 2, false>(a, grid, s); break;
     default: launch_v2<1, 2, 1, 4, false>(a, grid, s); break;
   }
@@ -558,7 +568,7 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
 int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const half_t* in, int H, int W, half_t* out,
                 hipStream_t s, int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr,
                 half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0,
-                const FusedHead* head = nullptr) {
+                const FusedHead* head = nullptr, const FusedFirst* first = nullptr) {
   if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
@@ -582,8 +592,9 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
         if (t[2] > 0) force_splits = t[2];
       }
   }
+  if (first) { force_cfg = 2; force_splits = 0; }
   if (up) {  // decoder layers: 2 / 13 (64 channels), 6 / 16 (32 channels)
-    const bool ok = cout % 64 == 0 ? (force_cfg == 2 || force_cfg == 17) : (force_cfg == 6 || force_cfg == 16);
+    const bool ok = cout % 64 == 0 ? (force_cfg == 2 || force_cfg == 17 || force_cfg == 21) : (force_cfg == 6 || force_cfg == 16 || force_cfg == 20);
     if (!ok) force_cfg = cout % 64 == 0 ? 2 : 6;
   }
   const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr, pool_out != nullptr);
@@ -599,6 +610,12 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
     if (cout != 32 || cp.splits != 1 || cfg_bnc(cp.cfg) != 32) return PXT_E_ARG;
     a.head = *head;
     a.head.enabled = 1;
+  }
+  std::memset(&a.first, 0, sizeof(a.first));
+  if (first) {  // the first layer computed in this layer's staging: the 64 -> 64 layer on its 16x16 x 64-channel tile only
+    if (cin != 64 || cp.cfg != 2 || cp.splits != 1 || up) return PXT_E_ARG;
+    a.first = *first;
+    a.first.enabled = 1;
   }
   if (pooled) *pooled = a.pool != nullptr;
   const dim3 grid(cp.tiles, cp.nb, cp.splits);
@@ -823,6 +840,8 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
   const half_t* skip[5];
   const half_t* cur = nullptr;
   bool pooled_by_conv = false;
+  bool fuse_first = false;
+  FusedFirst ff;
   for (int b = 0; b < 5; ++b) {
     const int h = P.h[b], w = P.w[b];
     const half_t* x;
@@ -838,8 +857,20 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
         fi.is_u8[i] = image_is_u8[i];
       }
       if (L0.cout != 64) return PXT_E_ARG;
-      hipLaunchKernelGGL(conv_first_kernel<64>, dim3(nblk, B), dim3(256), 0, s, fi, h, w, (const float*)L0.w, L0.b, o);
-      x = o;
+      // The first layer is computed inside the second layer's staging (pxt_conv_v2.h FusedFirst): its 39-MB output per
+      // image is never written.  PXT_UNET_FUSE_FIRST=0 keeps the separate launch (A/B, tests/test_variants_gpu.py).
+      static const bool fuse_first_env = [] { const char* e = getenv("PXT_UNET_FUSE_FIRST"); return e ? atoi(e) != 0 : true; }();
+      fuse_first = fuse_first_env && ctx->conv[1].cin == 64 && ctx->conv[1].cout == 64;
+      if (fuse_first) {
+        std::memset(&ff, 0, sizeof(ff));
+        for (int i = 0; i < B; ++i) { ff.image[i] = fi.image[i]; ff.mask[i] = fi.mask[i]; ff.is_u8[i] = fi.is_u8[i]; }
+        ff.w = (const float*)L0.w;
+        ff.b = L0.b;
+        x = nullptr;
+      } else {
+        hipLaunchKernelGGL(conv_first_kernel<64>, dim3(nblk, B), dim3(256), 0, s, fi, h, w, (const float*)L0.w, L0.b, o);
+        x = o;
+      }
     } else {
       half_t* o = buf(P.enc_pool[b]);
       if (!pooled_by_conv) {
@@ -858,8 +889,10 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       // the block's last conv also writes the next block's pooled input (epilogue fusion)
       half_t* pool_to = (last && b < 4) ? buf(P.enc_pool[b + 1]) : nullptr;
       g_conv_layer = li;
+      const bool with_first = li == 1 && fuse_first;
       int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
-                           1, (float*)(ws + P.splitk), B, nullptr, pool_to, pool_to ? &pooled_by_conv : nullptr);
+                           1, with_first ? nullptr : (float*)(ws + P.splitk), B, nullptr, pool_to,
+                           pool_to ? &pooled_by_conv : nullptr, with_first ? 2 : 0, 0, nullptr, with_first ? &ff : nullptr);
       if (rc != PXT_OK) return rc;
       x = o;
     }
