@@ -595,7 +595,9 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   if (first) { force_cfg = 2; force_splits = 0; }
   if (up) {  // decoder layers: 2 / 13 (64 channels), 6 / 16 (32 channels)
     const bool ok = cout % 64 == 0 ? (force_cfg == 2 || force_cfg == 17 || force_cfg == 21) : (force_cfg == 6 || force_cfg == 16 || force_cfg == 20);
-    if (!ok) force_cfg = cout % 64 == 0 ? 2 : 6;
+    // round 3: the third kernel's 16-channel-chunk tiles (33-39 KB of LDS: four workgroups per CU instead of three on
+    // these latency-bound layers) for the three high-resolution decoder layers; the 60x80 one keeps its split-K tile
+    if (!ok) force_cfg = cout % 64 == 0 ? ((long long)H * W >= 120 * 160 ? 21 : 2) : 20;
   }
   const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr, pool_out != nullptr);
   ConvArgs a;
