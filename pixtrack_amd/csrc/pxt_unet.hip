@@ -438,8 +438,15 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   return P;
 }
 
+// Tile configuration of a decoder (upsample + concat) layer.  Round 3: the third kernel's 16-channel-chunk tiles (33-39 KB
+// of LDS: four workgroups per CU instead of three on these latency-bound layers) for the three high-resolution layers;
+// the 60x80 one keeps its split-K tile.
+inline int upcat_cfg(int cout, int H, int W) {
+  return cout % 64 == 0 ? ((long long)H * W >= 120 * 160 ? 21 : 2) : 20;
+}
+
 size_t splitk_bytes(int n_img, int H, int W, int cin, int cout, bool upcat = false) {
-  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, true, upcat ? (cout % 64 == 0 ? 2 : 6) : 0, 0, upcat);
+  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, true, upcat ? upcat_cfg(cout, H, W) : 0, 0, upcat);
   return cp.splits > 1 ? (size_t)cp.splits * n_img * H * W * cout * sizeof(float) : 0;
 }
 
@@ -595,9 +602,7 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   if (first) { force_cfg = 2; force_splits = 0; }
   if (up) {  // decoder layers: 2 / 13 (64 channels), 6 / 16 (32 channels)
     const bool ok = cout % 64 == 0 ? (force_cfg == 2 || force_cfg == 17 || force_cfg == 21) : (force_cfg == 6 || force_cfg == 16 || force_cfg == 20);
-    // round 3: the third kernel's 16-channel-chunk tiles (33-39 KB of LDS: four workgroups per CU instead of three on
-    // these latency-bound layers) for the three high-resolution decoder layers; the 60x80 one keeps its split-K tile
-    if (!ok) force_cfg = cout % 64 == 0 ? ((long long)H * W >= 120 * 160 ? 21 : 2) : 20;
+    if (!ok) force_cfg = upcat_cfg(cout, H, W);
   }
   const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, partial != nullptr, force_cfg, force_splits, up != nullptr, pool_out != nullptr);
   ConvArgs a;
