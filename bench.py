@@ -20,8 +20,8 @@ The timed loop carries only the roofline's instrumentation (HIP events around th
 kernel's launches of every 4th render, one sample-count atomic per workgroup); per-stage times
 and the dominant kernel's isolated timing come from a separate untimed pass over the next 20
 frames.  The per-frame cost varies along the synthetic orbit (more samples per render as the
-object turns), so `value` depends on K: ~630-640 frames/s at the driver's K = 20, ~550 over the
-200 frames that follow (`extras.value_k200`); `extras.value_two_renders` (~500) is the real-asset
+object turns), so `value` depends on K: ~655 frames/s at the driver's K = 20, ~575 over the
+200 frames that follow (`extras.value_k200`); `extras.value_two_renders` (~515) is the real-asset
 case in which the mask and the reference image need two renders.
 
 N > 1 without a launcher (`python bench.py --gpus 8`) spawns its own N ranks under
