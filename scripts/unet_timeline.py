@@ -8,7 +8,10 @@ import sys
 def main(path, which=None):
     c = sqlite3.connect(path)
     rows = list(c.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, queue_id from kernels order by start"))
-    firsts = [i for i, r in enumerate(rows) if "conv_first" in r[0]]
+    # a pass opens with the first layer: its own kernel, or (round 3) the 64 -> 64 layer's FIRST variant
+    def opens(n):
+        return "conv_first" in n or "false, 3, true>" in n
+    firsts = [i for i, r in enumerate(rows) if opens(r[0]) and (i == 0 or not opens(rows[i - 1][0]) or rows[i][1] - rows[i - 1][1] > 200000)]
     i0 = firsts[which if which is not None else (2 * len(firsts)) // 3]
     nxt = [i for i in firsts if i > i0]
     i1 = nxt[0] if nxt else len(rows)

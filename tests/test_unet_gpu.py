@@ -187,3 +187,22 @@ def test_conv3x3_every_tile_configuration(device, cfg, H, W, Cin, Cout):
     got3, _ = _packed_conv(device, x, w, b, 0, cfg=cfg)
     ref3 = F.conv2d(x.float()[None], w.float(), b, padding=1)[0]
     assert (got3 - ref3).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("cfg,splits", [(18, 2), (18, 4), (19, 2), (15, 4), (11, 8)])
+def test_split_k_on_the_third_kernel(device, cfg, splits):
+    """The 30x40 layers' shape: split-K on the third kernel - also with the K range of every split divided between two wave
+    quartets (18 / 19) - summed by the reduction kernel in split order: bit-identical run to run."""
+    H, W, Cin, Cout = 30, 40, 512, 256
+    g = torch.Generator().manual_seed(cfg * 31 + splits)
+    x = torch.randn(Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.float()[None], w.float(), b, padding=1)[0])
+    tol = 2e-3 * max(1.0, ref.abs().max().item())
+    first = None
+    for _ in range(3):
+        got, _ = _packed_conv(device, x, w, b, 1, cfg=cfg, splits=splits)
+        assert torch.isfinite(got).all() and (got - ref).abs().max().item() < tol
+        first = got if first is None else first
+        assert torch.equal(got, first)
