@@ -539,7 +539,7 @@ def main():
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
             traffic_src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
     iso_avg_ms = iso_ms / max(iso_launches, 1)
-    iso_spl = iso_samples / max(iso_renders * 5, 1)  # one pipeline: 5 launches per render
+    iso_spl = iso_samples / max(iso_launches, 1)  # one pipeline, every launch timed (5+ rounds per render)
     iso_achieved = iso_spl * NERF_BYTES_PER_SAMPLE / (iso_avg_ms * 1e-3) / 1e9 if iso_avg_ms > 0 else 0.0
     # What actually binds the kernel (rocprofv3 TCP / TCC counter passes of this command, scripts/collect_profiles.sh):
     # not HBM bytes - the fabric side moves ~0.35 x the algorithmic bytes - but the L1's miss path: requests to the L2

@@ -341,8 +341,8 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 //              shade   -- ngp_shade_kernel<MODE, true>: 8 rays x K=8 samples per wave; the wave gathers the hash-grid
 //                         features of its own 64 samples (16 levels x 8 corners), runs both MLPs on MFMA, composites
 //                         in order, terminates rays early
-//   tail     : after kRounds rounds the few remaining rays (grazing the soft shell) finish in
-//              a fused per-ray loop (march + encode + MLP per step)
+//   tail     : after the wavefront rounds the remaining rays (grazing the soft shell) finish in a per-WAVE loop of the
+//              same march + shade steps (8 rays x 8 samples per trip)
 //   resolve  : fixed-order mean over spp + background
 //
 // History (profiles/r02_ngp_experiments.md): round 1 gathered in a separate LEVEL-MAJOR kernel
@@ -357,9 +357,10 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // samples; samples a round evaluates past a ray's termination point are discarded.
 // ===========================================================================
 constexpr int kK = 8;          // samples per ray per round
-// wavefront rounds before the tail kernel (3 / 4 / 6 measured: 1.08 / 1.02 / 1.01 ms per render against 1.00,
-// profiles/r02_ngp_experiments.md)
-constexpr int kRounds = 5;
+// wavefront rounds before the straggler kernel (3 / 4 / 6 measured on a view that leaves it nothing: 1.08 / 1.02 / 1.01 ms
+// per render against 1.00, profiles/r02_ngp_experiments.md).  PXT_NGP_ROUNDS=n (1 .. kMaxRounds) overrides the count: a
+// ray's result does not depend on it (tests/test_variants_gpu.py).
+constexpr int kRounds = 5, kMaxRounds = 12;
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {
@@ -505,7 +506,7 @@ struct RayState {  // SoA, indexed by compact slot; two copies ping-pong between
 
 struct NgpWork {
   RayState st[2];
-  int* counters;       // [(kRounds + 2) * kCtrStride]: live rays entering round r
+  int* counters;       // [(kMaxRounds + 2) * kCtrStride]: live rays entering round r
   float4* spos;        // [slot * kK + k] = (x, y, z, dt); dt == 0 marks "no sample"
   float* st_t;         // t of each sample (depth mode)
   uint8_t* exhausted;  // per slot: the ray left the box during this round's march
@@ -965,68 +966,74 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   }
 }
 
-// Stragglers: wave = 64 live rays (lane = ray), fused march + encode + MLP per step until done.
+// Stragglers.  Rays that outlive the wavefront rounds finish here: a WAVE takes 8 of them and repeats the rounds' own two
+// steps - every ray's next K = 8 lattice samples (the lane that owns the ray's first slot marches), then ngp_shade_group on
+// the wave's 8 x 8 samples - until its rays are done: the same arithmetic in the same grouping as a wavefront round, so a
+// ray's result does not depend on how many rounds ran before (any PXT_NGP_ROUNDS gives the same image, bit for bit).
+// (The first version was one ray per LANE with a fused march + encode + MLP step per sample: a wave took max-over-64-lanes
+// steps, and a view along the object's soft shell - 10-14 k rays left, frames 100-250 of the synthetic orbit - spent
+// 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  Its sequential compositing also differed from the rounds' butterfly sums
+// in the last bit.)
 template <int MODE>
 __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
-  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
-  __syncthreads();
+  __shared__ unsigned s_feat[4 * 8 * 64];
   const int n = Wk.counters[round * kCtrStride];
+  if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(P.stats + 1, (unsigned long long)Wk.counters[0]);
+    atomicAdd(P.stats + 2, (unsigned long long)n);  // rays left for this kernel
+  }
+  if (blockIdx.x * 32 >= n) return;  // (workgroup-uniform: nothing left for this workgroup's four waves)
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
+  const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
+  const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
+  __syncthreads();
   const RayState& S = Wk.st[round & 1];
+  uint8_t* const keep = Wk.keep[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float half_s = P.aabb_scale * 0.5f;
-  const float scene_lo = 0.5f - half_s, inv_s = 1.0f / P.aabb_scale;
+  const int rlane = lane >> 3, k0 = lane & 7;
   unsigned long long n_samples = 0;
-  for (int base = (blockIdx.x * 4 + wave) * 64; base < n; base += gridDim.x * 4 * 64) {
-    const int slot = base + lane;
+  for (int base = (blockIdx.x * 4 + wave) * 8; base < n; base += gridDim.x * 4 * 8) {
+    const int slot = base + rlane;
     bool alive = slot < n;
-    const int sl = alive ? slot : 0;
-    const unsigned rid = S.rid[sl];
-    const Ray r = ray_from_record(P, Wk.raydir[rid]);
-    unsigned shB0[4], shB1[4];
-    sh_fragments(r.d, shB0, shB1);
-    float t = S.t[sl], T = S.T[sl];
-    float4 acc = S.acc[sl];
-    float accd = (MODE == 2) ? S.accd[sl] : 0.f;
-    bool terminated = false;
     while (__any(alive)) {
-      float pos[3] = {0.5f, 0.5f, 0.5f}, dt = P.dt_lo;
-      if (alive) alive = next_sample(P, r, t, pos, dt);
-      if (!__any(alive)) break;
-      float logit, rgbv[3];
-      ngp_eval<MODE == 1>(P, s_w, lane, alive, (pos[0] - scene_lo) * inv_s, (pos[1] - scene_lo) * inv_s,
-                      (pos[2] - scene_lo) * inv_s, shB0, shB1, logit, rgbv);
-      if (alive) {
-        n_samples += 1;
-        const float depth = (MODE != 0) ? (t * r.zdot) * P.depth_scale : 0.f;
-        if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
-        const float alpha = 1.0f - expf(-expf(logit) * dt);
-        const float wgt = alpha * T;
-        if (MODE == 2) accd += wgt * depth;
-        acc.x += wgt * rgbv[0];
-        acc.y += wgt * rgbv[1];
-        acc.z += wgt * rgbv[2];
-        acc.w += wgt;
-        T = T * (1.0f - alpha);
-        if (T < P.min_T) {
-          terminated = true;
-          alive = false;
+      if (alive && k0 == 0) {  // this ray's next K samples: ngp_march_kernel's loop
+        const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
+        float t = S.t[slot];
+        const size_t s0 = (size_t)slot * kK;
+        int k = 0;
+        bool out = false;
+        while (k < kK) {
+          if (t >= r.tmax) { out = true; break; }
+          float pos[3], dt;
+          int mip;
+          if (probe_cell(P, r, t, pos, dt, mip)) {
+            Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
+            Wk.st_t[s0 + k] = t;
+            t = t + dt;
+            ++k;
+          } else {
+            advance_past_cell(P, r, t, pos, mip);
+          }
         }
-        t = t + dt;
+        for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        S.t[slot] = t;
+        Wk.exhausted[slot] = out ? 1 : 0;
       }
-    }
-    if (slot < n) {
-      if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
-      finish_ray(Wk, rid, acc, terminated);
+      // the samples travel through memory from the marching lane to the wave's other lanes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      ngp_shade_group<MODE>(P, Wk, S, keep, s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, alive, base, n_samples);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (alive) alive = keep[slot] != 0;
     }
   }
   if (P.stats) {
     for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
     if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      atomicAdd(P.stats + 1, (unsigned long long)Wk.counters[0]);
-      atomicAdd(P.stats + 2, (unsigned long long)n);  // rays left for the tail
-    }
   }
 }
 
@@ -1090,7 +1097,7 @@ struct NgpCounterList { int* p[4]; int n; };
 __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk, const NgpCounterList zl) {
   if (blockIdx.x == 0)
     for (int w = 0; w < zl.n; ++w)
-      for (int i = threadIdx.x; i < (kRounds + 2) * kCtrStride; i += 256) zl.p[w][i] = 0;
+      for (int i = threadIdx.x; i < (kMaxRounds + 2) * kCtrStride; i += 256) zl.p[w][i] = 0;
   // One lane per pixel: it reads the pixel's spp finished rays (contiguous: 16 B x spp, whole lines per lane)
   // and adds them in pass order - the fixed order of a sequential mean.  All passes of a pixel share one ray
   // (snap_to_pixel_centers), so a pixel whose ray misses the box has no finished rays to read: nothing
@@ -1362,7 +1369,7 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
       o[w].rid[i] = take(half * 4); o[w].t[i] = take(half * 4); o[w].T[i] = take(half * 4);
       o[w].acc[i] = take(half * 16); o[w].accd[i] = take(half * 4);
     }
-    o[w].cnt = take((kRounds + 2) * kCtrStride * sizeof(int));
+    o[w].cnt = take((kMaxRounds + 2) * kCtrStride * sizeof(int));
     o[w].spos = take(samples * 16); o[w].stt = take(samples * 4);
     o[w].exh = take(half); o[w].keep = take(2 * al(half));
   }
@@ -1464,14 +1471,15 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
   for (int w = 0; w < n_pipe; ++w) {
     if (!counters_clean)
-      PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kRounds + 2) * kCtrStride * sizeof(int), st[w]));
+      PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), st[w]));
     if (fuse_init)  // ray generation + compaction + the first march
       hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
     else
       hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
-  for (int r = 0; r < kRounds; ++r) {
+  static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 1), kMaxRounds) : kRounds; }();
+  for (int r = 0; r < n_rounds; ++r) {
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
         hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
@@ -1502,7 +1510,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
       }
     }
     for (int w = 0; w < n_pipe; ++w) {
-      if (fuse_cm && r + 1 < kRounds)  // compaction of round r + march of round r + 1 in one launch
+      if (fuse_cm && r + 1 < n_rounds)  // compaction of round r + march of round r + 1 in one launch
         hipLaunchKernelGGL(ngp_compact_march_kernel<false>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
       else
         hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
@@ -1510,11 +1518,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   }
   for (int w = 0; w < n_pipe; ++w) {
     if (mode == 1)
-      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
     else if (mode == 2)
-      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
     else
-      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], kRounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
   }
   for (int w = 1; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));

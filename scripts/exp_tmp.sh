@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_unet_gpu.py tests/test_variants_gpu.py -q -x 2>&1 | tail -5
-run() { printf "%-22s" "inlaunch=$1"; PXT_CONV_INLAUNCH_REDUCE=$1 timeout 120 python scripts/unet_pass_timeline.py 2>&1 | grep "host ahead" | sed 's/two-image pass, host ahead://'; }
-for rep in 1 2 3; do run 1; run 0; done
+timeout 600 python -m pytest tests/test_ngp_gpu.py tests/test_variants_gpu.py tests/test_fullsize_golden_gpu.py tests/test_sequence_golden_gpu.py tests/test_ycb_gpu.py -q 2>&1 | tail -5
+timeout 300 python scripts/tail_rays.py 2>&1 | grep frame
+PXT_NGP_ROUNDS=2 timeout 300 python scripts/tail_rays.py 2>&1 | grep frame | head -4
