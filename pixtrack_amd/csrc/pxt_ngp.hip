@@ -357,10 +357,14 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // samples; samples a round evaluates past a ray's termination point are discarded.
 // ===========================================================================
 constexpr int kK = 8;          // samples per ray per round
-// wavefront rounds before the straggler kernel (3 / 4 / 6 measured on a view that leaves it nothing: 1.08 / 1.02 / 1.01 ms
-// per render against 1.00, profiles/r02_ngp_experiments.md).  PXT_NGP_ROUNDS=n (1 .. kMaxRounds) overrides the count: a
-// ray's result does not depend on it (tests/test_variants_gpu.py).
-constexpr int kRounds = 5, kMaxRounds = 12;
+// Wavefront rounds before the straggler kernel.  Round 3, with the per-wave straggler kernel (render_both, ms, frames 0 / 30 /
+// 60 / 100 / 150 / 200 / 250 / 300 of the synthetic orbit): 1 round 0.75 / 0.71 / 0.73 / 0.76 / 0.79 / 0.79 / 0.76 / 0.69;
+// 2: 0.66 / 0.63 / 0.65 / 0.69 / 0.70 / 0.72 / 0.67 / 0.62; **3: 0.66 / 0.61 / 0.64 / 0.68 / 0.70 / 0.71 / 0.67 / 0.62**;
+// 4: 0.66 / 0.61 / 0.65 / 0.70 / 0.69 / 0.71 / 0.69 / 0.63; 5: 0.67 / 0.61 / 0.64 / 0.72 / 0.72 / 0.74 / 0.71 / 0.64; 6: 0.66 /
+// 0.62 / 0.65 / 0.72 / 0.74 / 0.75 / 0.71 / 0.64.  (Rounds 1-2 used 5 with the one-ray-per-lane straggler kernel, which took
+// 0.15-0.45 ms on the views of frames 100-250.)  PXT_NGP_ROUNDS=n (1 .. kMaxRounds) overrides the count: a ray's result
+// does not depend on it (tests/test_variants_gpu.py).
+constexpr int kRounds = 3, kMaxRounds = 12;
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {
@@ -946,7 +950,6 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
   __syncthreads();
   const int n = Wk.counters[round * kCtrStride];
-  if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(P.stats + 3, (unsigned long long)n * kK);
   const RayState& S = Wk.st[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rlane = lane >> 3;
@@ -1033,7 +1036,10 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
   }
   if (P.stats) {
     for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
-    if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
+    if (lane == 0 && n_samples) {
+      atomicAdd(P.stats + 0, n_samples);
+      atomicAdd(P.stats + 3, n_samples);  // ... of which composited here, not by the rounds' shade launches
+    }
   }
 }
 
