@@ -513,7 +513,7 @@ def main():
     # ALGORITHMIC bytes per launch = composited samples per launch x 512 B; samples the
     # rounds evaluate past a ray's termination are waste and are not credited.
     enc_avg_ms = enc_ms / max(enc_launches, 1)          # over the timed (sampled) launches
-    # gather launches per render (5 rounds x the renderer's pipeline count), from the sampled renders
+    # gather launches per render (the wavefront rounds x the renderer's pipeline count), from the sampled renders
     sampled_renders = (n_renders + 3) // 4
     launches_total = int(round(enc_launches / max(sampled_renders, 1))) * n_renders
     # (samples composited by the straggler kernel - the same per-wave march + shade steps in another kernel - are not the
@@ -542,7 +542,7 @@ def main():
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
             traffic_src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
     iso_avg_ms = iso_ms / max(iso_launches, 1)
-    iso_spl = iso_samples / max(iso_launches, 1)  # one pipeline, every launch timed (5+ rounds per render)
+    iso_spl = iso_samples / max(iso_launches, 1)  # one pipeline, every launch timed
     iso_achieved = iso_spl * NERF_BYTES_PER_SAMPLE / (iso_avg_ms * 1e-3) / 1e9 if iso_avg_ms > 0 else 0.0
     # What actually binds the kernel (rocprofv3 TCP / TCC counter passes of this command, scripts/collect_profiles.sh):
     # not HBM bytes - the fabric side moves ~0.35 x the algorithmic bytes - but the L1's miss path: requests to the L2
