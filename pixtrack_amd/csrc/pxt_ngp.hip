@@ -46,25 +46,8 @@ constexpr int kFragD1 = 0, kFragD2 = 4, kFragC1 = 8, kFragC2 = 12, kFragC3 = 20;
 
 struct NgpLevel {
   float scale;
-  unsigned res, offset, size, hashed;  // hashed: 0 = tcnn's dense level, 1 = hashed, 2 = hashed, read through `box`
-  // A hashed level's values over the render box, copied out of the hash table into a dense array in brick order
-  // (ngp_box_fill_kernel): entry (x, y, z) of the box - grid point (bx0 + x, by0 + y, bz0 + z) - holds
-  // table[hash(grid point)].  Same values, so the same image bit for bit; what changes is where they live: a sample's
-  // 8 corners and its neighbours' share 128-B lines (4 x 4 x 2 points) and 128-KB bricks (32^3 points) instead of
-  // landing on 8 unrelated lines of a 2-MB table.
-  unsigned bx0, by0, bz0;   // grid coordinates of the box origin
-  unsigned bmx, bmy, bmz;   // largest local coordinate a sample's LOWER corner may take (extent - 2)
-  unsigned sby, sbz;        // entries between bricks along y / z: bricks_x << 15, bricks_x * bricks_y << 15
-  const unsigned* box;
-  unsigned box_bytes;
+  unsigned res, offset, size, hashed;
 };
-
-// Offset (in entries) of local grid point (x, y, z) in brick order: 32^3-point bricks, x-fastest brick order; inside a
-// brick 4 x 4 x 2-point lines (32 entries = 128 B), lines x-fastest (8 x 8 x 16 of them).  The three coordinates
-// contribute disjoint terms, so the 8 corners of a cell are sums of 2 x 3 partial offsets.
-__device__ __host__ inline unsigned box_off_x(unsigned x) { return (x & 3u) | (((x >> 2) & 7u) << 5) | ((x >> 5) << 15); }
-__device__ __host__ inline unsigned box_off_y(unsigned y, unsigned sby) { return ((y & 3u) << 2) | (((y >> 2) & 7u) << 8) | ((y >> 5) * sby); }
-__device__ __host__ inline unsigned box_off_z(unsigned z, unsigned sbz) { return ((z & 1u) << 4) | (((z >> 1) & 15u) << 11) | ((z >> 5) * sbz); }
 
 struct NgpParams {
   const unsigned* grid;        // [entries] packed 2 x fp16
@@ -209,19 +192,7 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
   const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
   unsigned vals[8];
   const int base = (int)(Lv.offset * 4u);
-  if (Lv.hashed == 2u) {
-    // (the level is wave-uniform: the descriptor lives in SGPRs)
-    const __amdgpu_buffer_rsrc_t box = __builtin_amdgcn_make_buffer_rsrc((void*)Lv.box, 0, (int)Lv.box_bytes, 0x00020000);
-    const unsigned lx = min(gx - Lv.bx0, Lv.bmx), ly = min(gy - Lv.by0, Lv.bmy), lz = min(gz - Lv.bz0, Lv.bmz);
-    const unsigned ox[2] = {box_off_x(lx), box_off_x(lx + 1u)};
-    const unsigned oy[2] = {box_off_y(ly, Lv.sby), box_off_y(ly + 1u, Lv.sby)};
-    const unsigned oz[2] = {box_off_z(lz, Lv.sbz), box_off_z(lz + 1u, Lv.sbz)};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const unsigned idx = ox[c & 1] + oy[(c >> 1) & 1] + oz[(c >> 2) & 1];
-      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(box, (int)(idx << 2), 0, 0);
-    }
-  } else if (Lv.hashed) {
+  if (Lv.hashed) {
     const unsigned mask = Lv.size - 1u;
     const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
     const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
@@ -356,24 +327,6 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
     if (l < 8) Flo[l] = pk; else Fhi[l - 8] = pk;
   }
   ngp_mlp<DEPTH_ONLY>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
-}
-
-// Copies one hashed level's values over the render box into brick order (NgpLevel::box): thread per entry of the
-// padded array (whole 32^3 bricks), writes contiguous, reads wherever the hash sends them (the 2-MB table sits in L2).
-__global__ void __launch_bounds__(256) ngp_box_fill_kernel(const unsigned* __restrict__ grid, NgpLevel Lv,
-                                                           unsigned* __restrict__ box, unsigned n_entries) {
-  const unsigned bricks_x = Lv.sby >> 15, bricks_y = Lv.sbz / Lv.sby;
-  const unsigned mask = Lv.size - 1u;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entries; i += gridDim.x * blockDim.x) {
-    const unsigned in = i & 32767u, b = i >> 15;
-    const unsigned bx = b % bricks_x, by = (b / bricks_x) % bricks_y, bz = b / (bricks_x * bricks_y);
-    const unsigned x = (in & 3u) | (((in >> 5) & 7u) << 2) | (bx << 5);
-    const unsigned y = ((in >> 2) & 3u) | (((in >> 8) & 7u) << 2) | (by << 5);
-    const unsigned z = ((in >> 4) & 1u) | (((in >> 11) & 15u) << 1) | (bz << 5);
-    const unsigned gx = Lv.bx0 + x, gy = Lv.by0 + y, gz = Lv.bz0 + z;
-    const unsigned idx = ((gx * 1u) ^ (gy * 2654435761u) ^ (gz * 805459861u)) & mask;
-    box[i] = grid[idx + Lv.offset];
-  }
 }
 
 // ===========================================================================
@@ -1244,11 +1197,6 @@ struct pxt_ngp {
   uint8_t* occ = nullptr;
   float* cam_dev = nullptr;  // 12 floats: the camera of a render enqueued ahead of its pose (render_both_from_pose)
   pxt::NgpLevel lv[pxt::kMaxLevels];
-  // brick-order copies of the hashed levels over the render box (ensure_boxes): lv_box[l].hashed == 2 where built
-  pxt::NgpLevel lv_box[pxt::kMaxLevels];
-  void* box_mem[pxt::kMaxLevels] = {};
-  float box_lo[3] = {0.f, 0.f, 0.f}, box_hi[3] = {-1.f, -1.f, -1.f};  // the (clipped) render box they cover; empty = none
-  size_t box_total_bytes = 0;
   // scratch of the wavefront renderer, grown on demand (rays = W*H*spp)
   void* scratch = nullptr;
   size_t scratch_rays = 0;
@@ -1356,8 +1304,6 @@ extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (ctx->occ) (void)hipFree(ctx->occ);
   if (ctx->cam_dev) (void)hipFree(ctx->cam_dev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
-  for (int l = 0; l < kMaxLevels; ++l)
-    if (ctx->box_mem[l]) (void)hipFree(ctx->box_mem[l]);
   for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
     if (ctx->ev_join[w]) (void)hipEventDestroy(ctx->ev_join[w]);
   }
@@ -1461,68 +1407,6 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
   return PXT_OK;
 }
 
-// Brick-order copies of the hashed levels over the render box `lo..hi` (already clipped to the scene cube), built on
-// `stream` ahead of the render that needs them and kept while later renders stay inside that box.  Memory: one entry
-// per grid point of the box, padded to 32^3 bricks - for the benchmark's box (0.27 x 0.47 x 0.53 of a scene of side 4)
-// 2.5 GB for the finest level, 3.6 GB for all twelve hashed levels; PXT_NGP_BOX_GB caps the sum (default 16, 0 = off:
-// every level read through its hash), finest levels first - they are the ones whose gathers miss.
-static int ensure_boxes(pxt_ngp* ctx, const float* lo, const float* hi, hipStream_t stream) {
-  static const double budget_gb = [] { const char* e = getenv("PXT_NGP_BOX_GB"); return e ? atof(e) : 16.0; }();
-  if (!(budget_gb > 0.0)) return PXT_OK;
-  bool inside = ctx->box_hi[0] >= ctx->box_lo[0];
-  for (int a = 0; a < 3 && inside; ++a) inside = lo[a] >= ctx->box_lo[a] && hi[a] <= ctx->box_hi[a];
-  if (inside) return PXT_OK;
-  for (int a = 0; a < 3; ++a)
-    if (!(hi[a] > lo[a])) return PXT_OK;  // an empty box renders background only
-  bool any = false;
-  for (int l = 0; l < kMaxLevels; ++l) any = any || ctx->box_mem[l];
-  if (any) {  // other streams may still read the old copies
-    PXT_HIP_CHECK(hipDeviceSynchronize());
-    for (int l = 0; l < kMaxLevels; ++l)
-      if (ctx->box_mem[l]) { (void)hipFree(ctx->box_mem[l]); ctx->box_mem[l] = nullptr; }
-  }
-  for (int l = 0; l < kMaxLevels; ++l) ctx->lv_box[l] = ctx->lv[l];
-  ctx->box_total_bytes = 0;
-  const float s = ctx->model.aabb_scale, enc_lo = 0.5f - s * 0.5f, enc_inv = 1.0f / s;
-  const double budget = budget_gb * (double)(1ull << 30);
-  for (int l = ctx->model.n_levels - 1; l >= 0; --l) {
-    NgpLevel& L = ctx->lv_box[l];
-    if (!L.hashed) continue;
-    // grid coordinates the samples' lower corners can take: floor(u * scale + 0.5) for u inside the box, with two
-    // points of margin either side for the last-bit differences between this arithmetic and the kernels'
-    unsigned g0[3], n[3];
-    for (int a = 0; a < 3; ++a) {
-      const float u0 = (lo[a] - enc_lo) * enc_inv, u1 = (hi[a] - enc_lo) * enc_inv;
-      const long long a0 = (long long)std::floor((double)u0 * L.scale + 0.5) - 2;
-      const long long a1 = (long long)std::floor((double)u1 * L.scale + 0.5) + 2 + 1;  // + 1: the upper corner
-      const long long c0 = std::max(a0, 0ll);
-      g0[a] = (unsigned)c0;
-      n[a] = (unsigned)std::max(a1 - c0 + 1, 2ll);
-    }
-    const unsigned long long bricks[3] = {(n[0] + 31) / 32, (n[1] + 31) / 32, (n[2] + 31) / 32};
-    const unsigned long long entries = (bricks[0] * bricks[1] * bricks[2]) << 15;
-    const unsigned long long bytes = entries * 4;
-    if (bytes >= (1ull << 32) || (double)(ctx->box_total_bytes + bytes) > budget) continue;
-    void* mem = nullptr;
-    hipError_t e = hipMalloc(&mem, (size_t)bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); continue; }  // no room: this level keeps its hash
-    ctx->box_mem[l] = mem;
-    ctx->box_total_bytes += bytes;
-    L.hashed = 2u;
-    L.bx0 = g0[0]; L.by0 = g0[1]; L.bz0 = g0[2];
-    L.bmx = n[0] - 2; L.bmy = n[1] - 2; L.bmz = n[2] - 2;
-    L.sby = (unsigned)(bricks[0] << 15);
-    L.sbz = (unsigned)((bricks[0] * bricks[1]) << 15);
-    L.box = (const unsigned*)mem;
-    L.box_bytes = (unsigned)bytes;
-    const unsigned blocks = (unsigned)std::min<unsigned long long>((entries + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(ngp_box_fill_kernel, dim3(blocks), dim3(256), 0, stream, ctx->grid, L, (unsigned*)mem, (unsigned)entries);
-    PXT_HIP_CHECK(hipGetLastError());
-  }
-  for (int a = 0; a < 3; ++a) { ctx->box_lo[a] = lo[a]; ctx->box_hi[a] = hi[a]; }
-  return PXT_OK;
-}
-
 static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
                        uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
                        float* cam_out = nullptr) {
@@ -1540,15 +1424,6 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   P.focal = v->focal;
   P.k1 = v->k1;
   for (int i = 0; i < 3; ++i) { P.lo[i] = v->aabb_min[i]; P.hi[i] = v->aabb_max[i]; }
-  {  // the box the rays are clipped to (ray_clip): the samples' positions stay inside it
-    const float half_s = P.aabb_scale * 0.5f;
-    float clo[3], chi[3];
-    for (int a = 0; a < 3; ++a) { clo[a] = std::max(P.lo[a], 0.5f - half_s); chi[a] = std::min(P.hi[a], 0.5f + half_s); }
-    const int rcb = ensure_boxes(ctx, clo, chi, (hipStream_t)stream);
-    if (rcb != PXT_OK) return rcb;
-    if (ctx->box_hi[0] >= ctx->box_lo[0])
-      for (int l = 0; l < P.n_levels; ++l) P.lv[l] = ctx->lv_box[l];
-  }
   for (int i = 0; i < 4; ++i) P.bg[i] = v->background[i];
   P.min_T = v->min_transmittance;
   P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = mode;

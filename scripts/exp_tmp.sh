@@ -1,10 +1,4 @@
-#!/bin/bash
-# scratch experiment driver (gpurun)
-cd /root/repo
-for gb in 0 0.008 0.03 0.1 0.3 1.0 16 0; do
-  echo "== PXT_NGP_BOX_GB=$gb"
-  PXT_NGP_BOX_GB=$gb timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], d['stage_ms_per_frame']['nerf_render'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['extras']['value_k200']['frames_per_s'])"
-done
+cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_ngp_gpu.py tests/test_variants_gpu.py tests/test_fullsize_golden_gpu.py tests/test_sequence_golden_gpu.py tests/test_ycb_gpu.py -q 2>&1 | tail -5
+timeout 300 python scripts/tail_rays.py 2>&1 | grep frame
+PXT_NGP_ROUNDS=2 timeout 300 python scripts/tail_rays.py 2>&1 | grep frame | head -4
