@@ -362,7 +362,7 @@ constexpr int kK = 8;          // samples per ray per round
 // 2: 0.66 / 0.63 / 0.65 / 0.69 / 0.70 / 0.72 / 0.67 / 0.62; **3: 0.66 / 0.61 / 0.64 / 0.68 / 0.70 / 0.71 / 0.67 / 0.62**;
 // 4: 0.66 / 0.61 / 0.65 / 0.70 / 0.69 / 0.71 / 0.69 / 0.63; 5: 0.67 / 0.61 / 0.64 / 0.72 / 0.72 / 0.74 / 0.71 / 0.64; 6: 0.66 /
 // 0.62 / 0.65 / 0.72 / 0.74 / 0.75 / 0.71 / 0.64.  (Rounds 1-2 used 5 with the one-ray-per-lane straggler kernel, which took
-// 0.15-0.45 ms on the views of frames 100-250.)  PXT_NGP_ROUNDS=n (1 .. kMaxRounds) overrides the count: a ray's result
+// 0.15-0.45 ms on the views of frames 100-250.)  PXT_NGP_ROUNDS=n (0 .. kMaxRounds) overrides the count: a ray's result
 // does not depend on it (tests/test_variants_gpu.py).
 constexpr int kRounds = 3, kMaxRounds = 12;
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
@@ -472,8 +472,8 @@ __device__ inline bool probe_cell(const NgpParams& P, const Ray& r, float t, flo
   return inside && ((P.occ[lin >> 3] >> (lin & 7u)) & 1u);
 }
 
-// advance_to_next_voxel: step in dt increments past the border of the (empty) cell at `pos`
-__device__ inline void advance_past_cell(const NgpParams& P, const Ray& r, float& t, const float* pos, int mip) {
+// advance_to_next_voxel's target: where the ray leaves the (empty) cell of cascade `mip` that holds `pos`
+__device__ inline float cell_exit_t(const Ray& r, float t, const float* pos, int mip) {
   const float res = pow2i(7 - mip), ires = pow2i(mip - 7);  // 128 / 2^mip cells per unit
   float tm = INFINITY;
 #pragma unroll
@@ -483,7 +483,12 @@ __device__ inline void advance_past_cell(const NgpParams& P, const Ray& r, float
     const float tx = (floorf(p + 0.5f + 0.5f * sg) - p) * r.idir[a];
     if (r.d[a] != 0.f) tm = fminf(tm, tx);
   }
-  const float t_target = t + fmaxf(tm * ires, 0.f);  // exact: res is a power of two
+  return t + fmaxf(tm * ires, 0.f);  // exact: res is a power of two
+}
+
+// advance_to_next_voxel: step in dt increments past the border of the (empty) cell at `pos`
+__device__ inline void advance_past_cell(const NgpParams& P, const Ray& r, float& t, const float* pos, int mip) {
+  const float t_target = cell_exit_t(r, t, pos, mip);
   do {
     t = t + calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
   } while (t < t_target);
@@ -833,16 +838,18 @@ __device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, b
 // keeps Flo / Fhi on static register indices at 4 waves per SIMD.  Then both MLPs, in-order compositing,
 // termination; lane (rlane, k) handles sample k of the ray in `slot`.  A ray's result does not depend on which
 // rays share its group.
+// (sp, sample_t, exhausted: the lane's sample and whether its ray left the box during the march - from the march's
+// buffers in a wavefront round, straight from the marching lanes' registers in the straggler kernel.)  Returns whether the
+// ray goes on (the same value in the 8 lanes of a ray).
 template <int MODE>
-__device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
-                                                const half8* s_w, unsigned* s_feat,
-                                                const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
-                                                int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples) {
+__device__ __forceinline__ bool ngp_shade_group_core(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
+                                                     const half8* s_w, unsigned* s_feat,
+                                                     const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
+                                                     int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples,
+                                                     const float4 sp, const float sample_t, const bool exhausted) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
   const int sl = ray_ok ? slot : safe_slot;  // lanes beyond the list read a slot that is known to be filled
-  const size_t si = (size_t)sl * kK + k;
-  const float4 sp = Wk.spos[si];
   const float dt = ray_ok ? sp.w : 0.f;
   const bool valid = dt != 0.f;
   const unsigned rid = S.rid[sl];
@@ -884,7 +891,7 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
   float alpha = 0.f;
   if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
   float depth = 0.f;
-  if (MODE != 0) depth = (Wk.st_t[si] * rd.w) * P.depth_scale;
+  if (MODE != 0) depth = (sample_t * rd.w) * P.depth_scale;
   if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
   // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
   float pinc = 1.0f - alpha;
@@ -925,7 +932,6 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
     float accd = 0.f;
     if (MODE == 2) accd = S.accd[slot] + cd;
     const bool terminated = grp != 0;
-    const bool exhausted = Wk.exhausted[slot] != 0;
     if (terminated || exhausted) {
       if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
       finish_ray(Wk, rid, acc, terminated);
@@ -937,6 +943,18 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
       keep_out[slot] = 1;
     }
   }
+  return ray_ok && !(grp != 0 || exhausted);
+}
+
+template <int MODE>
+__device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
+                                                const half8* s_w, unsigned* s_feat,
+                                                const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
+                                                int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples) {
+  const int sl = ray_ok ? slot : safe_slot;
+  const size_t si = (size_t)sl * kK + (threadIdx.x & 7);
+  (void)ngp_shade_group_core<MODE>(P, Wk, S, keep_out, s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, ray_ok, safe_slot,
+                                   n_samples, Wk.spos[si], MODE != 0 ? Wk.st_t[si] : 0.f, Wk.exhausted[sl] != 0);
 }
 
 template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
@@ -969,14 +987,98 @@ __global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const
   }
 }
 
-// Stragglers.  Rays that outlive the wavefront rounds finish here: a WAVE takes 8 of them and repeats the rounds' own two
-// steps - every ray's next K = 8 lattice samples (the lane that owns the ray's first slot marches), then ngp_shade_group on
-// the wave's 8 x 8 samples - until its rays are done: the same arithmetic in the same grouping as a wavefront round, so a
-// ray's result does not depend on how many rounds ran before (any PXT_NGP_ROUNDS gives the same image, bit for bit).
-// (The first version was one ray per LANE with a fused march + encode + MLP step per sample: a wave took max-over-64-lanes
-// steps, and a view along the object's soft shell - 10-14 k rays left, frames 100-250 of the synthetic orbit - spent
-// 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  Its sequential compositing also differed from the rounds' butterfly sums
-// in the last bit.)
+// The next K = 8 samples of the wave's 8 rays, marched by all 64 lanes.  The 8 lanes of a ray probe 8 consecutive
+// lattice points per trip - one dependent occupancy load per 8 points instead of one per point - and then every lane
+// replays ngp_march_kernel's walk over the 8 results (sample / skip to the border of the empty cell / leave the box), so
+// the samples are the serial loop's bit for bit: the lattice t' = t + dt(t) does not depend on what the cells hold.
+// Lane k of a ray returns the ray's k-th sample (dt = 0: none), `t` moves on, `exhausted` = the ray left the box.
+__device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r, bool alive, float& t, float4& sp,
+                                                float& sample_t, bool& exhausted) {
+  const int lane = threadIdx.x & 63, j = lane & 7;
+  int k = 0, have = 0;
+  bool out = false, busy = alive;
+  float pending = -INFINITY;  // a skip that ran past the trip's last point
+  float ts = 0.f;
+  while (__any(busy)) {
+    if (busy) {
+      float tt[9];
+      tt[0] = t;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tt[i + 1] = tt[i] + calc_dt(tt[i], P.cone_angle, P.dt_lo, P.dt_hi);
+      float tj = tt[0];
+      unsigned ge_tmax = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        tj = (j == i) ? tt[i] : tj;
+        ge_tmax |= (tt[i] >= r.tmax ? 1u : 0u) << i;
+      }
+      bool occ = false;
+      float target = -INFINITY;
+      if (tj < r.tmax && tj >= pending) {  // (the walk cannot reach the other points)
+        float pos[3], dt;
+        int mip;
+        occ = probe_cell(P, r, tj, pos, dt, mip);
+        if (!occ) target = cell_exit_t(r, tj, pos, mip);
+      }
+      // an empty point's successor: the first later point at or past the cell's border (advance_past_cell steps at
+      // least once); 8 = beyond this trip
+      int nxt = 8;
+#pragma unroll
+      for (int i = 7; i >= 1; --i) nxt = (i > j && tt[i] >= target) ? i : nxt;
+      unsigned word = (occ ? 8u : (unsigned)(nxt - 1)) << (4 * j);
+      word |= __shfl_xor(word, 1, 8);
+      word |= __shfl_xor(word, 2, 8);
+      word |= __shfl_xor(word, 4, 8);
+      int cur = 8;
+#pragma unroll
+      for (int i = 7; i >= 0; --i) cur = (tt[i] >= pending) ? i : cur;
+      int last_skip = -1, mine = -1;
+      while (cur < 8 && k < kK) {
+        if ((ge_tmax >> cur) & 1u) { out = true; break; }
+        const unsigned nb = (word >> (4 * cur)) & 15u;
+        if (nb & 8u) {
+          if (k == j) mine = cur;
+          ++k; ++cur; last_skip = -1;
+        } else {
+          last_skip = cur;
+          cur = (int)(nb & 7u) + 1;
+        }
+      }
+      float t_cur = tt[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        t_cur = (cur == i) ? tt[i] : t_cur;
+        if (mine == i) { ts = tt[i]; have = 1; }
+      }
+      const float tg = __shfl(target, (lane & ~7) | (last_skip >= 0 ? last_skip : j), 64);
+      pending = (last_skip >= 0 && tt[8] < tg) ? tg : -INFINITY;
+      t = t_cur;  // k == 8: the point after the last sample; otherwise the next trip's first point
+      busy = !out && k < kK;
+    }
+  }
+  sp = make_float4(0.f, 0.f, 0.f, 0.f);
+  sample_t = 0.f;
+  if (have) {
+    sp.x = r.o[0] + ts * r.d[0]; sp.y = r.o[1] + ts * r.d[1]; sp.z = r.o[2] + ts * r.d[2];
+    sp.w = calc_dt(ts, P.cone_angle, P.dt_lo, P.dt_hi);
+    sample_t = ts;
+  }
+  exhausted = out;
+}
+
+// Stragglers.  Rays that outlive the wavefront rounds finish here: a WAVE holds 8 of them and repeats the rounds' own two
+// steps - every ray's next K = 8 lattice samples (ngp_march_group: the ray's 8 lanes probe 8 lattice points at a time), then
+// ngp_shade_group on the wave's 8 x 8 samples, the samples handed over in registers - and replaces a ray that has finished
+// by the next one of its share of the list.  The same arithmetic in the same grouping as a wavefront round, so a ray's result
+// does not depend on how many rounds ran before: any PXT_NGP_ROUNDS, 0 included (the whole render in this kernel), gives
+// the same image bit for bit.  Measured (render_both, ms, frames 0 / 100 / 150 / 200 of the orbit; PXT_NGP_TAIL_GRID
+// workgroups): 3 rounds + 1024: 0.63 0.69 0.68 0.69; 1 round + 4096: 0.65 0.68 0.68 0.68; 0 rounds + 1024 / 2048 / 4096 /
+// 8192: 0.85 0.81 0.76 0.79 / 0.75 0.72 0.68 0.69 / 0.69 0.69 0.65 0.67 / 0.72 0.69 0.66 0.67 - the one-kernel render matches
+// the rounds on the long views and loses 10 % on the short ones, and in the tracking loop (bench.py) 0 / 1 rounds lose 6-12 %.
+// (History: the first version was one ray per LANE with a fused march + encode + MLP step per sample: a wave took
+// max-over-64-lanes steps, and a view along the object's soft shell - 10-14 k rays left, frames 100-250 of the synthetic
+// orbit - spent 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  The second marched with one lane per ray: 0.70-0.72 ms on
+// those views, 0.75-0.80 with one round before it.)
 template <int MODE>
 __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
@@ -996,42 +1098,41 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rlane = lane >> 3, k0 = lane & 7;
   unsigned long long n_samples = 0;
-  for (int base = (blockIdx.x * 4 + wave) * 8; base < n; base += gridDim.x * 4 * 8) {
-    const int slot = base + rlane;
-    bool alive = slot < n;
-    while (__any(alive)) {
-      if (alive && k0 == 0) {  // this ray's next K samples: ngp_march_kernel's loop
-        const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
-        float t = S.t[slot];
-        const size_t s0 = (size_t)slot * kK;
-        int k = 0;
-        bool out = false;
-        while (k < kK) {
-          if (t >= r.tmax) { out = true; break; }
-          float pos[3], dt;
-          int mip;
-          if (probe_cell(P, r, t, pos, dt, mip)) {
-            Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
-            Wk.st_t[s0 + k] = t;
-            t = t + dt;
-            ++k;
-          } else {
-            advance_past_cell(P, r, t, pos, mip);
-          }
+  // A wave's rays: groups wave_id, wave_id + n_waves, ... of 8 consecutive list entries, handed to the wave's 8 ray
+  // positions in that order; a position whose ray has finished takes the next one, so that the wave keeps shading 64
+  // samples per step until its share of the list runs out.  (Shares drawn from a shared counter instead, 64 entries per
+  // atomic: 0.85-1.4 ms per render against 0.63-0.70 - returning atomics on one word are served one per ~100 ns, and the
+  // 4096 waves' first draw alone takes 0.4 ms.  The grid is larger than what is resident instead: the dispatcher is the queue.)
+  const int n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + wave;
+  auto stream_slot = [&](int s) { return ((s >> 3) * n_waves + wave_id) * 8 + (s & 7); };
+  int cursor = 8;
+  int slot = stream_slot(rlane);
+  bool alive = slot < n;
+  float t = alive ? S.t[slot] : 0.f;
+  const int safe = wave_id * 8;  // (the workgroup left above unless this exists)
+  while (__any(alive)) {
+    float4 sp;
+    float sample_t;
+    bool exhausted;
+    {
+      const Ray r = ray_from_record(P, Wk.raydir[S.rid[alive ? slot : safe]]);
+      ngp_march_group(P, r, alive, t, sp, sample_t, exhausted);
+    }
+    alive = ngp_shade_group_core<MODE>(P, Wk, S, keep, s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, alive, safe, n_samples,
+                                       sp, sample_t, exhausted);
+    // refill the free positions, lowest first
+    const unsigned long long dead = __ballot(!alive && k0 == 0);  // bit 8 r: ray position r is free
+    if (dead) {
+      const int rank = __popcll(dead & ((1ull << (rlane * 8)) - 1ull));
+      if (!alive) {
+        const int ns = stream_slot(cursor + rank);
+        if (ns < n) {
+          slot = ns;
+          alive = true;
+          t = S.t[slot];
         }
-        for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        S.t[slot] = t;
-        Wk.exhausted[slot] = out ? 1 : 0;
       }
-      // the samples travel through memory from the marching lane to the wave's other lanes
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      ngp_shade_group<MODE>(P, Wk, S, keep, s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, alive, base, n_samples);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (alive) alive = keep[slot] != 0;
+      cursor += __popcll(dead);
     }
   }
   if (P.stats) {
@@ -1473,18 +1574,19 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
   // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)
   static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : true; }();
+  static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kRounds; }();
+  static const int tail_grid = [] { const char* e = getenv("PXT_NGP_TAIL_GRID"); return e ? atoi(e) : 1024; }();
   const bool counters_clean = ctx->counters_clean;
   ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
   for (int w = 0; w < n_pipe; ++w) {
     if (!counters_clean)
       PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), st[w]));
-    if (fuse_init)  // ray generation + compaction + the first march
+    if (fuse_init && n_rounds > 0)  // ray generation + compaction + the first march
       hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
     else
       hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
   const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
-  static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 1), kMaxRounds) : kRounds; }();
   for (int r = 0; r < n_rounds; ++r) {
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
@@ -1524,11 +1626,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   }
   for (int w = 0; w < n_pipe; ++w) {
     if (mode == 1)
-      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
     else if (mode == 2)
-      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
     else
-      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
   }
   for (int w = 1; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));

@@ -1,4 +1,13 @@
-cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_ngp_gpu.py tests/test_variants_gpu.py tests/test_fullsize_golden_gpu.py tests/test_sequence_golden_gpu.py tests/test_ycb_gpu.py -q 2>&1 | tail -5
-timeout 300 python scripts/tail_rays.py 2>&1 | grep frame
-PXT_NGP_ROUNDS=2 timeout 300 python scripts/tail_rays.py 2>&1 | grep frame | head -4
+#!/bin/bash
+# scratch experiment driver (gpurun)
+cd /root/repo
+for rep in 1 2; do
+for cfg in "3 1024" "3 4096" "2 4096" "1 4096" "0 4096" "0 8192"; do
+    set -- $cfg
+    echo "== rounds=$1 tail_grid=$2"
+    PXT_NGP_ROUNDS=$1 PXT_NGP_TAIL_GRID=$2 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['stage_ms_per_frame']['nerf_render'], d['extras']['value_k200']['frames_per_s'], d['extras']['value_two_renders']['frames_per_s'])"
+done
+done

@@ -1,5 +1,5 @@
 """Rays left for the straggler kernel (after the wavefront rounds) along the synthetic orbit, and the render's time:
-    python scripts/tail_rays.py"""
+    python scripts/tail_rays.py [frame ...]"""
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -15,7 +15,7 @@ assets = make_tracking_assets(seed=1002, n_frames=330)
 tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets)
 cam = Camera.from_colmap(assets["query_camera"])
 tb = tr.testbed
-for i in (0, 30, 60, 100, 150, 200, 250, 300):
+for i in ([int(v) for v in sys.argv[1:]] or (0, 30, 60, 100, 150, 200, 250, 300)):
     Rg, tg = assets["gt_poses"][i]
     wIc = np.eye(4); wIc[:3, :3], wIc[:3, 3] = Rg, tg
     nerf_pose = sfm_to_nerf_pose(assets["nerf2sfm"], np.linalg.inv(wIc))
