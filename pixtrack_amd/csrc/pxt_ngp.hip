@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
 // orbit - spent 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  The second marched with one lane per ray: 0.70-0.72 ms on
 // those views, 0.75-0.80 with one round before it.)
 template <int MODE>
-__global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round) {
+__global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round, int rays_per_wg) {
   __shared__ half8 s_w[kNumFrags * 64];
   __shared__ unsigned s_feat[4 * 8 * 64];
   const int n = Wk.counters[round * kCtrStride];
@@ -1088,7 +1088,12 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
     atomicAdd(P.stats + 1, (unsigned long long)Wk.counters[0]);
     atomicAdd(P.stats + 2, (unsigned long long)n);  // rays left for this kernel
   }
-  if (blockIdx.x * 32 >= n) return;  // (workgroup-uniform: nothing left for this workgroup's four waves)
+  // Workgroups that take part: one per `rays_per_wg` rays, at least gridDim.x / 4.  This kernel's workgroups live as long
+  // as their longest ray, and four of them fill a CU's registers: a full grid of them keeps the OTHER pipeline's next
+  // launches waiting for a slot (its 5-us compaction took 10-90 us beside this kernel), a small one leaves a long list
+  // to too few waves.
+  const int n_wg = min((int)gridDim.x, max((int)gridDim.x / 4, (n + rays_per_wg - 1) / rays_per_wg));
+  if ((int)blockIdx.x >= n_wg || blockIdx.x * 32 >= n) return;  // (workgroup-uniform)
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
   // samples per step until its share of the list runs out.  (Shares drawn from a shared counter instead, 64 entries per
   // atomic: 0.85-1.4 ms per render against 0.63-0.70 - returning atomics on one word are served one per ~100 ns, and the
   // 4096 waves' first draw alone takes 0.4 ms.  The grid is larger than what is resident instead: the dispatcher is the queue.)
-  const int n_waves = gridDim.x * 4, wave_id = blockIdx.x * 4 + wave;
+  const int n_waves = n_wg * 4, wave_id = blockIdx.x * 4 + wave;
   auto stream_slot = [&](int s) { return ((s >> 3) * n_waves + wave_id) * 8 + (s & 7); };
   int cursor = 8;
   int slot = stream_slot(rlane);
@@ -1576,6 +1581,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : true; }();
   static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kRounds; }();
   static const int tail_grid = [] { const char* e = getenv("PXT_NGP_TAIL_GRID"); return e ? atoi(e) : 1024; }();
+  static const int tail_div = [] { const char* e = getenv("PXT_NGP_TAIL_DIV"); return e ? std::max(atoi(e), 1) : 64; }();
   const bool counters_clean = ctx->counters_clean;
   ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
   for (int w = 0; w < n_pipe; ++w) {
@@ -1626,11 +1632,11 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   }
   for (int w = 0; w < n_pipe; ++w) {
     if (mode == 1)
-      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds, tail_div);
     else if (mode == 2)
-      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds, tail_div);
     else
-      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds);
+      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds, tail_div);
   }
   for (int w = 1; w < n_pipe; ++w) {
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));
