@@ -104,7 +104,10 @@ int pxt_lm_refine(const float* p3d, const uint8_t* point_mask /* may be NULL */,
                   float* out /* device, 16+PXT_MAX_LEVELS */, float* log /* device or NULL */,
                   void* workspace /* device, pxt_lm_workspace_bytes() */, void* stream);
 
-/* Bytes of scratch pxt_lm_refine needs (partials + counters), independent of N. */
+/* Bytes of scratch pxt_lm_refine needs (control words + tagged partial sums), independent of N.  One workspace serves
+ * one launch at a time; its content carries over between launches (the tags of a launch continue above those of the
+ * previous one, so nothing is zeroed per launch) and may start as anything - zeroing it once after allocation is tidy,
+ * not required. */
 int64_t pxt_lm_workspace_bytes(void);
 
 /* -------------------------------------------------------------------------

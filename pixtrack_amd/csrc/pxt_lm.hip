@@ -458,6 +458,12 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
   __syncthreads();
 
   unsigned epoch = 0;
+  // Tags continue where the workspace's previous launch stopped (control word 1, advanced by workgroup 0 at the end of
+  // every launch - which it reaches only after every workgroup has published, hence read this word, at least once): what
+  // earlier launches left in the granule areas never carries a tag of this one, so nothing has to be zeroed between
+  // launches (the memset node before every launch was 5 us + a dependent-launch gap on the frame's serial chain).
+  const unsigned base = ld_relaxed_u32(P.err + 1);
+  const unsigned launch_id = base + 1u;  // what the error word holds when THIS launch timed out
   int total_iters = 0;
   bool failed = false;
   bool aborted = false;
@@ -497,11 +503,11 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
       // drain, no counter, no fence; EVERY workgroup then sweeps all G x 32 granules of this epoch (a few per
       // thread) until every tag matches, so an iteration's only inter-workgroup traffic is one store and one (re-read)
       // load round trip.  (The first version - partials, drain, arrive on a counter, spin, all-gather - was four
-      // dependent round trips, 8.1k of a 23k-cycle iteration; stamps.)  The granule area is zeroed by the
-      // launch's memset node, tags count from 1 within the call, two areas alternate by epoch parity (a
+      // dependent round trips, 8.1k of a 23k-cycle iteration; stamps.)  Tags count on from the workspace's previous
+      // launch (`base`), two areas alternate by epoch parity (a
       // workgroup publishes epoch e + 1 only after it has read every granule of epoch e).
       unsigned long long* const area = P.granules + (size_t)(epoch & 1u) * G * kNAcc;
-      const unsigned long long tag = (unsigned long long)(epoch + 1u) << 32;
+      const unsigned long long tag = (unsigned long long)(base + epoch + 1u) << 32;
       {  // the workgroup's own sums, in a fixed order: 16 strided partials per slot, then the 16 in sequence
         const int slot = tid & (kNAcc - 1), part = tid >> 5;
         float s = 0.f;
@@ -543,8 +549,8 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
               break;
             }
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit || (((spins & 255u) == 0u) && ld_relaxed_u32(P.err) != 0u)) {
-              __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > kSpinLimit || (((spins & 255u) == 0u) && ld_relaxed_u32(P.err) == launch_id)) {
+              __hip_atomic_store(P.err, launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               s_flags[2] = 1;  // (benign race: every writer stores 1)
               i0 = n_gran;
               break;
@@ -620,6 +626,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
   }
 
   if (blockIdx.x == 0 && tid == 0) {
+    P.err[1] = base + epoch + 1u;  // the next launch's tags start above every tag of this one
     for (int i = 0; i < 12; ++i) P.out[i] = s_T[i];
     P.out[12] = failed ? 1.f : 0.f;
     P.out[13] = aborted ? (float)PXT_E_TIMEOUT : 0.f;
@@ -795,9 +802,7 @@ extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_
     if (grid > resident_cap[dev_id]) grid = resident_cap[dev_id];
   }
   hipStream_t s = (hipStream_t)stream;
-  // every polled word is zeroed before every launch (tags count from 1 within the call): the granules of
-  // the `grid` workgroups in both areas, and the error word
-  PXT_HIP_CHECK(hipMemsetAsync(ws, 0, 256 + (size_t)2 * grid * kNAcc * sizeof(unsigned long long), s));
+  // (no memset: the polled words - granule tags, error word - are compared with values only this launch writes)
   hipLaunchKernelGGL(lm_refine_kernel, dim3(grid), dim3(kLmBlock), 0, s, P);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
