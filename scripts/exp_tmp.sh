@@ -1,13 +1,13 @@
 #!/bin/bash
 # scratch experiment driver (gpurun)
 cd /root/repo
-run() { printf "%-44s" "[$1]"; PXT_CONV_PLAN="$1" python scripts/unet_pass_timeline.py 2>&1 | grep "host ahead" | sed 's/two-image pass, host ahead://'; }
-run ""
-for c in "22:1" "22:2" "23:1" "23:2" "24:1" "24:2" "24:4" "18:2" "18:4"; do
-  cfg=${c%%:*}; sp=${c##*:}
-  run "10:$cfg:$sp;11:$cfg:$sp;12:$cfg:$sp"
+for rep in 1 2; do
+for cfg in "2 2048" "3 2048" "3 1024" "4 1024" "4 2048"; do
+    set -- $cfg
+    echo "== pipes=$1 shade_grid=$2"
+    PXT_NGP_PIPES=$1 PXT_NGP_SHADE_GRID=$2 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['stage_ms_per_frame']['nerf_render'], d['extras']['value_k200']['frames_per_s'], d['extras']['value_two_renders']['frames_per_s'])"
 done
-run ""
-# 60x80 layers (7 = 256->512 no pool, 8 = 512->512, 9 = 512->512 pooled output)
-for c in "22:1" "23:1" "24:1"; do cfg=${c%%:*}; sp=${c##*:}; run "7:$cfg:$sp;8:$cfg:$sp"; done
-run ""
+done
