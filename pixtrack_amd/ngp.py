@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from enum import IntEnum
 from typing import Dict, Optional
@@ -325,6 +326,7 @@ class Testbed:
         self.render_mode = RenderMode.Shade
         self._cam_ngp = np.eye(4)[:3]
         self._ctx = None
+        self._ctx_side = None  # a second renderer context over the same snapshot (see _side_ctx_int)
         self._snap: Optional[NerfSnapshot] = None
         self._stats = None
         self.stats_accum = None
@@ -349,16 +351,14 @@ class Testbed:
 
     def __del__(self):
         try:
-            if self._ctx:
-                _lib.lib().pxt_ngp_destroy(self._ctx)
-                self._ctx = None
+            for name in ("_ctx", "_ctx_side"):
+                if getattr(self, name, None):
+                    _lib.lib().pxt_ngp_destroy(getattr(self, name))
+                    setattr(self, name, None)
         except Exception:
             pass
 
-    def load_snapshot(self, path_or_snapshot):
-        snap = path_or_snapshot if isinstance(path_or_snapshot, NerfSnapshot) else load_snapshot_file(str(path_or_snapshot))
-        if self.device.type != "cuda":
-            raise _lib.PxtError("the NeRF renderer needs a ROCm device; no CPU path exists")
+    def _create_ctx(self, snap: NerfSnapshot):
         L = _lib.lib()
         model = _lib.NgpModel(snap.n_levels, snap.n_features, snap.log2_hashmap, snap.base_res, snap.per_level_scale,
                               snap.cascades, snap.aabb_scale, snap.cone_angle, 1.0 / snap.scale)
@@ -370,10 +370,31 @@ class Testbed:
             _lib.check(
                 L.pxt_ngp_create(C.byref(model), grid.ctypes.data, grid.size, mlp.ctypes.data, mlp.size,
                                  occ.ctypes.data, occ.size, C.byref(ctx)), "pxt_ngp_create")
-        if self._ctx:
-            L.pxt_ngp_destroy(self._ctx)
+        return ctx
+
+    def load_snapshot(self, path_or_snapshot):
+        snap = path_or_snapshot if isinstance(path_or_snapshot, NerfSnapshot) else load_snapshot_file(str(path_or_snapshot))
+        if self.device.type != "cuda":
+            raise _lib.PxtError("the NeRF renderer needs a ROCm device; no CPU path exists")
+        ctx = self._create_ctx(snap)
+        for name in ("_ctx", "_ctx_side"):
+            if getattr(self, name):
+                _lib.lib().pxt_ngp_destroy(getattr(self, name))
+                setattr(self, name, None)
         self._ctx, self._snap = ctx, snap
         self.nerf.cone_angle_constant = snap.cone_angle
+
+    def _side_ctx_int(self) -> int:
+        """A second context over the same snapshot (its own scratch, counters and camera slot; the 30-MB tables are
+        duplicated): two renders of DIFFERENT views - the tracker's mask at the query camera and its reference image at
+        the reference camera - run side by side on two streams, each as one pipeline, instead of one after the other
+        as two pipelines each.  Same images bit for bit (a ray's result does not depend on the pipeline count)."""
+        assert self._snap is not None, "load_snapshot first"
+        if self._ctx_side is None:
+            self._ctx_side = self._create_ctx(self._snap)
+            _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx_side, 1), "pxt_ngp_set_pipelines")
+        c = self._ctx_side
+        return int(c.value) if hasattr(c, "value") else int(c)
 
     def set_nerf_camera_matrix(self, nerf_c2w_3x4):
         assert self._snap is not None, "load_snapshot first"
@@ -394,8 +415,9 @@ class Testbed:
         return v
 
     def render_device(self, width: int, height: int, spp: int = 8, linear: bool = True,
-                      collect_stats: bool = False) -> torch.Tensor:
-        """float32 [H, W, 4] on the device, linear premultiplied RGBA."""
+                      collect_stats: bool = False, side: bool = False, pipelines: int = 0) -> torch.Tensor:
+        """float32 [H, W, 4] on the device, linear premultiplied RGBA.  ``side`` / ``pipelines``: as
+        render_from_pose_device (two renders of different views side by side on two streams)."""
         assert linear, "pixtrack renders with linear=True (run_vis_on_poses.py:51)"
         assert self._ctx is not None, "load_snapshot first"
         if not self.snap_to_pixel_centers:
@@ -404,8 +426,15 @@ class Testbed:
         stats = self.stats_accum  # running totals across launches when set (bench)
         if collect_stats:
             stats = torch.zeros(4, dtype=torch.int64, device=self.device)
-        ops.ngp_render(self._ctx_int(), self._view_for(width, height), int(width), int(height), int(spp),
-                       int(self.render_mode), out, stats)
+        ctx = self._side_ctx_int() if side else self._ctx_int()
+        if pipelines and not side:
+            _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, int(pipelines)), "pxt_ngp_set_pipelines")
+        try:
+            ops.ngp_render(ctx, self._view_for(width, height), int(width), int(height), int(spp),
+                           int(self.render_mode), out, stats)
+        finally:
+            if pipelines and not side:
+                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, 0), "pxt_ngp_set_pipelines")
         if collect_stats:
             self._stats = stats
         self.n_renders += 1
@@ -450,16 +479,26 @@ class Testbed:
         self.n_renders += 1
         return rgba, depth, cam_out
 
-    def render_from_pose_device(self, width: int, height: int, spp: int, pose_record: torch.Tensor, conv: list):
+    def render_from_pose_device(self, width: int, height: int, spp: int, pose_record: torch.Tensor, conv: list,
+                                side: bool = False, pipelines: int = 0):
         """render_device (in the current render_mode) for a pose that is still on the device; see
-        render_both_from_pose_device.  Returns (rgba, cam_out)."""
+        render_both_from_pose_device.  Returns (rgba, cam_out).  ``side``: through the second context
+        (_side_ctx_int; the caller puts the call on another stream); ``pipelines``: ray slices rendered side by
+        side by THIS call (0 = the default)."""
         assert self._ctx is not None, "load_snapshot first"
         if not self.snap_to_pixel_centers:
             raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
         out = torch.empty(height, width, 4, device=self.device, dtype=torch.float32)
         cam_out = self._next_cam_out()
-        ops.ngp_render_both_from_pose(self._ctx_int(), self._view_for(width, height), pose_record, conv, int(width),
-                                      int(height), int(spp), int(self.render_mode), out, None, cam_out, self.stats_accum)
+        ctx = self._side_ctx_int() if side else self._ctx_int()
+        if pipelines and not side:
+            _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, int(pipelines)), "pxt_ngp_set_pipelines")
+        try:
+            ops.ngp_render_both_from_pose(ctx, self._view_for(width, height), pose_record, conv, int(width),
+                                          int(height), int(spp), int(self.render_mode), out, None, cam_out, self.stats_accum)
+        finally:
+            if pipelines and not side:
+                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, 0), "pxt_ngp_set_pipelines")
         self.n_renders += 1
         return out, cam_out
 

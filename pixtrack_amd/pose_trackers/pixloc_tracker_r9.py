@@ -283,6 +283,22 @@ class PixLocPoseTrackerR9(PoseTracker):
             self.testbed.set_nerf_camera_matrix(np.asarray(self._nerf_pose(pose))[:3, :])
             rgba, depth = self.testbed.render_both_device(width, height, self.spp)
             self._fused_reference = (pose, rgba_to_u8(rgba, 0.0))
+        elif os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0":
+            # the frame's two renders - this mask's depth at the query camera, the reference image at the reference
+            # camera (get_reference_image is asked for it at the same pose next) - side by side on two streams
+            main, side = self._two_streams()
+            self._ahead_fork.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(self._ahead_fork)
+                rgba = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self._reference_camera(), spp=self.spp,
+                                             side=True)
+                ref_u8 = rgba_to_u8(rgba, 0.0)
+                self._ahead_join.record(side)
+            ref_u8.record_stream(main)
+            depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp,
+                                          pipelines=1)
+            main.wait_event(self._ahead_join)
+            self._fused_reference = (pose, ref_u8)
         else:
             depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp)
         H, W = int(depth.shape[0]), int(depth.shape[1])
@@ -292,6 +308,13 @@ class PixLocPoseTrackerR9(PoseTracker):
         return mask
 
     # ------------------------------------------------------------------ the next frame's render, ahead of the host
+    def _two_streams(self):
+        """(current stream, the stream the second of a frame's two renders runs on) + the fork / join events."""
+        if self.__dict__.get("_ahead_stream") is None:
+            self._ahead_stream = torch.cuda.Stream(self.device)
+            self._ahead_fork, self._ahead_join = torch.cuda.Event(), torch.cuda.Event()
+        return torch.cuda.current_stream(self.device), self._ahead_stream
+
     def _render_ahead(self, pending):
         """Called between the LM launch and the wait for its result: the mask + reference render of the NEXT frame,
         whose camera a one-thread kernel derives from the LM kernel's pose record on the device."""
@@ -313,21 +336,44 @@ class PixLocPoseTrackerR9(PoseTracker):
             rgba, depth, cam_out = self.testbed.render_both_from_pose_device(width, height, spp, pending.buf, conv)
             cams = [cam_out]
         else:  # two renders: Depth with the query camera, Shade with SfM camera 1 x reference_scale (:145-152, :207-214)
-            width, height, self.testbed.fov = fov_of(self.camera)
+            # ... side by side: the reference image on a second stream through the testbed's second context, the mask's
+            # depth on this one, one pipeline each (PXT_AHEAD_TWO_STREAMS=0: one after the other, two pipelines each)
+            width, height, fov_q = fov_of(self.camera)
+            rw, rh, fov_r = fov_of(self._reference_camera())
+            self.testbed.fov = fov_q
             views = [self._ahead_view_key(width, height, spp)]
+            self.testbed.fov = fov_r
+            views.append(self._ahead_view_key(rw, rh, spp))
+            two = os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0"
+            if two:
+                main, _ = self._two_streams()
+                self._ahead_fork.record(main)  # behind the LM launch
+                with torch.cuda.stream(self._ahead_stream):
+                    self._ahead_stream.wait_event(self._ahead_fork)
+                    self.testbed.fov = fov_r
+                    rgba, cam_ref = self.testbed.render_from_pose_device(rw, rh, spp, pending.buf, conv, side=True)
+                    ref_u8 = rgba_to_u8(rgba, 0.0)
+                    self._ahead_join.record(self._ahead_stream)
+                ref_u8.record_stream(main)
+            self.testbed.fov = fov_q
             self.testbed.render_mode = self.testbed.render_mode.Depth
             try:
-                depth, cam_out = self.testbed.render_from_pose_device(width, height, spp, pending.buf, conv)
+                depth, cam_out = self.testbed.render_from_pose_device(width, height, spp, pending.buf, conv,
+                                                                      pipelines=1 if two else 0)
             finally:
                 self.testbed.render_mode = self.testbed.render_mode.Shade
-            rw, rh, self.testbed.fov = fov_of(self._reference_camera())
-            views.append(self._ahead_view_key(rw, rh, spp))
-            rgba, cam_ref = self.testbed.render_from_pose_device(rw, rh, spp, pending.buf, conv)
+            if not two:
+                self.testbed.fov = fov_r
+                rgba, cam_ref = self.testbed.render_from_pose_device(rw, rh, spp, pending.buf, conv)
+                ref_u8 = rgba_to_u8(rgba, 0.0)
             cams = [cam_out, cam_ref]  # both records stay referenced until their kernels have been observed
-        ref_u8 = rgba_to_u8(rgba, 0.0)
+        if self._views_coincide():
+            ref_u8 = rgba_to_u8(rgba, 0.0)
         mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
         tmp = torch.empty(2 * height * width, dtype=torch.uint8, device=self.device)
         ops.depth_mask(depth, 1, 5, mask, tmp)
+        if self.__dict__.get("_ahead_stream") is not None and not self._views_coincide():
+            torch.cuda.current_stream(self.device).wait_event(self._ahead_join)  # (a no-op if nothing was recorded since)
         self._ahead = (cams, mask, ref_u8, views)
 
     def _ahead_view_key(self, width, height, spp):

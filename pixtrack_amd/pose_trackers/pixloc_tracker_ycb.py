@@ -100,6 +100,11 @@ class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
             self.relocalize(query_path)
             self.cold_start = False
         refiner.query_mask = self.get_mask(self.pose)  # every frame
+        # the next frame's mask + reference renders need only this frame's pose: queued behind the LM launch, used next
+        # frame if the pose is accepted and the host arrives at the same camera (pixloc_tracker_r9._render_ahead)
+        steady = self.render_ahead and list(refiner.conf.multiscale or [1]) == [1] and len(self.reference_ids) == 1
+        self._ahead = None
+        refiner.after_lm_enqueued = self._render_ahead if steady else None
 
         self.dynamic_id = self.get_dynamic_id(self.pose)
         rotation, translation = self.pose.numpy()
@@ -126,6 +131,8 @@ class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
             self.pose = ret["T_refined"]
         ret["success"] = success
         self.success = success
+        refiner.after_lm_enqueued = None
+        self._verify_render_ahead(success)
         img_name = os.path.basename(str(query_path))
         self.pose_history[img_name] = ret
         self.pose_tracker_history[img_name] = trackers[best_ref_id]

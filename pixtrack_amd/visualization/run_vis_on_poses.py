@@ -13,7 +13,7 @@ from ..ops import ops
 
 
 def get_nerf_image_device(testbed, nerf_pose, camera, depth: bool = False, alpha_thresh: float = 0.0,
-                          spp: int = 8):
+                          spp: int = 8, **render_kw):
     """Renders at ``camera``'s size with fov from fx (cx, cy, fy ignored: reference quirk
     Appendix D.5).  Returns the float32 RGBA frame [H,W,4] left on the device; ``alpha_thresh``
     is applied by ``rgba_to_u8`` (kept in the signature for parity with get_nerf_image)."""
@@ -26,7 +26,7 @@ def get_nerf_image_device(testbed, nerf_pose, camera, depth: bool = False, alpha
     if depth:
         testbed.render_mode = testbed.render_mode.Depth
     try:
-        rgba = testbed.render_device(width, height, spp, True)
+        rgba = testbed.render_device(width, height, spp, True, **render_kw)
     finally:
         if depth:
             testbed.render_mode = testbed.render_mode.Shade

@@ -54,14 +54,16 @@ def test_device_camera_and_render_equal_the_host_path(device):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_tracking_is_identical_with_and_without_render_ahead(device, fused):
+def test_tracking_is_identical_with_and_without_render_ahead(device, fused, monkeypatch):
     n = 14
     assets = make_tracking_assets(seed=1002, width=320, height=240, n_frames=n)
     hist = {}
-    for ahead in (False, True):
+    # "serial": the two renders of the unfused case one after the other instead of side by side on two streams
+    for ahead in (False, True) + (() if fused else ("serial",)):
+        monkeypatch.setenv("PXT_AHEAD_TWO_STREAMS", "0" if ahead == "serial" else "1")
         tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
         tr.fuse_identical_views = fused  # False: mask and reference image are two renders (the real-asset case)
-        tr.render_ahead = ahead
+        tr.render_ahead = bool(ahead)
         frames = render_query_frames(assets, tr.testbed)
         for i in range(n):
             tr.run_single_frame((f"{i:06d}.png", frames[i]))
@@ -70,6 +72,8 @@ def test_tracking_is_identical_with_and_without_render_ahead(device, fused):
         if ahead:
             assert tr.renders_ahead_used >= n - 3
     assert np.array_equal(hist[False], hist[True])
+    if not fused:
+        assert np.array_equal(hist[False], hist["serial"])
 
 
 def test_a_queued_render_is_not_used_after_the_view_settings_changed(device):
