@@ -21,8 +21,8 @@ kernel's launches of every 4th render, one sample-count atomic per workgroup); p
 and the dominant kernel's isolated timing come from a separate untimed pass over the next 20
 frames.  The per-frame cost varies along the synthetic orbit (longer rays as the object turns:
 render 0.66 ms on the first frames, 0.70-0.79 later), so `value` depends a little on K: 647-670
-frames/s at the driver's K = 20, 642-651 over the 200 frames that follow (`extras.value_k200`);
-`extras.value_two_renders` (511-528) is the real-asset case in which the mask and the reference
+frames/s at the driver's K = 20, 642-655 over the 200 frames that follow (`extras.value_k200`);
+`extras.value_two_renders` (543-557) is the real-asset case in which the mask and the reference
 image need two renders.  The pool's boxes differ by ~5 % for one commit.
 
 N > 1 without a launcher (`python bench.py --gpus 8`) spawns its own N ranks under
