@@ -174,6 +174,16 @@ int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* i
                            float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
                            void* workspace, void* stream);
 
+/* Two images of possibly DIFFERENT sizes (H[i] x W[i]) as two single-image passes side by side on two streams - a frame's
+ * reference render (reference camera x reference_scale, pixloc_pose_refiners.py:145-152) and its masked query
+ * (feature_extractor.py:48 twice per frame).  Arguments as pxt_unet_forward_batch with n_images = 2; out_maps[3 i + k];
+ * workspace >= pxt_unet_workspace_bytes_pair. */
+int64_t pxt_unet_workspace_bytes_pair(const pxt_unet* ctx, const int32_t H[2], const int32_t W[2]);
+int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, const int32_t* image_is_u8,
+                          const uint8_t* const* masks, const int32_t H[2], const int32_t W[2],
+                          float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
+                          void* workspace, void* stream);
+
 /* One 3x3 convolution (pad 1) of the pyramid as a stand-alone call, for layer-by-layer
  * parity tests against torch.nn.functional.conv2d (SURVEY KAT-6) and for profiling:
  * in  [H][W][Cin]  fp16 NHWC (Cin % 32 == 0), weights [Cout][3][3][Cin] fp16

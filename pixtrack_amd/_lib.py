@@ -126,6 +126,12 @@ PROTOTYPES = {
         [_VP, _I32, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_VP), _I32, _I32, C.POINTER(_VP), C.POINTER(_I32),
          C.POINTER(_I32), _VP, _VP],
     ),
+    "pxt_unet_workspace_bytes_pair": (_I64, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "pxt_unet_forward_pair": (
+        C.c_int,
+        [_VP, C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_VP), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_VP),
+         C.POINTER(_I32), C.POINTER(_I32), _VP, _VP],
+    ),
     "pxt_conv3x3_nhwc_f16": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _I32, _I32, _VP, _VP]),
     "pxt_conv3x3_packed_bytes": (_I64, [_I32, _I32]),
     "pxt_conv3x3_pack_weights": (C.c_int, [_VP, _I32, _I32, _VP, _VP]),

@@ -785,7 +785,7 @@ extern "C" int64_t pxt_unet_workspace_bytes_batch(const pxt_unet* ctx, int32_t n
   Plan P, P1;
   if (!make_plan(ctx, n_images, H, W, P) || !make_plan(ctx, 1, H, W, P1)) return 0;
   // (a batch of two may run as two single-image passes in the two halves of the workspace)
-  return (int64_t)std::max(P.total, (size_t)n_images * P1.total);
+  return (int64_t)std::max(P.total, (size_t)n_images * ((P1.total + 255) / 256 * 256));
 }
 
 extern "C" int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W) {
@@ -966,8 +966,28 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   if (n_images != 2 || n_streams < 2)
     return forward_pass(ctx, n_images, images, image_is_u8, masks, H, W, out_maps, out_cstride, normalize, workspace,
                         stream, ctx->sides[0]);
-  Plan P1;
-  if (!make_plan(ctx, 1, H, W, P1)) return PXT_E_ARG;
+  const int32_t Hs[2] = {H, H}, Ws[2] = {W, W};
+  return pxt_unet_forward_pair(ctx, images, image_is_u8, masks, Hs, Ws, out_maps, out_cstride, normalize, workspace, stream);
+}
+
+extern "C" int64_t pxt_unet_workspace_bytes_pair(const pxt_unet* ctx, const int32_t H[2], const int32_t W[2]) {
+  if (!ctx || !H || !W) return PXT_E_ARG;
+  Plan P0, P1;
+  if (!make_plan(ctx, 1, H[0], W[0], P0) || !make_plan(ctx, 1, H[1], W[1], P1)) return 0;
+  return (int64_t)((P0.total + 255) / 256 * 256 + P1.total);
+}
+
+// Two images of (possibly) DIFFERENT sizes as two single-image passes side by side: the first on the caller's stream, the
+// second on a side stream, in two parts of the workspace.  (The frame's reference render and its masked query: equal sizes
+// in the benchmark, different ones with real assets - reference camera x 0.5 / x 0.3 - where the two passes used to run
+// one after the other: 0.54 + 0.54 ms against 0.72 ms side by side.)
+extern "C" int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, const int32_t* image_is_u8,
+                                     const uint8_t* const* masks, const int32_t H[2], const int32_t W[2],
+                                     float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
+                                     void* workspace, void* stream) {
+  if (!ctx || !images || !image_is_u8 || !H || !W || !out_maps || !out_cstride || !normalize || !workspace) return PXT_E_ARG;
+  Plan P0, P1;
+  if (!make_plan(ctx, 1, H[0], W[0], P0) || !make_plan(ctx, 1, H[1], W[1], P1)) return PXT_E_ARG;
   if (!ctx->pass2) {
     ctx->pass2 = pxt::shared_side_stream(0);
     if (!ctx->pass2) return PXT_E_HIP;
@@ -979,9 +999,10 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   PXT_HIP_CHECK(hipStreamWaitEvent(ctx->pass2, ctx->ev_fork, 0));
   const uint8_t* const no_mask[1] = {nullptr};
   struct Peers { Peers() { g_conv_peers = 2; } ~Peers() { g_conv_peers = 1; } } peers_guard;
+  const size_t second = (P0.total + 255) / 256 * 256;
   for (int im = 0; im < 2; ++im) {
-    int rc = forward_pass(ctx, 1, images + im, image_is_u8 + im, masks ? masks + im : no_mask, H, W, out_maps + 3 * im,
-                          out_cstride, normalize + im, (char*)workspace + (size_t)im * P1.total,
+    int rc = forward_pass(ctx, 1, images + im, image_is_u8 + im, masks ? masks + im : no_mask, H[im], W[im], out_maps + 3 * im,
+                          out_cstride, normalize + im, (char*)workspace + (im ? second : 0),
                           im == 0 ? (void*)s : (void*)ctx->pass2, ctx->sides[im]);
     if (rc != PXT_OK) return rc;
   }

@@ -59,8 +59,8 @@ class PixTrackFeatureExtractor:
               normalize: bool = False) -> None:
         """Announces an extraction that WILL be requested next with exactly these arguments (the
         frame's masked query, known before the reference render is encoded).  The next
-        extract_packed of an equally sized image then runs both through the UNet in one batched
-        pass (pxt_unet_forward_batch) and keeps the staged result for the announced call.  Purely
+        extract_packed then runs both images through the UNet side by side
+        (pxt_unet_forward_batch, or pxt_unet_forward_pair when their sizes differ) and keeps the staged result for the announced call.  Purely
         a scheduling hint: results are those of separate calls up to fp32 summation order."""
         self._staged = (image, scale_image, mask, normalize)
         self._ready = None
@@ -88,7 +88,7 @@ class PixTrackFeatureExtractor:
             if st_image is not image:
                 a_img, a_mask, a_same, a_sr = self._prepare(image, scale_image, mask)
                 b_img, b_mask, b_same, b_sr = self._prepare(st_image, st_scale, st_mask)
-                if a_same and b_same and a_img.shape == b_img.shape:
+                if a_same and b_same:  # (equal sizes: one batched call; two sizes: the pair entry - both side by side)
                     both = self.model.forward_packed_batch([(a_img, a_mask, normalize), (b_img, b_mask, st_norm)])
                     self._ready = (st_image, st_scale, st_mask, st_norm, both[1],
                                    [(b_sr[0] / s, b_sr[1] / s) for s in self.model.scales])

@@ -146,17 +146,23 @@ def _unet_forward_batch(ctx, images, masks, normalize, outs, workspace):
     n = len(images)
     if n == 0 or len(masks) != n or len(normalize) != n or len(outs) != 3 * n:
         raise _lib.PxtError("unet_forward_batch: per image one mask slot, one normalize flag and three output maps")
-    H, W = int(images[0].shape[0]), int(images[0].shape[1])
-    for im, mk in zip(images, masks):
+    sizes = [(int(im.shape[0]), int(im.shape[1])) for im in images]
+    H, W = sizes[0]
+    # two images of different sizes (a frame's reference render and its query with real assets): two single-image
+    # passes side by side (pxt_unet_forward_pair); any other batch holds images of one size
+    pair = n == 2 and sizes[1] != sizes[0]
+    for im, mk, hw in zip(images, masks, sizes):
         if im.dim() != 3 or im.shape[2] != 3 or not im.is_contiguous() or im.dtype not in (torch.float32, torch.uint8):
             raise _lib.PxtError("unet_forward_batch: images are contiguous HWC, 3 channels, float32 or uint8")
-        if (int(im.shape[0]), int(im.shape[1])) != (H, W):
-            raise _lib.PxtError("unet_forward_batch: a batch holds images of one size")
-        if mk is not None and (mk.dtype != torch.uint8 or tuple(mk.shape) != (H, W) or not mk.is_contiguous()):
+        if hw != (H, W) and not pair:
+            raise _lib.PxtError("unet_forward_batch: a batch of more than two holds images of one size")
+        if mk is not None and (mk.dtype != torch.uint8 or tuple(mk.shape) != hw or not mk.is_contiguous()):
             raise _lib.PxtError("unet_forward_batch: masks are contiguous uint8 [H, W]")
-    need = int(L.pxt_unet_workspace_bytes_batch(ctx, n, H, W))
+    Hs = (C.c_int32 * 2)(sizes[0][0], sizes[-1][0])
+    Ws = (C.c_int32 * 2)(sizes[0][1], sizes[-1][1])
+    need = int(L.pxt_unet_workspace_bytes_pair(ctx, Hs, Ws)) if pair else int(L.pxt_unet_workspace_bytes_batch(ctx, n, H, W))
     if need <= 0:
-        raise _lib.PxtError(f"image {H}x{W} (batch {n}) is not supported by the 4-level encoder")
+        raise _lib.PxtError(f"images {sizes} are not supported by the 4-level encoder")
     if workspace.numel() * workspace.element_size() < need:
         raise _lib.PxtError(f"unet_forward_batch: workspace holds {workspace.numel()} bytes, {need} needed")
     for o in outs:
@@ -167,8 +173,12 @@ def _unet_forward_batch(ctx, images, masks, normalize, outs, workspace):
     norm = (C.c_int32 * n)(*[int(bool(x)) for x in normalize])
     ptrs = (C.c_void_p * (3 * n))(*[o.data_ptr() for o in outs])
     cs = (C.c_int32 * 3)(*[int(o.shape[2]) for o in outs[:3]])
-    _lib.check(L.pxt_unet_forward_batch(ctx, n, imgs, is_u8, mks, H, W, ptrs, cs, norm, workspace.data_ptr(),
-                                        _stream(images[0])), "pxt_unet_forward_batch")
+    if pair:
+        _lib.check(L.pxt_unet_forward_pair(ctx, imgs, is_u8, mks, Hs, Ws, ptrs, cs, norm, workspace.data_ptr(),
+                                           _stream(images[0])), "pxt_unet_forward_pair")
+    else:
+        _lib.check(L.pxt_unet_forward_batch(ctx, n, imgs, is_u8, mks, H, W, ptrs, cs, norm, workspace.data_ptr(),
+                                            _stream(images[0])), "pxt_unet_forward_batch")
 
 
 def _conv3x3(x, weight, bias, relu, out):

@@ -100,6 +100,11 @@ class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
             self.relocalize(query_path)
             self.cold_start = False
         refiner.query_mask = self.get_mask(self.pose)  # every frame
+        # the masked query is fully known here: announce it so that it goes through the UNet beside the reference render
+        if self.batch_frame_images and list(refiner.conf.multiscale or [1]) == [1]:
+            refiner.feature_extractor.stage(query_image, 1, refiner.query_mask, True)
+        else:
+            refiner.feature_extractor.unstage()
         # the next frame's mask + reference renders need only this frame's pose: queued behind the LM launch, used next
         # frame if the pose is accepted and the host arrives at the same camera (pixloc_tracker_r9._render_ahead)
         steady = self.render_ahead and list(refiner.conf.multiscale or [1]) == [1] and len(self.reference_ids) == 1

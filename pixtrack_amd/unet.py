@@ -262,20 +262,24 @@ class UNet:
         return self.forward_packed_batch([(image, mask, normalize)])[0]
 
     def forward_packed_batch(self, items) -> List[List[torch.Tensor]]:
-        """items: [(image, mask or None, normalize)], images of one size -> per image the three
-        maps of forward_packed, from ONE set of launches (pxt_unet_forward_batch)."""
+        """items: [(image, mask or None, normalize)], images of one size (or exactly two of different sizes) -> per
+        image the three maps of forward_packed (pxt_unet_forward_batch / pxt_unet_forward_pair)."""
         n = len(items)
-        H, W = int(items[0][0].shape[0]), int(items[0][0].shape[1])
+        sizes = [(int(it[0].shape[0]), int(it[0].shape[1])) for it in items]
+        H, W = sizes[0]
         for image, _mask, _ in items:
             _lib.require_gpu(image, "image")
-        need = int(_lib.lib().pxt_unet_workspace_bytes_batch(self._ctx, n, H, W))
+        if n == 2 and sizes[1] != sizes[0]:  # two sizes: two single-image passes side by side (pxt_unet_forward_pair)
+            Hs, Ws = (C.c_int32 * 2)(sizes[0][0], sizes[1][0]), (C.c_int32 * 2)(sizes[0][1], sizes[1][1])
+            need = int(_lib.lib().pxt_unet_workspace_bytes_pair(self._ctx, Hs, Ws))
+        else:
+            need = int(_lib.lib().pxt_unet_workspace_bytes_batch(self._ctx, n, H, W))
         if need <= 0:
-            raise _lib.PxtError(f"image {H}x{W} (batch {n}) is not supported by the 4-level encoder")
+            raise _lib.PxtError(f"images {sizes} are not supported by the 4-level encoder")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        shapes = self.level_shapes(H, W)
         outs = [[torch.empty(h, w, cstride_for(c), device=self.device, dtype=torch.float32)
-                 for (h, w), c in zip(shapes, OUTPUT_DIMS)] for _ in range(n)]
+                 for (h, w), c in zip(self.level_shapes(*hw), OUTPUT_DIMS)] for hw in sizes]
         ops.unet_forward_batch(int(self._ctx.value), [it[0] for it in items], [it[1] for it in items],
                                [bool(it[2]) for it in items], [o for per in outs for o in per], self._ws)
         return outs

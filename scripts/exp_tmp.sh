@@ -1,5 +1,9 @@
 #!/bin/bash
 # scratch experiment driver (gpurun)
 cd /root/repo
-timeout 900 python -m pytest tests/test_ycb_gpu.py tests/test_render_ahead_gpu.py -q -x 2>&1 | tail -3
-for rep in 1 2; do for ra in 1 0; do echo "== PXT_RENDER_AHEAD=$ra"; PXT_RENDER_AHEAD=$ra python scripts/bench_ycb.py 70 2>&1 | tail -1; done; done
+timeout 900 python -m pytest tests/test_unet_gpu.py tests/test_ycb_gpu.py tests/test_render_ahead_gpu.py tests/test_tracker_gpu.py tests/test_abi.py -q -x 2>&1 | tail -3
+for i in 1 2 3; do python scripts/bench_ycb.py 70 | head -1; done
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['stage_ms_per_frame'], {k:v['frames_per_s'] for k,v in d['extras'].items()})"

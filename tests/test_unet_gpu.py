@@ -140,6 +140,32 @@ def test_unet_batch_matches_single_images_and_oracle(device, H, W):
         assert (both[1][k][..., c].cpu() - confs[k][0]).abs().max().item() < 5e-3
 
 
+def test_unet_pair_of_two_sizes_matches_single_images(device):
+    """pxt_unet_forward_pair: a frame's reference render and its masked query have different sizes with real assets
+    (reference camera x 0.5 / x 0.3); the two single-image passes then run side by side on two streams.  Each image's
+    maps equal its single-image maps up to fp32 summation order, in either order of the pair, run after run."""
+    w = make_synthetic_unet_weights(seed=5)
+    rng = np.random.default_rng(11)
+    a = np.floor(rng.uniform(0, 255, size=(144, 191, 3))).astype(np.uint8)   # odd width: cropped like pixloc
+    b = rng.uniform(0, 255, size=(240, 320, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(240, 320)) > 0.3).astype(np.uint8)
+    net = UNet(w, device)
+    ta, tb, tm = torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), torch.from_numpy(mask).to(device)
+    single_a = [o.clone() for o in net.forward_packed(ta, None, normalize=False)]
+    single_b = [o.clone() for o in net.forward_packed(tb, tm, normalize=True)]
+    both = net.forward_packed_batch([(ta, None, False), (tb, tm, True)])
+    swapped = net.forward_packed_batch([(tb, tm, True), (ta, None, False)])
+    again = net.forward_packed_batch([(ta, None, False), (tb, tm, True)])
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert both[0][k].shape == single_a[k].shape and both[1][k].shape == single_b[k].shape
+        for got, ref in ((both[0][k], single_a[k]), (both[1][k], single_b[k])):
+            scale = ref.abs().max().item()
+            assert (got - ref).abs().max().item() < 2e-3 * scale, k
+        assert torch.equal(both[0][k], swapped[1][k]) and torch.equal(both[1][k], swapped[0][k])
+        assert torch.equal(both[0][k], again[0][k]) and torch.equal(both[1][k], again[1][k])
+
+
 def _packed_conv(device, x, w, b, relu, cfg=0, splits=1, pool=False):
     """x [Cin,H,W] fp16, w [Cout,Cin,3,3] fp16 -> (out [Cout,H,W] float, pooled or None) through
     pxt_conv3x3_pack_weights + pxt_conv3x3_packed with an explicit tile configuration."""
