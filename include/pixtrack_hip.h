@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (6), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (7), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 

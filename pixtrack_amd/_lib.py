@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class PxtError(RuntimeError):
