@@ -44,9 +44,14 @@ def test_unet_rejects_images_it_cannot_encode(device):
     net = UNet(make_synthetic_unet_weights(1), device)
     with pytest.raises(_lib.PxtError):  # 8 px: the fourth pooling would have nothing left
         net.forward_packed(torch.zeros(8, 8, 3, device=device), None, False)
-    with pytest.raises(_lib.PxtError):  # a batch holds one image size (checked by the op)
+    with pytest.raises(_lib.PxtError):  # a batch of more than two holds one image size (checked by the op; exactly
+        # two images of two sizes are the pair entry: tests/test_unet_gpu.py)
         net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False),
-                                  (torch.zeros(32, 48, 3, device=device), None, False)])
+                                  (torch.zeros(32, 48, 3, device=device), None, False),
+                                  (torch.zeros(32, 32, 3, device=device), None, False)])
+    with pytest.raises(_lib.PxtError):  # ... and a pair one of whose images cannot be encoded
+        net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False),
+                                  (torch.zeros(8, 8, 3, device=device), None, False)])
     with pytest.raises(_lib.PxtError):  # PXT_UNET_MAX_BATCH
         net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False)] * 9)
 
