@@ -169,7 +169,8 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
     both REPLAY the frames of the timed region (same warm-up frames, same timed frames) on a fresh tracker,
     so they compare with `value` frame for frame;
     (c) `value_k200`: the headline configuration over the 200 frames that follow (the per-frame cost drifts
-        along the synthetic orbit as the object turns its broad side to the camera)."""
+        along the synthetic orbit as the object turns its broad side to the camera);
+    (d) `value_ycb_policy`: the YCB tracker's policy on its own synthetic object (ycb_policy_extra)."""
     import gc
 
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
@@ -219,7 +220,39 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
         gc.enable()
     out["value_k200"] = {"frames_per_s": round(fps, 2), "frames": 200, "tracked_ok": ok,
                          "what": "headline configuration, the 200 frames after the timed and diagnostic ones"}
+    out["value_ycb_policy"] = ycb_policy_extra(dev)
     return out
+
+
+def ycb_policy_extra(dev, n=70, lead=10):
+    """BASELINE configs[2]'s policy (pixloc_tracker_ycb.py:241-295: mask every frame, GT-gated pose update, reference
+    camera x 0.3, render box from the SfM points) on the synthetic unit-cube object at 640x480: per frame two renders of
+    DIFFERENT cameras and two UNet passes of different sizes.  A different object and policy than `value` - reported
+    beside it, never as it."""
+    from pixtrack_amd.geometry import Camera, Pose
+    from pixtrack_amd.pose_trackers import pixloc_tracker_ycb as ycb
+    from pixtrack_amd.synthetic import CRACKER_BOX_AABB, make_tracking_assets, render_query_frames
+
+    assets = make_tracking_assets(seed=1005, width=640, height=480, n_frames=n, aabb=CRACKER_BOX_AABB, reference_scale=0.3,
+                                  n_points=5600)
+    tr = ycb.PixLocPoseTrackerYCB("", "", "/tmp", "003_cracker_box", device=dev, assets=assets)
+    f = float(assets["query_camera"]["params"][0])
+    cam = Camera.from_colmap(dict(model="OPENCV", width=640, height=480, params=np.array([f, f, 319.5, 239.5])))
+    frames = render_query_frames(assets, tr.testbed)
+    gts = [Pose.from_Rt(*p) for p in assets["gt_poses"]]
+    ok, t0 = 0, 0.0
+    for i in range(n):
+        if i == lead:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        good = bool(tr.refine((f"{i + 1:06d}-color.png", frames[i], gts[i], cam)))
+        ok += int(good and i >= lead)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_per_s": round((n - lead) / dt, 2), "frames": n - lead, "tracked_ok": ok,
+            "renders_ahead_used": int(tr.renders_ahead_used),
+            "what": "the YCB policy (configs[2]) on the synthetic unit-cube object, 640x480, 5600 points, reference at 0.3 x: "
+                    "two renders of different cameras + two UNet passes of different sizes per frame, each pair side by side"}
 
 
 def run_hd(args, rank, ws, dev, coll_dev, numa_node):

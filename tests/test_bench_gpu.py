@@ -39,9 +39,10 @@ def test_single_gpu_line_has_the_contract_fields(device):
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
     # the extra passes that say what the headline leaves out (two renders, host frames + debug 1, K = 200)
     ex = d["extras"]
-    for k in ("value_two_renders", "value_host_frames_debug1", "value_k200"):
+    for k in ("value_two_renders", "value_host_frames_debug1", "value_k200", "value_ycb_policy"):
         assert ex[k]["frames_per_s"] > 30.0 and ex[k]["tracked_ok"] == ex[k]["frames"], (k, ex[k])
     assert ex["value_two_renders"]["frames_per_s"] < d["value"] * 1.05
+    assert ex["value_ycb_policy"]["renders_ahead_used"] >= ex["value_ycb_policy"]["frames"] - 2
 
 
 def test_objects8_and_hd_workloads_run(device):
