@@ -170,7 +170,8 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
     so they compare with `value` frame for frame;
     (c) `value_k200`: the headline configuration over the 200 frames that follow (the per-frame cost drifts
         along the synthetic orbit as the object turns its broad side to the camera);
-    (d) `value_ycb_policy`: the YCB tracker's policy on its own synthetic object (ycb_policy_extra)."""
+    (d) `value_ycb_policy`: the YCB tracker's policy on its own synthetic object (ycb_policy_extra);
+    (e) `value_objects8_rank0`, `value_hd`: the other two workloads at N = 1, each its own run of this file."""
     import gc
 
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
@@ -221,7 +222,24 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
     out["value_k200"] = {"frames_per_s": round(fps, 2), "frames": 200, "tracked_ok": ok,
                          "what": "headline configuration, the 200 frames after the timed and diagnostic ones"}
     out["value_ycb_policy"] = ycb_policy_extra(dev)
+    # BASELINE configs[3] / [4] at N = 1, each as its own `--config` run of this file: one driver record for all three workloads
+    for key, argv in (("value_objects8_rank0", ["--config", "objects8", "--steps", "20", "--warmup", "5"]),
+                      ("value_hd", ["--config", "hd", "--steps", "12", "--warmup", "3"])):
+        out[key] = other_config_extra(argv)
     return out
+
+
+def other_config_extra(argv, timeout_s=240):
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], capture_output=True, text=True, timeout=timeout_s,
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"frames_per_s": line["value"], "frames": line["steps"], "tracked_ok": line.get("tracked_ok"),
+                "ms_per_step": line["ms_per_step"], "what": "python bench.py " + " ".join(argv) + ": " + line["config"]["workload"][:160]}
+    except Exception as e:  # (reported, never fatal: the headline line must come out)
+        return {"frames_per_s": None, "what": "python bench.py " + " ".join(argv), "error": repr(e)[:200]}
 
 
 def ycb_policy_extra(dev, n=70, lead=10):
