@@ -1,9 +1,11 @@
 #!/bin/bash
 # scratch experiment driver (gpurun)
-cd /root/repo
-timeout 900 python -m pytest tests/test_variants_gpu.py tests/test_render_ahead_gpu.py tests/test_ycb_gpu.py tests/test_ngp_gpu.py -q -x 2>&1 | tail -2
-for rep in 1 2 3; do python scripts/bench_ycb.py 70 | head -1; done
-for rep in 1 2; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], {k:v['frames_per_s'] for k,v in d['extras'].items()})"; done
+cd /tmp && export TMPDIR=/tmp
+R=/root/repo; out=$R/gpurun_out
+rocprofv3 --kernel-trace -d /tmp/kty -o kt -- python $R/scripts/bench_ycb.py 70 > /tmp/y.log 2>&1
+db=$(find /tmp/kty -name '*.db' | head -1)
+{ head -1 /tmp/y.log; python $R/scripts/gpu_busy.py $db lm_refine 40; python $R/scripts/frame_timeline.py $db 30; } > $out/r03_ycb_frame_timeline.txt 2>&1
+python $R/scripts/rocpd_summary.py $db | head -30 > $out/r03_ycb_kernel_stats.csv
+rocprofv3 --kernel-trace -d /tmp/ktb -o kt -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > /tmp/b.log 2>&1
+db=$(find /tmp/ktb -name '*.db' | head -1)
+{ python $R/scripts/gpu_busy.py $db lm_refine 30; python $R/scripts/frame_timeline.py $db 25; } > $out/r03_frame_timeline.txt 2>&1
