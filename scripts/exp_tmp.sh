@@ -1,11 +1,12 @@
 #!/bin/bash
 # scratch experiment driver (gpurun)
-cd /tmp && export TMPDIR=/tmp
-R=/root/repo; out=$R/gpurun_out
-rocprofv3 --kernel-trace -d /tmp/kty -o kt -- python $R/scripts/bench_ycb.py 70 > /tmp/y.log 2>&1
-db=$(find /tmp/kty -name '*.db' | head -1)
-{ head -1 /tmp/y.log; python $R/scripts/gpu_busy.py $db lm_refine 40; python $R/scripts/frame_timeline.py $db 30; } > $out/r03_ycb_frame_timeline.txt 2>&1
-python $R/scripts/rocpd_summary.py $db | head -30 > $out/r03_ycb_kernel_stats.csv
-rocprofv3 --kernel-trace -d /tmp/ktb -o kt -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras > /tmp/b.log 2>&1
-db=$(find /tmp/ktb -name '*.db' | head -1)
-{ python $R/scripts/gpu_busy.py $db lm_refine 30; python $R/scripts/frame_timeline.py $db 25; } > $out/r03_frame_timeline.txt 2>&1
+cd /root/repo
+for rep in 1 2; do
+for sg in 2048 4096 8192 16384; do
+    echo -n "shade_grid=$sg: "
+    PXT_NGP_SHADE_GRID=$sg timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['stage_ms_per_frame']['nerf_render'], d['roofline']['frac'])"
+done
+done
