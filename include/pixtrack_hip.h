@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (7), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (8), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -84,6 +84,8 @@ typedef struct {
   float dt_stop, dR_stop;   /* dt < dt_stop AND dR(deg) < dR_stop -> stop */
   int32_t min_valid;        /* failed |= n_valid < min_valid (10) */
   int32_t n_workgroups;     /* persistent grid size; 0 = library default */
+  int32_t spin_limit;       /* polls before an inter-workgroup wait gives up with PXT_E_TIMEOUT; 0 = library default
+                               (2^22, seconds).  Tests force a time-out with 1. */
 } pxt_lm_conf;
 
 /* Output record (device, floats):
@@ -222,6 +224,9 @@ typedef struct {
   float aabb_scale;        /* scene box = [0.5 - s/2, 0.5 + s/2]^3 */
   float cone_angle;        /* dt growth (1/256 when aabb_scale > 1) */
   float depth_scale;       /* colour written in Depth mode = depth * depth_scale */
+  int32_t linear_colors;   /* 0: Shade applies srgb_to_linear to every finished ray's colour before the spp mean
+                              (instant-ngp's shade_kernel_nerf for snapshots trained on LDR images - pixtrack's);
+                              1: the snapshot was trained in linear colours (HDR set): no conversion */
 } pxt_ngp_model;
 
 int pxt_ngp_create(const pxt_ngp_model* model_host, const void* grid_params_f16_host,
@@ -268,13 +273,12 @@ int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* view_host, c
 
 /* A render of >= 2^19 rays runs as n pipelines over equal slices of the rays, on the caller's
  * stream and n-1 internal side streams joined before the final resolve: the image is bit for bit
- * the same, the kernel chains overlap (the VALU-bound march of one slice beside the L1-bound
- * encode or MFMA-bound shade of another).  n = 0 restores the default (2, or $PXT_NGP_PIPES);
+ * the same, the kernel chains overlap (the latency-bound march of one slice beside the L1-bound
+ * gathers / MFMA-bound MLPs of another's shade kernel).  n = 0 restores the default (2, or $PXT_NGP_PIPES);
  * n = 1 serialises the render on the caller's stream (isolated per-kernel timing); n <= 4. */
 int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n);
 
-/* Live HIP-event timing of the renderer's dominant kernel (the round's gather kernel: ngp_shade_kernel<MODE, true>,
- * or ngp_encode_kernel under PXT_NGP_INLINE_FROM=5), for the
+/* Live HIP-event timing of the renderer's dominant kernel (the round's gather kernel, ngp_shade_kernel<MODE>), for the
  * roofline line of bench.py.  every_nth > 0: those launches of every every_nth-th render
  * are bracketed by an event pair recorded on the render's own stream (an event record is a
  * marker packet between kernels, so sampling keeps the measurement from slowing what it

@@ -53,7 +53,7 @@ def colmap_camera_to_pix(cam) -> torch.Tensor:
 def ngp_model(snapshot) -> NO.NgpModel:
     return NO.NgpModel(grid=snapshot.grid, mlp=snapshot.mlp_dict(), occupancy=snapshot.occupancy,
                        cascades=snapshot.cascades, aabb_scale=snapshot.aabb_scale, cone_angle=snapshot.cone_angle,
-                       depth_scale=1.0 / snapshot.scale)
+                       depth_scale=1.0 / snapshot.scale, linear_colors=bool(getattr(snapshot, "linear_colors", False)))
 
 
 def nerf_view(snapshot, nerf2sfm, aabb, R, t, cam: torch.Tensor, mode: int, spp: int = 8) -> NO.View:

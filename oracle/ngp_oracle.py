@@ -25,6 +25,11 @@ specification the HIP kernel is tested against:
   exp(out[0]), rgb = sigmoid(out[0..2]);
 * compositing front to back, stop when transmittance < min_transmittance with the
   accumulated colour renormalised by 1/alpha (instant-ngp's early-out);
+* Shade mode: every finished ray's composited (premultiplied) colour goes through
+  `srgb_to_linear` before it is accumulated over spp, unless the snapshot was trained in
+  linear colours (instant-ngp's shade_kernel_nerf: `if (!train_in_linear_colors && mode ==
+  Shade) rgb = srgb_to_linear(rgb)`; pixtrack's PNG datasets are not HDR, so the conversion
+  is ON for them) -- `NgpModel.linear_colors`, default False = convert.  Depth mode: none;
 * output = premultiplied linear RGBA averaged over spp, composited over
   background.rgb * background.a (transparent for pixtrack's [255,255,255,0]).
 
@@ -33,6 +38,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Tuple
 
@@ -54,6 +60,7 @@ class NgpModel:
     aabb_scale: float = 4.0
     cone_angle: float = 1.0 / 256.0
     depth_scale: float = 1.0
+    linear_colors: bool = False  # True: the network's colours are linear already (HDR training set): no srgb_to_linear
     grid: np.ndarray = None  # float16 [n_entries_total, n_features]
     mlp: Dict[str, np.ndarray] = None  # float16: d1 [64,32], d2 [16,64], c1 [64,32], c2 [64,64], c3 [16,64]
     occupancy: np.ndarray = None  # uint8 bitfield [cascades * 128^3 / 8]
@@ -75,12 +82,22 @@ def grid_level_layout(m: NgpModel) -> List[Tuple[float, int, int, int, bool]]:
     return out
 
 
+# Switches for scripts/renderer_decisions.py ONLY (the measured effect of every recall-level decision of
+# this file).  The defaults ARE the specification; no test or product path changes them.
+VARIANT = {"jitter": "hash", "undistort_iters": 8, "max_step_cascades": None}
+
+
 def max_step(m: NgpModel) -> np.float32:
-    return F32(MIN_STEP * F32(2 ** (m.cascades - 1)) * F32(1024 // GRID))
+    c = m.cascades if VARIANT["max_step_cascades"] is None else int(VARIANT["max_step_cascades"])
+    return F32(MIN_STEP * F32(2 ** (c - 1)) * F32(1024 // GRID))
 
 
 def start_jitter(pixel_index: np.ndarray, spp_index: int) -> np.ndarray:
     """u in [0,1): 24-bit integer hash of (pixel, sample), exact in float32."""
+    if VARIANT["jitter"] == "none":  # (decision table: every pass starts at the box entry)
+        return np.zeros(pixel_index.shape, np.float32)
+    if VARIANT["jitter"] == "other":  # (decision table: an unrelated sequence of the same quality)
+        pixel_index = pixel_index * 2654435761 + 12345
     h = (pixel_index.astype(np.uint64) * 747796405 + np.uint64(spp_index) * 2891336453 + 1) & 0xFFFFFFFF
     h ^= h >> 16
     h = (h * 0x7FEB352D) & 0xFFFFFFFF
@@ -98,6 +115,13 @@ def nerf_matrix_to_ngp(nerf_c2w: np.ndarray, scale: float = 0.33, offset: float 
     m[:, 2] *= -1
     m[:, 3] = m[:, 3] * scale + offset
     return m[[1, 2, 0], :]
+
+
+def srgb_to_linear(c: np.ndarray) -> np.ndarray:
+    """instant-ngp common_device.cuh srgb_to_linear, element-wise, float32."""
+    c = np.asarray(c, np.float32)
+    hi = np.power((np.maximum(c, F32(0.04045)) + F32(0.055)) / F32(1.055), F32(2.4)).astype(np.float32)
+    return np.where(c <= F32(0.04045), c / F32(12.92), hi).astype(np.float32)
 
 
 def calc_dt(t, cone_angle, lo, hi):
@@ -203,8 +227,19 @@ def sh4(d: np.ndarray) -> np.ndarray:
     return o.astype(np.float16)
 
 
+_MIN_GEMM_ROWS = 128
+
+
 def _layer(w16: np.ndarray, x16: np.ndarray, relu: bool) -> np.ndarray:
-    y = x16.astype(np.float32) @ w16.astype(np.float32).T
+    """fp16 operands, fp32 accumulation.  Batches below 128 rows are zero-padded to 128: this image's OpenBLAS sends
+    small products (M <= 18 .. 75 for these shapes) through a different kernel with another summation order, which
+    would make a sample's value depend on how many other rays happen to be alive with it - and a render tiled over
+    processes (render_parallel) differ from the serial one in the last bits."""
+    n = x16.shape[0]
+    x32 = x16.astype(np.float32)
+    if n < _MIN_GEMM_ROWS:
+        x32 = np.concatenate([x32, np.zeros((_MIN_GEMM_ROWS - n, x32.shape[1]), np.float32)], 0)
+    y = (x32 @ w16.astype(np.float32).T)[:n]
     if relu:
         y = np.maximum(y, 0)
     return y
@@ -252,7 +287,7 @@ def generate_rays(v: View):
     dy = ((w_ - F32(0.5)) * F32(H) / F32(v.focal)).astype(np.float32).ravel()
     if v.k1 != 0.0:
         xu, yu = dx.copy(), dy.copy()
-        for _ in range(8):
+        for _ in range(int(VARIANT["undistort_iters"])):
             r2 = (xu * xu + yu * yu).astype(np.float32)
             s = (F32(1.0) + F32(v.k1) * r2).astype(np.float32)
             xu, yu = (dx / s).astype(np.float32), (dy / s).astype(np.float32)
@@ -278,9 +313,18 @@ def ray_aabb(o, d, lo, hi):
     return tmin, tmax, idir
 
 
-def render(m: NgpModel, v: View, return_stats: bool = False):
-    """Returns float32 [H, W, 4] linear premultiplied RGBA."""
+def render(m: NgpModel, v: View, return_stats: bool = False, rows: Tuple[int, int] = None):
+    """Returns float32 [H, W, 4] linear premultiplied RGBA.  ``rows = (r0, r1)``: only image rows r0 <= y < r1
+    ([r1 - r0, W, 4]; every ray is computed exactly as in the full render - rays are independent and keep their
+    global pixel index for the start jitter), the unit render_parallel deals to worker processes.
+    With DEFAULT_PROCS > 1 (``$PXT_ORACLE_PROCS``; the fixture generators and bench.py's cpu_baseline set it) a
+    full render is dealt to that many processes - same image, bit for bit."""
+    if rows is None and DEFAULT_PROCS > 1 and not _PAR:
+        return render_parallel(m, v, DEFAULT_PROCS, return_stats)
     o, d, fwd = generate_rays(v)
+    r0, r1 = (0, v.height) if rows is None else (int(rows[0]), int(rows[1]))
+    sel = slice(r0 * v.width, r1 * v.width)
+    o, d = o[sel], d[sel]
     n = o.shape[0]
     half = F32(m.aabb_scale / 2.0)
     scene_lo, scene_hi = F32(0.5) - half, F32(0.5) + half
@@ -290,7 +334,7 @@ def render(m: NgpModel, v: View, return_stats: bool = False):
     hit = tmax > np.maximum(tmin, F32(0.0))
     dt_lo, dt_hi = MIN_STEP, max_step(m)
     out = np.zeros((n, 4), np.float32)
-    pix = np.arange(n, dtype=np.int64)
+    pix = np.arange(r0 * v.width, r1 * v.width, dtype=np.int64)
     n_samples = 0
     zdot = ((d[:, 0] * fwd[0] + d[:, 1] * fwd[1]).astype(np.float32) + d[:, 2] * fwd[2]).astype(np.float32)
     inv_s = F32(1.0 / m.aabb_scale)
@@ -347,13 +391,62 @@ def render(m: NgpModel, v: View, return_stats: bool = False):
                 rgba[di] = rgba[di] / rgba[di, 3:4]
                 alive[di] = False
             t[idx] = (ti + dti).astype(np.float32)
+        if v.mode == 0 and not m.linear_colors:
+            rgba[:, :3] = srgb_to_linear(rgba[:, :3])
         out += rgba
     out /= F32(v.spp)
     bg = np.asarray(v.background, np.float32)
     a = out[:, 3:4]
     out[:, :3] += bg[:3] * bg[3] * (1 - a)
     out[:, 3:4] = a + bg[3] * (1 - a)
-    img = out.reshape(v.height, v.width, 4)
+    img = out.reshape(r1 - r0, v.width, 4)
     if return_stats:
         return img, {"samples": int(n_samples), "rays_hit": int(hit.sum()) * v.spp}
     return img
+
+
+# ---- the same render on several host cores ------------------------------------------------------
+_PAR = {}
+DEFAULT_PROCS = int(os.environ.get("PXT_ORACLE_PROCS", "1") or 1)
+
+
+def _worker_init():
+    """One BLAS thread per worker process (the workers ARE the parallelism)."""
+    try:
+        import threadpoolctl
+
+        _PAR["_limit"] = threadpoolctl.threadpool_limits(1)
+    except Exception:  # pragma: no cover - threadpoolctl is optional
+        pass
+
+
+def _render_rows_job(job):
+    r0, r1 = job
+    return r0, render(_PAR["m"], _PAR["v"], return_stats=True, rows=(r0, r1))
+
+
+def render_parallel(m: NgpModel, v: View, procs: int, return_stats: bool = False, rows_per_job: int = 0):
+    """render() with the image rows dealt to ``procs`` forked worker processes (the model is shared copy-on-write).
+    Rays are independent, so the image and the counts are those of the serial render - bit for bit as long as the
+    BLAS rows of the MLP products do not depend on the batch they sit in (tests/test_oracle_kats.py asserts it here;
+    bench.py's cpu_baseline re-asserts it on the box it runs on)."""
+    import multiprocessing as mp
+
+    procs = max(1, int(procs))
+    if procs == 1:
+        return render(m, v, return_stats)
+    step = rows_per_job or max(1, v.height // (procs * 4))
+    jobs = [(r, min(r + step, v.height)) for r in range(0, v.height, step)]
+    _PAR["m"], _PAR["v"] = m, v
+    try:
+        with mp.get_context("fork").Pool(procs, initializer=_worker_init) as pool:
+            parts = pool.map(_render_rows_job, jobs, chunksize=1)
+    finally:
+        _PAR.clear()
+    img = np.empty((v.height, v.width, 4), np.float32)
+    stats = {"samples": 0, "rays_hit": 0}
+    for r0, (part, st) in parts:
+        img[r0:r0 + part.shape[0]] = part
+        stats["samples"] += st["samples"]
+        stats["rays_hit"] += st["rays_hit"]
+    return (img, stats) if return_stats else img

@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class PxtError(RuntimeError):
@@ -53,6 +53,7 @@ class LmConf(C.Structure):
         ("dR_stop", C.c_float),
         ("min_valid", C.c_int32),
         ("n_workgroups", C.c_int32),
+        ("spin_limit", C.c_int32),
     ]
 
 
@@ -80,6 +81,7 @@ class NgpModel(C.Structure):
         ("aabb_scale", C.c_float),
         ("cone_angle", C.c_float),
         ("depth_scale", C.c_float),
+        ("linear_colors", C.c_int32),
     ]
 
 

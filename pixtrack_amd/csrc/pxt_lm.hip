@@ -36,7 +36,7 @@ constexpr int kLmWaves = kLmBlock / PXT_WAVE;
 constexpr int kLmMaxGrid = 256;
 constexpr int kNAcc = 32;  // 6 g + 21 H + cost sum + n_valid + pad
 constexpr int kGrpStride = 33;  // padded: leaders of one wave hit distinct banks
-constexpr unsigned kSpinLimit = 1u << 24;
+constexpr unsigned kSpinLimit = 1u << 22;  // polls of ~1.5 us before a spin gives up (pxt_lm_conf.spin_limit overrides)
 
 struct LmLevelDev {
   const float* fmap;
@@ -464,6 +464,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
   // launches (the memset node before every launch was 5 us + a dependent-launch gap on the frame's serial chain).
   const unsigned base = ld_relaxed_u32(P.err + 1);
   const unsigned launch_id = base + 1u;  // what the error word holds when THIS launch timed out
+  const unsigned spin_limit = P.conf.spin_limit > 0 ? (unsigned)P.conf.spin_limit : kSpinLimit;
   int total_iters = 0;
   bool failed = false;
   bool aborted = false;
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
               break;
             }
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinLimit || (((spins & 255u) == 0u) && ld_relaxed_u32(P.err) == launch_id)) {
+            if (++spins > spin_limit || (((spins & 255u) == 0u) && ld_relaxed_u32(P.err) == launch_id)) {
               __hip_atomic_store(P.err, launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               s_flags[2] = 1;  // (benign race: every writer stores 1)
               i0 = n_gran;
@@ -626,7 +627,13 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
   }
 
   if (blockIdx.x == 0 && tid == 0) {
-    P.err[1] = base + epoch + 1u;  // the next launch's tags start above every tag of this one
+    // The next launch's tags start above every tag of this one.  After a time-out that needs a margin: workgroup 0
+    // leaves at epoch e, but a workgroup that lagged may still complete epoch e (every other granule is tagged by
+    // then) and publish epoch e + 1 with tag base + e + 2 before it sees the error word - which a next launch
+    // starting at base + e + 1 would have accepted as its own epoch 0.  It can get at most one epoch
+    // further than the slowest of the others (it needs THEIR granules of that epoch), so 8 is generous; the host
+    // zeroes the workspace after a time-out as well (optimizer.py).
+    P.err[1] = base + epoch + 1u + (aborted ? 8u : 0u);
     for (int i = 0; i < 12; ++i) P.out[i] = s_T[i];
     P.out[12] = failed ? 1.f : 0.f;
     P.out[13] = aborted ? (float)PXT_E_TIMEOUT : 0.f;

@@ -65,6 +65,7 @@ struct NgpParams {
   float bg[4];
   float min_T;
   int W, H, spp, mode;
+  int srgb_to_linear;  // Shade: a finished ray's colour goes through srgb_to_linear before the spp mean (model.linear_colors == 0)
   float* out;
   float* out_depth;  // mode 2 only
   unsigned long long* stats;
@@ -1051,7 +1052,11 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
         if (mine == i) { ts = tt[i]; have = 1; }
       }
       const float tg = __shfl(target, (lane & ~7) | (last_skip >= 0 ? last_skip : j), 64);
-      pending = (last_skip >= 0 && tt[8] < tg) ? tg : -INFINITY;
+      // A skip that runs past this trip's last point stays pending - also across a trip none of whose points reaches
+      // it (a mip >= 1 cell is 9-32 minimum steps wide: `cur` starts at 8, the walk does not run, and the skip must
+      // not be dropped and re-derived from a point inside the same cell).
+      if (last_skip >= 0) pending = (tt[8] < tg) ? tg : -INFINITY;
+      else if (!(pending > tt[8])) pending = -INFINITY;
       t = t_cur;  // k == 8: the point after the last sample; otherwise the next trip's first point
       busy = !out && k < kK;
     }
@@ -1203,6 +1208,14 @@ __global__ void ngp_pose_to_camera_kernel(const float* __restrict__ pose12, cons
   if (cam_out) __hip_atomic_store(&cam_out[12], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// instant-ngp's srgb_to_linear (common_device.cuh), applied by its shade_kernel_nerf to every finished ray's
+// composited colour when the snapshot was not trained in linear colours.  pow through v_log_f32 / v_exp_f32
+// (1 ulp each): relative error < 3e-6 over (0.04045, 1], far inside the renderer's 5e-4 parity bar.
+__device__ inline float srgb_to_linear(float c) {
+  if (c <= 0.04045f) return c / 12.92f;
+  return __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((c + 0.055f) / 1.055f));
+}
+
 // The last kernel of a render also zeroes the round counters of every pipeline for the NEXT render (everything that
 // reads them has finished by now): no memset launch in front of a render's first kernel.
 struct NgpCounterList { int* p[4]; int n; };
@@ -1230,6 +1243,12 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
       for (int k = 0; k < 8; ++k) {
         v[k] = (s0 + k < P.spp) ? src[s0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
         vd[k] = (P.out_depth && s0 + k < P.spp) ? srcd[s0 + k] : 0.f;
+      }
+      if (P.mode != 1 && P.srgb_to_linear) {  // Shade colours only: mode 1's buffer holds depths
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v[k].x = srgb_to_linear(v[k].x); v[k].y = srgb_to_linear(v[k].y); v[k].z = srgb_to_linear(v[k].z);
+        }
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {  // sequential: ((v0 + v1) + v2) + ...
@@ -1430,6 +1449,7 @@ static void fill_model(const pxt_ngp* ctx, NgpParams& P) {
   P.aabb_scale = ctx->model.aabb_scale;
   P.cone_angle = ctx->model.cone_angle;
   P.depth_scale = ctx->model.depth_scale;
+  P.srgb_to_linear = ctx->model.linear_colors ? 0 : 1;
   P.dt_lo = (float)(std::sqrt(3.0) / 1024.0);
   P.dt_hi = P.dt_lo * (float)(1 << (P.cascades - 1)) * (float)(1024 / kGrid);
 }
@@ -1574,7 +1594,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     for (int w = 1; w < n_pipe; ++w) PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side[w], ctx->ev_fork, 0));
   }
   const int wide = 2048, cmp_grid = 1024;  // grid-stride kernels: full grids measured best
-  static const int shade_grid = [] { const char* e = getenv("PXT_NGP_SHADE_GRID"); return e ? atoi(e) : 2048; }();
+  constexpr int shade_grid = 2048;  // (1024 / 1536 / 3072 / 4096 measured in round 3: 2048 best; no knob)
   static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
   // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
   // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)

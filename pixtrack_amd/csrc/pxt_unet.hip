@@ -445,16 +445,26 @@ inline int upcat_cfg(int cout, int H, int W) {
   return cout % 64 == 0 ? ((long long)H * W >= 120 * 160 ? 21 : 2) : 20;
 }
 
+// Bytes of split-K partials a layer may need.  The launch-time plan depends on whether the layer's output is pooled and on
+// the number of passes sharing the chip (g_conv_peers), neither of which is known when the workspace is sized: the
+// largest factor over those four cases.  launch_conv checks its plan against the region it is given.
 size_t splitk_bytes(int n_img, int H, int W, int cin, int cout, bool upcat = false) {
-  const ConvPlan cp = plan_conv(n_img, H, W, cin, cout, true, upcat ? upcat_cfg(cout, H, W) : 0, 0, upcat);
-  return cp.splits > 1 ? (size_t)cp.splits * n_img * H * W * cout * sizeof(float) : 0;
+  int splits = 1;
+  const int peers_before = g_conv_peers;
+  for (int peers = 1; peers <= 2; ++peers)
+    for (int pool = 0; pool < (upcat ? 1 : 2); ++pool) {
+      g_conv_peers = peers;
+      splits = std::max(splits, plan_conv(n_img, H, W, cin, cout, true, upcat ? upcat_cfg(cout, H, W) : 0, 0, upcat, pool != 0).splits);
+    }
+  g_conv_peers = peers_before;
+  return splits > 1 ? (size_t)splits * n_img * H * W * cout * sizeof(float) : 0;
 }
 
 struct Plan {
   int h[5], w[5];          // encoder block resolutions
   int dh[4], dw[4];        // decoder block output resolutions
   // byte offsets into the workspace
-  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_out[4], splitk, total;
+  size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_out[4], splitk, splitk_bytes, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -491,6 +501,7 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
   for (int d = 0; d < 4; ++d)
     sk = std::max(sk, splitk_bytes(n_img, P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout, true));
   P.splitk = take(sk + 256);
+  P.splitk_bytes = sk;
   P.total = off;
   return true;
 }
@@ -575,7 +586,7 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
 int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const half_t* in, int H, int W, half_t* out,
                 hipStream_t s, int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr,
                 half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0,
-                const FusedHead* head = nullptr, const FusedFirst* first = nullptr) {
+                const FusedHead* head = nullptr, const FusedFirst* first = nullptr, size_t partial_cap = ~(size_t)0) {
   if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
@@ -612,6 +623,8 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
   a.up = up ? *up : UpSrc{nullptr, 0, 0, 0, 0, 0};
   a.pool = (cp.splits == 1 && !(cfg_v3(cp.cfg) && (kV2Cfgs[cp.cfg].PBW & 1))) ? pool_out : nullptr;
   if (kV2Cfgs[cp.cfg].KS == 2 && ((cin / 32) / cp.splits) % 2 != 0) return PXT_E_ARG;  // both quartets need equal K shares
+  // the partials of this plan must fit the region the caller sized (a forced plan - PXT_CONV_PLAN - may ask for more)
+  if (cp.splits > 1 && (size_t)cp.splits * n_img * H * W * cout * sizeof(float) > partial_cap) return PXT_E_ARG;
   std::memset(&a.head, 0, sizeof(a.head));
   if (head) {
     if (cout != 32 || cp.splits != 1 || cfg_bnc(cp.cfg) != 32) return PXT_E_ARG;
@@ -899,7 +912,8 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       const bool with_first = li == 1 && fuse_first;
       int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
                            1, with_first ? nullptr : (float*)(ws + P.splitk), B, nullptr, pool_to,
-                           pool_to ? &pooled_by_conv : nullptr, with_first ? 2 : 0, 0, nullptr, with_first ? &ff : nullptr);
+                           pool_to ? &pooled_by_conv : nullptr, with_first ? 2 : 0, 0, nullptr, with_first ? &ff : nullptr,
+                           P.splitk_bytes);
       if (rc != PXT_OK) return rc;
       x = o;
     }
@@ -936,7 +950,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
     g_conv_layer = 13 + d;
     int rc = launch_conv(L.cin, L.cout, ctx->conv_packed[13 + d], L.b, skip[sb], P.dh[d], P.dw[d], o, s, 1,
                          fuse_head ? nullptr : (float*)(ws + P.splitk), B, &up, nullptr, nullptr, 0, 0,
-                         fuse_head ? &fh : nullptr);
+                         fuse_head ? &fh : nullptr, nullptr, P.splitk_bytes);
     if (rc != PXT_OK) return rc;
     prev = o;
     ph = P.dh[d]; pw = P.dw[d]; pc = L.cout;

@@ -27,6 +27,7 @@ class PixTrackFeatureExtractor:
         self.model = model
         self._staged = None   # (image, scale_image, mask, normalize) announced by stage()
         self._ready = None    # (image, scale_image, mask, normalize, maps, scales) computed alongside
+        self.last_input_wh = None  # (w, h) the UNet ran the last extract_packed image at (after the resize rule)
         assert hasattr(self.model, "scales")
         assert self.conf.resize_by in ["max", "max_force"], self.conf.resize_by
 
@@ -69,10 +70,21 @@ class PixTrackFeatureExtractor:
         self._staged = self._ready = None
 
     def _prepare(self, image, scale_image, mask):
+        """-> (HWC image on the device at the size the UNet runs it, mask still to apply, scale_resize).  An image above
+        the resize target is masked first and resized here (the reference multiplies the mask into the image before its
+        `resize`, pixloc_pose_refiners.py:240-249 + feature_extractor.py:41-45)."""
         img = self._to_device_hwc(image)
         H, W = int(img.shape[0]), int(img.shape[1])
         h_new, w_new, scale_resize = self.target_size(H, W, scale_image)
-        return img, mask, (h_new, w_new) == (H, W), scale_resize
+        if (h_new, w_new) != (H, W):
+            if mask is not None:
+                img = img.float() * mask.to(self.device)[..., None].float()
+                mask = None
+            src = img.float().contiguous()
+            dst = torch.empty(h_new, w_new, 3, device=self.device, dtype=torch.float32)
+            ops.resize_linear(src, dst)
+            img = dst
+        return img, mask, scale_resize
 
     def extract_packed(self, image, scale_image: int = 1, mask: Optional[torch.Tensor] = None,
                        normalize: bool = False):
@@ -82,31 +94,20 @@ class PixTrackFeatureExtractor:
             self._ready = None
             if r[0] is image and r[1] == scale_image and r[2] is mask and r[3] == normalize:
                 return r[4], r[5]
+        a_img, a_mask, a_sr = self._prepare(image, scale_image, mask)
+        self.last_input_wh = (int(a_img.shape[1]), int(a_img.shape[0]))
+        scales = [(a_sr[0] / s, a_sr[1] / s) for s in self.model.scales]
         if self._staged is not None:
             st_image, st_scale, st_mask, st_norm = self._staged
             self._staged = None
             if st_image is not image:
-                a_img, a_mask, a_same, a_sr = self._prepare(image, scale_image, mask)
-                b_img, b_mask, b_same, b_sr = self._prepare(st_image, st_scale, st_mask)
-                if a_same and b_same:  # (equal sizes: one batched call; two sizes: the pair entry - both side by side)
-                    both = self.model.forward_packed_batch([(a_img, a_mask, normalize), (b_img, b_mask, st_norm)])
-                    self._ready = (st_image, st_scale, st_mask, st_norm, both[1],
-                                   [(b_sr[0] / s, b_sr[1] / s) for s in self.model.scales])
-                    return both[0], [(a_sr[0] / s, a_sr[1] / s) for s in self.model.scales]
-        img = self._to_device_hwc(image)
-        H, W = int(img.shape[0]), int(img.shape[1])
-        h_new, w_new, scale_resize = self.target_size(H, W, scale_image)
-        if (h_new, w_new) != (H, W):
-            if mask is not None:  # the reference multiplies the mask into the image first
-                img = img.float() * mask.to(self.device)[..., None].float()
-                mask = None
-            src = img.float().contiguous()
-            dst = torch.empty(h_new, w_new, 3, device=self.device, dtype=torch.float32)
-            ops.resize_linear(src, dst)
-            img = dst
-        maps = self.model.forward_packed(img, mask, normalize=normalize)
-        scales = [(scale_resize[0] / s, scale_resize[1] / s) for s in self.model.scales]
-        return maps, scales
+                # equal sizes: one batched call; two sizes: the pair entry - both images side by side either way
+                b_img, b_mask, b_sr = self._prepare(st_image, st_scale, st_mask)
+                both = self.model.forward_packed_batch([(a_img, a_mask, normalize), (b_img, b_mask, st_norm)])
+                self._ready = (st_image, st_scale, st_mask, st_norm, both[1],
+                               [(b_sr[0] / s, b_sr[1] / s) for s in self.model.scales])
+                return both[0], scales
+        return self.model.forward_packed(a_img, a_mask, normalize=normalize), scales
 
     @torch.no_grad()
     def __call__(self, image: np.ndarray, scale_image: int = 1):

@@ -54,6 +54,10 @@ class NerfSnapshot:
     scale: float = 0.33  # nerf -> ngp coordinate scale
     offset: float = 0.5
     k1: float = 0.0  # training lens (render_with_camera_distortion)
+    # instant-ngp's shade_kernel_nerf passes a finished ray's colour through srgb_to_linear unless the snapshot was
+    # trained in linear colours (`m_nerf.training.linear_colors` = the dataset's is_hdr).  pixtrack trains on PNGs,
+    # so its snapshots convert: False = convert (render(..., linear=True) then returns linear light).
+    linear_colors: bool = False
 
     def mlp_dict(self) -> Dict[str, np.ndarray]:
         out, o = {}, 0
@@ -80,6 +84,7 @@ def save_snapshot(path: str, snap: NerfSnapshot) -> None:
             "density_grid_binary": snap.occupancy.tobytes(),
             "density_grid_size": 128,
             "nerf": {"aabb_scale": snap.aabb_scale, "cascades": snap.cascades, "cone_angle_constant": snap.cone_angle,
+                     "linear_colors": bool(snap.linear_colors),
                      "dataset": {"scale": snap.scale, "offset": [snap.offset] * 3, "k1": snap.k1}},
         },
     }
@@ -106,6 +111,7 @@ def load_snapshot_file(path: str) -> NerfSnapshot:
         base_res=enc["base_resolution"], per_level_scale=enc["per_level_scale"], cascades=nerf["cascades"],
         aabb_scale=nerf["aabb_scale"], cone_angle=nerf["cone_angle_constant"], scale=nerf["dataset"]["scale"],
         offset=nerf["dataset"]["offset"][0], k1=nerf["dataset"].get("k1", 0.0),
+        linear_colors=bool(nerf.get("linear_colors", False)),
     )
 
 
@@ -124,7 +130,10 @@ def load_snapshot_file(path: str) -> NerfSnapshot:
 #       fp16 or fp32 by byte count; occupancy bit = density > min(0.01, mean over cascade 0),
 #       then each coarser cascade ORs in the 2x2x2 max-pool of the finer one over its centre
 #       half (instant-ngp update_density_grid_mean_and_bitfield / bitfield_max_pool).
-#   snapshot.nerf.dataset.{scale, offset, aabb_scale, metadata[0].camera_distortion}
+#   snapshot.nerf.dataset.{scale, offset, aabb_scale, is_hdr, metadata[0].camera_distortion}
+#   colour space: instant-ngp sets training.linear_colors = dataset.is_hdr when it loads the training set and its
+#       shade kernel converts sRGB -> linear unless that flag is set; read here as nerf.linear_colors if the key
+#       exists, else dataset.is_hdr, else False (LDR images: convert).
 _NGP_GRID = 128
 _NGP_MIN_OPTICAL_THICKNESS = 0.01
 _MLP_PARAMS = sum(r * c for _, r, c in MLP_SHAPES)
@@ -217,7 +226,8 @@ def from_instant_ngp(d: Dict) -> NerfSnapshot:
         occupancy=occupancy_from_density_grid(density), n_levels=n_levels, n_features=F, log2_hashmap=log2_T,
         base_res=base, per_level_scale=pls, cascades=expect_c, aabb_scale=aabb_scale,
         cone_angle=0.0 if aabb_scale <= 1.0 else 1.0 / 256.0, scale=float(ds.get("scale", 0.33)),
-        offset=float(offset[0]), k1=k1)
+        offset=float(offset[0]), k1=k1,
+        linear_colors=bool(nerf.get("linear_colors", ds.get("is_hdr", False))))
 
 
 def _training_lens_k1(meta0: Dict) -> float:
@@ -278,6 +288,7 @@ def to_instant_ngp(snap: NerfSnapshot) -> Dict:
             "params_binary": params.tobytes(), "density_grid_size": _NGP_GRID,
             "density_grid_binary": density.tobytes(),
             "nerf": {"dataset": {"scale": snap.scale, "offset": [snap.offset] * 3, "aabb_scale": snap.aabb_scale,
+                                 "is_hdr": bool(snap.linear_colors),
                                  "metadata": [{"camera_distortion": {"mode": 1, "params": [snap.k1, 0.0, 0.0, 0.0]}}]}},
         },
     }
@@ -331,6 +342,7 @@ class Testbed:
         self._stats = None
         self.stats_accum = None
         self.n_renders = 0
+        self._pipelines = 0  # what set_pipelines() asked for (0: the library default); per-call overrides restore THIS
         self._cam_ring = None  # pinned camera records of pose-driven renders (see _next_cam_out)
         self._cam_next = 0
 
@@ -361,7 +373,8 @@ class Testbed:
     def _create_ctx(self, snap: NerfSnapshot):
         L = _lib.lib()
         model = _lib.NgpModel(snap.n_levels, snap.n_features, snap.log2_hashmap, snap.base_res, snap.per_level_scale,
-                              snap.cascades, snap.aabb_scale, snap.cone_angle, 1.0 / snap.scale)
+                              snap.cascades, snap.aabb_scale, snap.cone_angle, 1.0 / snap.scale,
+                              1 if snap.linear_colors else 0)
         grid = np.ascontiguousarray(snap.grid.astype(np.float16))
         mlp = np.ascontiguousarray(snap.mlp.astype(np.float16))
         occ = np.ascontiguousarray(snap.occupancy.astype(np.uint8))
@@ -434,7 +447,7 @@ class Testbed:
                            int(self.render_mode), out, stats)
         finally:
             if pipelines and not side:
-                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, 0), "pxt_ngp_set_pipelines")
+                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, self._pipelines), "pxt_ngp_set_pipelines")
         if collect_stats:
             self._stats = stats
         self.n_renders += 1
@@ -498,7 +511,7 @@ class Testbed:
                                           int(height), int(spp), int(self.render_mode), out, None, cam_out, self.stats_accum)
         finally:
             if pipelines and not side:
-                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, 0), "pxt_ngp_set_pipelines")
+                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, self._pipelines), "pxt_ngp_set_pipelines")
         self.n_renders += 1
         return out, cam_out
 
@@ -509,15 +522,17 @@ class Testbed:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 
     def set_pipelines(self, n: int = 0):
-        """Number of ray slices a large render processes side by side (0: default of 2)."""
+        """Number of ray slices a large render processes side by side (0: default of 2).  Per-call `pipelines=`
+        overrides of render_device / render_from_pose_device return to this value afterwards."""
         _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, int(n)), "pxt_ngp_set_pipelines")
+        self._pipelines = int(n)
 
     def timing_enable(self, every_nth: int = 1):
-        """HIP events around the encode launches of every ``every_nth``-th render (0 / False: off)."""
+        """HIP events around the gather-kernel (ngp_shade_kernel) launches of every ``every_nth``-th render (0 / False: off)."""
         _lib.check(_lib.lib().pxt_ngp_timing_enable(self._ctx, int(every_nth)), "pxt_ngp_timing_enable")
 
     def timing_read(self):
-        """(total ms, launches) of ngp_encode_kernel since the last read (HIP events on the render stream)."""
+        """(total ms, launches) of ngp_shade_kernel since the last read (HIP events on the render stream)."""
         ms, n = C.c_float(0), C.c_int32(0)
         _lib.check(_lib.lib().pxt_ngp_timing_read(self._ctx, C.byref(ms), C.byref(n)), "pxt_ngp_timing_read")
         return float(ms.value), int(n.value)

@@ -159,6 +159,7 @@ class PixTrackOptimizer:
         learned_damping=True,
         min_valid=10,
         n_workgroups=0,
+        spin_limit=0,  # polls before an inter-workgroup wait gives up (0: the library's default; tests force a time-out with 1)
     )
 
     def __init__(self, conf=None, device: Optional[torch.device] = None):
@@ -232,6 +233,7 @@ class PixTrackOptimizer:
         c.dR_stop = float(self.conf.dR_stop_criteria)
         c.min_valid = int(self.conf.min_valid)
         c.n_workgroups = int(self.conf.n_workgroups)
+        c.spin_limit = int(self.conf.get("spin_limit", 0))
         return c
 
     @staticmethod
@@ -270,7 +272,7 @@ class PixTrackOptimizer:
         ops.lm_refine(p3d, mask, [lp.fmap for lp in levels], [lp.fref for lp in levels], [int(lp.C) for lp in levels],
                       cams, ndist, lambdas, T0, conf.num_iters, conf.pad, conf.loss, conf.loss_alpha, conf.loss_scale,
                       conf.grad_stop, conf.dt_stop, conf.dR_stop, conf.min_valid, conf.n_workgroups, buf, workspace,
-                      bool(want_log))
+                      bool(want_log), int(conf.spin_limit))
         keep = list(levels)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
@@ -373,6 +375,12 @@ class PendingLM:
         nh = 16 + _lib.PXT_MAX_LEVELS
         status = int(h[13])
         if status != 0:
+            # a timed-out launch may leave granules of epochs it never finished behind: the next launch on this
+            # workspace starts from zeroed tags (the kernel also advances its tag base by a margin)
+            if self._keep is not None:
+                self._done.synchronize()
+                self._keep[3].zero_()
+            self._keep = None
             raise _lib.PxtError(f"pxt_lm_refine: in-kernel status {status} (spin bound exceeded)")
         iters = [int(h[16 + l]) for l in range(self.n_levels)]
         if self.has_log:

@@ -352,12 +352,25 @@ def surface_points(rng, n: int, aabb, level: float = 0.12):
     return p, nrm
 
 
+# SfM camera 1 of the reference's real assets (width, height, f, cx, cy); see make_tracking_assets
+REF_CAMERA_YCB = (3072, 3072, 2700.0, 1536.0, 1536.0)   # scripts/create_sfm_from_obj.py:154-159; x 0.3 (pixloc_tracker_ycb.py:89)
+REF_CAMERA_PHONE = (1920, 1440, 1500.0, 960.0, 720.0)   # a 4:3 phone frame as colmap2ingp.py:226 quotes them; x 0.5 (r9:145-152)
+REF_CAMERA_12MP = (4032, 3024, 3150.0, 2016.0, 1512.0)  # 12-MP stills; x 0.5 = 2016 x 1512 -> resized to 1024 x 768 by the extractor
+YCB_QUERY_FXY = (1066.778, 1067.487)                    # YCB-Video intrinsics (scripts/create_sfm_from_obj.py:162-163)
+
+
 def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, n_frames: int = 200,
                          aabb=PREMIER_PROTEIN_AABB, n_points: int = 5600, n_refs: int = 16,
                          step_deg: float = 0.5, jitter_deg: float = 0.3, jitter_trans: float = 0.003,
-                         unet_seed: int = 7, reference_scale: float = 0.5):
+                         unet_seed: int = 7, reference_scale: float = 0.5, ref_camera=None, query_f=None):
     """Returns the dict PixLocPoseTrackerR9(assets=...) consumes plus 'gt_poses' [(R, t)] and
-    'query_camera' (COLMAP dict).  All seeded."""
+    'query_camera' (COLMAP dict).  All seeded.
+
+    ``ref_camera`` = (width, height, f, cx, cy): SfM camera 1 as the reference's own assets have it, instead of the
+    default "query size / reference_scale" stand-in - REF_CAMERA_YCB (3072 x 3072, f 2700: scripts/create_sfm_from_obj.py:
+    154-159; x 0.3 -> a 921 x 921 reference render), REF_CAMERA_PHONE (1920 x 1440; x 0.5 -> 960 x 720), REF_CAMERA_12MP
+    (4032 x 3024; x 0.5 -> 2016 x 1512, which the extractor resizes to 1024 x 768).  ``query_f`` = focal length (fx) of
+    the query camera (YCB: 1066.778); the orbit's distance follows it so that the object fills the QUERY as before."""
     from .model3d import Model3D
     from .unet import make_synthetic_unet_weights
     from .utils.colmap import ColmapCamera, ColmapImage, ColmapPoint3D, rotmat2qvec
@@ -372,16 +385,19 @@ def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, 
     lo, hi = np.asarray(aabb[0], float), np.asarray(aabb[1], float)
     center = ngp_to_sfm_points((0.5 * (lo + hi))[None])[0]
     extent = float(np.max(hi - lo)) / NGP_SCALE
-    f_q = 1.2 * max(width, height)
+    f_q = 1.2 * max(width, height) if query_f is None else float(query_f)
     dist = f_q * extent / (0.5 * min(width, height))
 
     # reference (mapping) cameras: one COLMAP camera whose size x reference_scale is the query size
     # ("reference camera 2x query resolution x reference_scale 0.5"; 1/0.3 for the YCB policy)
-    Wr, Hr = int(round(width / reference_scale)), int(round(height / reference_scale))
-    cameras = {1: ColmapCamera(1, "SIMPLE_RADIAL", Wr, Hr, np.array([1.2 * max(Wr, Hr), Wr / 2.0, Hr / 2.0, 0.0]))}
+    if ref_camera is None:
+        Wr, Hr = int(round(width / reference_scale)), int(round(height / reference_scale))
+        fr, cxr, cyr = 1.2 * max(Wr, Hr), Wr / 2.0, Hr / 2.0
+    else:
+        Wr, Hr, fr, cxr, cyr = int(ref_camera[0]), int(ref_camera[1]), *(float(x) for x in ref_camera[2:5])
+    cameras = {1: ColmapCamera(1, "SIMPLE_RADIAL", Wr, Hr, np.array([fr, cxr, cyr, 0.0]))}
     up_axis = np.array([0.0, 0.0, 1.0])  # sfm z is the object's long axis (ngp -y ... +y)
     images, obs = {}, {i: [] for i in range(n_points)}
-    fr = 1.2 * max(Wr, Hr)
     for k in range(n_refs):
         az = 2 * math.pi * k / n_refs
         el = math.radians(15.0 * math.sin(3 * az))
@@ -390,7 +406,7 @@ def make_tracking_assets(seed: int = 1002, width: int = 640, height: int = 480, 
         Rk, tk = look_at_pose(eye, center, up=up_axis)
         pc = p_sfm @ Rk.T + tk
         facing = np.einsum("ij,ij->i", n_sfm, eye[None] - p_sfm) > 0.15 * np.linalg.norm(eye[None] - p_sfm, axis=1)
-        uv = pc[:, :2] / pc[:, 2:3] * fr + np.array([Wr / 2.0, Hr / 2.0])
+        uv = pc[:, :2] / pc[:, 2:3] * fr + np.array([cxr, cyr])
         vis = facing & (pc[:, 2] > 0) & (uv[:, 0] > 2) & (uv[:, 0] < Wr - 2) & (uv[:, 1] > 2) & (uv[:, 1] < Hr - 2)
         ids = np.nonzero(vis)[0]
         for j, pid in enumerate(ids):

@@ -3,6 +3,7 @@ pixtrack/utils/ingp_utils.py:16-83).  ``nerf2sfm.pkl`` = {up, centroid, avglen, 
 written by colmap2ingp (reference pixtrack/utils/colmap2ingp.py:356-362)."""
 from __future__ import annotations
 
+import os
 import pickle as pkl
 
 import numpy as np
@@ -13,6 +14,9 @@ _FLIP_YZ = np.diag([1.0, -1.0, -1.0, 1.0])
 def load_nerf2sfm(path):
     with open(path, "rb") as f:
         return pkl.load(f)
+
+
+_WARNED_AABB = []
 
 
 def initialize_ingp(snapshot_path, aabb, background=None, device=None):
@@ -32,6 +36,21 @@ def initialize_ingp(snapshot_path, aabb, background=None, device=None):
     testbed.shall_train = False
     # config/motor_core.sh writes its y bounds max-first; a box with min > max on an axis contains no point, so
     # instant-ngp would render background only.  The corners are sorted per axis here (builder's decision).
+    # PXT_STRICT_AABB=1 keeps the corners as given (instant-ngp's behaviour: an empty box); otherwise a swapped pair is
+    # sorted WITH a warning, once per process - a deviation from the reference that must not be silent.
+    swapped = [i for i, (a, b) in enumerate(zip(aabb[0], aabb[1])) if float(a) > float(b)]
+    if swapped and os.environ.get("PXT_STRICT_AABB", "0") == "1":
+        testbed.render_aabb.min = [float(a) for a in aabb[0]]
+        testbed.render_aabb.max = [float(b) for b in aabb[1]]
+        testbed.exposure = 0.0
+        return testbed
+    if swapped and not _WARNED_AABB:
+        import warnings
+
+        _WARNED_AABB.append(True)
+        warnings.warn(f"render box {aabb} has min > max on axis {swapped}: instant-ngp would render background only "
+                      "(the box contains no point); the corners are sorted per axis here (PXT_STRICT_AABB=1 keeps them)",
+                      RuntimeWarning, stacklevel=2)
     testbed.render_aabb.min = [min(float(a), float(b)) for a, b in zip(aabb[0], aabb[1])]
     testbed.render_aabb.max = [max(float(a), float(b)) for a, b in zip(aabb[0], aabb[1])]
     testbed.exposure = 0.0

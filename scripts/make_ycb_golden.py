@@ -6,6 +6,13 @@ render box = box of the SfM points (get_nerf_aabb_from_sfm).  Mask and reference
 this is the TWO-render path.  CPU only (~3 min).
 
     python scripts/make_ycb_golden.py
+    python scripts/make_ycb_golden.py --refshape     # tests/golden/ycb_refshape_921.npz
+
+``--refshape``: the same frame with the reference's OWN camera shapes instead of the "query size / 0.3" stand-in:
+SfM camera 1 = 3072 x 3072, f 2700, c 1536 (scripts/create_sfm_from_obj.py:154-159) x 0.3 -> a 921 x 921 reference
+render and UNet pass (int(921.6): run_vis_on_poses.py:30-32), query 640 x 480 with the YCB-Video intrinsics
+fx 1066.778 / fy 1067.487 and the principal point forced to (319.5, 239.5) (pixtrack/utils/io.py:46-50).
+PXT_ORACLE_PROCS=n deals the renders' rows to n processes (bit-identical).
 """
 import sys
 import time
@@ -17,21 +24,25 @@ import numpy as np
 
 from oracle import frame_oracle as FO
 from oracle import ngp_oracle as NO
-from pixtrack_amd.synthetic import CRACKER_BOX_AABB, make_tracking_assets, perturb_pose
+from pixtrack_amd.synthetic import (CRACKER_BOX_AABB, REF_CAMERA_YCB, YCB_QUERY_FXY, make_tracking_assets,
+                                    perturb_pose)
 from pixtrack_amd.utils.ingp_utils import get_nerf_aabb_from_sfm
 
-OUT = ROOT / "tests" / "golden" / "ycb_640x480.npz"
+REFSHAPE = "--refshape" in sys.argv
+OUT = ROOT / "tests" / "golden" / ("ycb_refshape_921.npz" if REFSHAPE else "ycb_640x480.npz")
 SEED, W, H, SPP = 1021, 640, 480, 8
 
 
 def ycb_assets(n_frames=12):
+    kw = dict(ref_camera=REF_CAMERA_YCB, query_f=YCB_QUERY_FXY[0]) if REFSHAPE else {}
     return make_tracking_assets(seed=SEED, width=W, height=H, n_frames=n_frames, aabb=CRACKER_BOX_AABB,
-                                reference_scale=0.3, n_points=5600)
+                                reference_scale=0.3, n_points=5600, **kw)
 
 
 def ycb_query_camera(assets):
     f = float(assets["query_camera"]["params"][0])
-    return dict(model="OPENCV", width=W, height=H, params=np.array([f, f, 319.5, 239.5]))
+    fx, fy = YCB_QUERY_FXY if REFSHAPE else (f, f)
+    return dict(model="OPENCV", width=W, height=H, params=np.array([fx, fy, 319.5, 239.5]))
 
 
 def nearest_reference(assets, R):
@@ -67,6 +78,7 @@ def main():
                         ref_id=ref_id, R=ret["R"].numpy(), t=ret["t"].numpy(), cost=ret["cost"], iters=np.array(ret["iters"]),
                         n_points=ret["n_points"], mask_bits=np.packbits(ret["mask"].astype(np.uint8)),
                         mask_sum=int(ret["mask"].sum()), ref_rgba=keep["ref_rgba"].astype(np.float16),
+                        ref_wh=np.array(keep["ref_rgba"].shape[1::-1]), query_params=np.asarray(cam["params"]),
                         gt_R=np.stack([g[0] for g in gt]), gt_t=np.stack([g[1] for g in gt]))
     print("wrote", OUT, round(OUT.stat().st_size / 1e6, 2), "MB; total", round(time.time() - t_all, 1), "s")
 

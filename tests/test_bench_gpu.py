@@ -134,3 +134,44 @@ def test_more_gpus_than_the_node_has_is_refused(device):
                               "--config", cfg], capture_output=True, text=True, timeout=300, cwd=str(ROOT), env=env)
         assert out.returncode != 0, cfg
         assert "GPU(s) visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_objects8_every_object_tracks_at_640x480(device, k):
+    """BASELINE configs[3] at the metric's resolution: `bench.py --config objects8 --object-index k` for every
+    config/*.sh object (k = 0 .. 7) at 640 x 480, spp 8; every frame must be tracked."""
+    names = ["bottle", "cracker_box", "gimble", "motor_core", "pickle_rick", "premier_protein", "roncelli_blankk",
+             "spirit_level"]
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "objects8", "--object-index", str(k),
+                          "--steps", "12", "--warmup", "3", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert names[k] in d["config"]["workload"] and d["config"]["width"] == 640 and d["config"]["height"] == 480
+    assert d["tracked_ok"] == d["frames_total"] == 12, (names[k], d["tracked_ok"])
+    assert d["mean_rot_err_vs_gt_rad"] < 2e-2 and d["value"] > 100.0
+
+
+def test_eight_ranks_rehearsal_on_one_gpu(device):
+    """The driver's 8-GPU command shape with eight gloo ranks sharing cuda:0 (ports, NUMA binding, eight processes'
+    memory, the pose gather of eight ranks): the first real 8-GPU node must not also be the first 8-rank run."""
+    env = dict(os.environ, PXT_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", "29561", str(ROOT / "bench.py"), "--gpus", "8", "--steps", "6", "--warmup", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == list(range(8)) and d["dist_backend"] == "gloo"
+    assert len({r["pid"] for r in d["ranks"]}) == 8 and all(r["frames"] == 6 for r in d["ranks"])
+    assert d["frames_total"] == 48 == d["tracked_ok"] and d["scaling"] == "weak"
+    # eight independently seeded sequences: the gathered records are eight DIFFERENT tracks
+    assert d["value"] <= sum(r["frames_per_s"] for r in d["ranks"]) * 1.001
+    # the objects8 workload on the same shape: rank r tracks object r
+    cmd = cmd[:-6] + ["--gpus", "8", "--steps", "4", "--warmup", "2", "--config", "objects8"]
+    cmd[cmd.index("29561")] = "29563"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["ranks_seen"] == list(range(8)) and d["frames_total"] == 32 == d["tracked_ok"]

@@ -130,6 +130,28 @@ def test_instant_ngp_param_split_and_round_trip(snap, tmp_path):
             assert blk.any()
 
 
+def test_snapshot_colour_space_flag(snap, tmp_path):
+    """instant-ngp's shade kernel converts a finished ray's colour sRGB -> linear unless the snapshot was trained in
+    linear colours (training.linear_colors = dataset.is_hdr).  Default (LDR images, pixtrack's case): convert."""
+    import dataclasses
+
+    d = ngp.to_instant_ngp(snap)
+    assert d["snapshot"]["nerf"]["dataset"]["is_hdr"] is False and ngp.from_instant_ngp(d).linear_colors is False
+    del d["snapshot"]["nerf"]["dataset"]["is_hdr"]  # a snapshot without the key: convert
+    assert ngp.from_instant_ngp(d).linear_colors is False
+    d["snapshot"]["nerf"]["dataset"]["is_hdr"] = True
+    assert ngp.from_instant_ngp(d).linear_colors is True
+    d["snapshot"]["nerf"]["linear_colors"] = False  # an explicit flag wins over the dataset's
+    assert ngp.from_instant_ngp(d).linear_colors is False
+    hdr = dataclasses.replace(snap, linear_colors=True)
+    assert ngp.from_instant_ngp(ngp.to_instant_ngp(hdr)).linear_colors is True
+    path = tmp_path / "own.msgpack"
+    ngp.save_snapshot(str(path), hdr)
+    assert ngp.load_snapshot_file(str(path)).linear_colors is True
+    ngp.save_snapshot(str(path), snap)
+    assert ngp.load_snapshot_file(str(path)).linear_colors is False
+
+
 def test_instant_ngp_density_threshold_and_dtype(snap):
     d = ngp.to_instant_ngp(snap)
     cells = 128**3

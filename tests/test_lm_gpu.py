@@ -276,3 +276,45 @@ def test_dirty_workspace_and_back_to_back_launches(device):
     second = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), dirty)
     r1, r2 = first.result(), second.result()
     assert torch.equal(r1.T.as12(), want.T.as12()) and torch.equal(r2.T.as12(), want.T.as12())
+
+
+def test_forced_timeout_then_workspace_reuse(device):
+    """a launch that times out must not poison the next launch on the same workspace.  A spin
+    bound of ONE poll makes the inter-workgroup wait of a 128-workgroup grid give up (PXT_E_TIMEOUT -> PxtError);
+    workgroups that lagged may still publish granules of an epoch the others never finished.  The kernel advances its
+    tag base by a margin on that path and the host zeroes the workspace: the next launch must return bit for bit what
+    a fresh workspace returns - also when the host's zeroing is bypassed (raw op call on the poisoned workspace)."""
+    from pixtrack_amd.ops import ops
+
+    sc = make_lm_scene(seed=1006, width=320, height=240, n_points=2048, sigma_px=2.0)
+    lam = lambdas(CONSTS)
+    packs = []
+    for level in reversed(range(3)):
+        fmap, fref, Cc, cam = pack_level(sc, level, device, sc.camera)
+        packs.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    nbytes = int(_lib.lib().pxt_lm_workspace_bytes())
+    good = PixTrackOptimizer(dict(num_iters=150, pad=1))
+    fresh = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, good.native_conf(),
+                                            torch.zeros(nbytes, dtype=torch.uint8, device=device)).result()
+    assert not fresh.failed
+    bad = PixTrackOptimizer(dict(num_iters=150, pad=1, spin_limit=1))
+    for zero_on_host in (True, False):
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        # a few healthy launches first, so that the tag base is not 0 and both granule areas hold old epochs
+        for _ in range(3):
+            PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, good.native_conf(), ws).result()
+        timed_out = 0
+        for _ in range(4):
+            pend = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, bad.native_conf(), ws)
+            if not zero_on_host:
+                pend._keep = None  # (PendingLM.result() then has no workspace to zero: the kernel's margin alone)
+            try:
+                pend.result()
+            except _lib.PxtError as e:
+                assert "status" in str(e)
+                timed_out += 1
+            torch.cuda.synchronize()
+        assert timed_out >= 1, "a one-poll spin bound did not time out on a 128-workgroup grid"
+        again = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, good.native_conf(), ws).result()
+        assert torch.equal(again.T.as12(), fresh.T.as12()) and again.iters == fresh.iters

@@ -21,7 +21,8 @@ def snap():
 
 def oracle_model(snap):
     return NO.NgpModel(grid=snap.grid, mlp=snap.mlp_dict(), occupancy=snap.occupancy, cascades=snap.cascades,
-                       aabb_scale=snap.aabb_scale, cone_angle=snap.cone_angle, depth_scale=1.0 / snap.scale)
+                       aabb_scale=snap.aabb_scale, cone_angle=snap.cone_angle, depth_scale=1.0 / snap.scale,
+                       linear_colors=snap.linear_colors)
 
 
 def ngp_camera(offset_dir, dist, up=(0.0, 1.0, 0.0)):

@@ -164,7 +164,26 @@ def test_kat7_constant_density_slab_transmittance():
     img = NO.render(m, v)
     sig16 = float(np.exp(np.float32(np.float16(math.log(sigma)))))
     assert np.allclose(img[..., 3], 1 - math.exp(-sig16 * 1.0), atol=3e-3)
-    assert np.allclose(img[..., :3], 0.5 * img[..., 3:4], atol=1e-6)  # sigmoid(0) = 0.5, premultiplied
+    # sigmoid(0) = 0.5, premultiplied, then instant-ngp's srgb_to_linear on the finished ray (Shade, LDR training set)
+    assert np.allclose(img[..., :3], NO.srgb_to_linear(0.5 * img[..., 3:4]), atol=1e-6)
+    m.linear_colors = True  # a snapshot trained in linear colours: no conversion
+    assert np.allclose(NO.render(m, v)[..., :3], 0.5 * img[..., 3:4], atol=1e-6)
+    m.linear_colors = False
+    vd = NO.View(cam=cam, focal=1e6, width=2, height=2, spp=1, min_transmittance=1e-12, background=(0, 0, 0, 0), mode=1)
+    dimg = NO.render(m, vd)  # Depth mode is never converted: expected depth of a uniform slab entered at z = 1
+    assert np.all(dimg[..., 0] > dimg[..., 3] * 1.0) and np.all(dimg[..., 0] < dimg[..., 3] * 2.0)
+    # an opaque ray: the early-out renormalises to exactly sigmoid(0) = 0.5 -> srgb_to_linear(0.5) = 0.2140
+    d2[0, 0] = np.float16(math.log(400.0))
+    vo = NO.View(cam=cam, focal=1e6, width=2, height=2, spp=1, min_transmittance=1e-4, background=(0, 0, 0, 0))
+    oimg = NO.render(m, vo)
+    assert np.allclose(oimg[..., 3], 1.0, atol=1e-6) and np.allclose(oimg[..., :3], 0.21404, atol=2e-5)
+
+
+def test_kat7_srgb_to_linear_known_values():
+    x = np.array([0.0, 0.04045, 0.0405, 0.5, 1.0], np.float32)
+    want = [0.0, 0.04045 / 12.92, ((0.0405 + 0.055) / 1.055) ** 2.4, ((0.5 + 0.055) / 1.055) ** 2.4, 1.0]
+    assert np.allclose(NO.srgb_to_linear(x), want, rtol=2e-6, atol=1e-9)
+    assert abs(float(NO.srgb_to_linear(np.float32(0.5))) - 0.21404114) < 1e-6
 
 
 def test_kat6_unet_shapes_and_resize():
@@ -192,3 +211,57 @@ def test_kat8_tracker_policy_cost_gate():
             thr = c + 0.1 * c
         out.append(bool(ok and c <= thr))
     assert out == [True, True, False, False, False, True] and abs(thr - 0.011) < 1e-12
+
+
+def test_kat7_tiled_render_is_the_serial_render():
+    """oracle.ngp_oracle.render_parallel (rows dealt to worker processes: fixture generators, bench.py's cpu_baseline)
+    returns the serial render bit for bit, counts included, whatever the tiling."""
+    from oracle import frame_oracle as FO
+    from pixtrack_amd.synthetic import make_tracking_assets
+
+    a = make_tracking_assets(seed=1002, width=96, height=72, n_frames=1, n_points=600)
+    ngp = FO.ngp_model(a["snapshot"])
+    R, t = a["gt_poses"][0]
+    qcam = FO.colmap_camera_to_pix(a["query_camera"])
+    for mode in (0, 1):
+        v = FO.nerf_view(a["snapshot"], a["nerf2sfm"], a["aabb"], R, t, qcam, mode, 2)
+        img, st = NO.render(ngp, v, True)
+        assert st["samples"] > 1000 and img[..., 3].max() > 0.5
+        for procs, step in ((2, 0), (3, 7)):
+            img2, st2 = NO.render_parallel(ngp, v, procs, True, rows_per_job=step)
+            assert np.array_equal(img, img2) and st == st2
+        part = NO.render(ngp, v, rows=(30, 41))
+        assert np.array_equal(part, img[30:41])
+
+
+def test_render_box_with_swapped_corners_warns_once(monkeypatch):
+    """config/motor_core.sh writes its y bounds max-first.  The corners are sorted per axis - with a warning,
+    never silently; PXT_STRICT_AABB=1 keeps them as given (instant-ngp: an empty box)."""
+    import warnings
+
+    from pixtrack_amd.utils import ingp_utils
+
+    class _TB:  # the part of Testbed that initialize_ingp touches, without a device
+        def __init__(self, *a, **k):
+            import types
+
+            self.nerf = types.SimpleNamespace()
+            self.render_aabb = types.SimpleNamespace(min=None, max=None)
+
+        def load_snapshot(self, p):
+            pass
+
+    import pixtrack_amd.ngp as ngp_mod
+
+    monkeypatch.setattr(ngp_mod, "Testbed", _TB)
+    monkeypatch.setattr(ingp_utils, "_WARNED_AABB", [])
+    box = [[0.1, 0.9, 0.2], [0.6, 0.3, 0.8]]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tb = ingp_utils.initialize_ingp("x", box)
+        tb2 = ingp_utils.initialize_ingp("x", box)
+    assert tb.render_aabb.min == [0.1, 0.3, 0.2] and tb.render_aabb.max == [0.6, 0.9, 0.8] and tb2.render_aabb.min == tb.render_aabb.min
+    assert len([x for x in w if "min > max" in str(x.message)]) == 1
+    monkeypatch.setenv("PXT_STRICT_AABB", "1")
+    tb3 = ingp_utils.initialize_ingp("x", box)
+    assert tb3.render_aabb.min == [0.1, 0.9, 0.2] and tb3.render_aabb.max == [0.6, 0.3, 0.8]

