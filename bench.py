@@ -129,6 +129,7 @@ def cpu_baseline(assets, frames, first, ref_id, budget_s=110.0, max_frames=20, m
                 break
     finally:
         NO.DEFAULT_PROCS = procs_before
+        NO.close_pool()
     n = len(per_frame)
     t_frame = float(np.mean(per_frame))
     model = ""
@@ -520,6 +521,7 @@ def main():
     timer = StageTimer()
     timer.wrap(tracker.testbed, "render_device", "nerf_render")
     timer.wrap(tracker.testbed, "render_both_device", "nerf_render")
+    timer.wrap(tracker.testbed, "render_frame_device", "nerf_render")
     timer.wrap(tracker.localizer.extractor.model, "forward_packed_batch", "unet")
     timer.wrap(tracker.localizer.refiner, "refine_pose_using_features", "lm")
     timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")

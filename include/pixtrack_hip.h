@@ -106,10 +106,25 @@ int pxt_lm_refine(const float* p3d, const uint8_t* point_mask /* may be NULL */,
                   float* out /* device, 16+PXT_MAX_LEVELS */, float* log /* device or NULL */,
                   void* workspace /* device, pxt_lm_workspace_bytes() */, void* stream);
 
+/* pxt_lm_refine whose last act is the NEXT frame's camera: once the final pose stands, the kernel converts it
+ * (get_camera_in_world_from_pixpose -> sfm_to_nerf_pose -> nerf_matrix_to_ngp, float64, pixtrack/utils/pose_utils.py:24,
+ * pixtrack/utils/ingp_utils.py:47-63) and stores the 12 camera floats into up to two renderer camera slots
+ * (pxt_ngp_camera_slot) and, optionally, a host-visible record cam_out13 (12 floats, then 1.0 stored last with
+ * system-scope release).  A render enqueued behind this launch with pxt_ngp_render_frame(camera_from_slot = 1) then needs
+ * no conversion launch of its own (pxt_ngp_render_both_from_pose's one-thread kernel).  cam_host == NULL: pxt_lm_refine. */
+typedef struct {
+  double conv27[27];   /* nerf2sfm centroid (3), 3 / avglen, R (4x4 row-major), totp (3), snapshot scale, offset (3) */
+  float* cam_slot[2];  /* device float[12] each, or NULL */
+  float* cam_out13;    /* pinned host or device float[13], or NULL */
+} pxt_lm_camera;
+int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_points, const pxt_lm_level* levels_host,
+                      int32_t n_levels, const float* T_init_host, const pxt_lm_conf* conf_host, float* out, float* log,
+                      void* workspace, const pxt_lm_camera* cam_host, void* stream);
+
 /* Bytes of scratch pxt_lm_refine needs (control words + tagged partial sums), independent of N.  One workspace serves
  * one launch at a time; its content carries over between launches (the tags of a launch continue above those of the
- * previous one, so nothing is zeroed per launch) and may start as anything - zeroing it once after allocation is tidy,
- * not required. */
+ * previous one, so nothing is zeroed per launch).  Zero it once after allocation, and again after a launch that
+ * reported PXT_E_TIMEOUT in out[13] (the kernel also skips a margin of tags on that path). */
 int64_t pxt_lm_workspace_bytes(void);
 
 /* -------------------------------------------------------------------------
@@ -271,6 +286,27 @@ int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* view_host, c
                                   const double* conv27_host, float* cam_out13, float* out_rgba,
                                   float* out_depth_rgba, uint64_t* stats, void* stream);
 
+/* One render with the outputs the tracking loop consumes written by the renderer's last kernel itself, and - for a
+ * render queued behind the LM launch - the camera taken from this context's camera slot instead of a conversion launch
+ * (between-stage fusion).
+ *   mode 0 Shade, 1 Depth, 2 Shade + Depth of the same view in one march (pxt_ngp_render_both).
+ *   out->rgba / depth_rgba : the float32 images of pxt_ngp_render(_both); each may be NULL when its 8-bit stand-in is given
+ *   out->rgb_u8  [H][W][3] : get_nerf_image's `(rgba[:, :, :3] * 255).astype(uint8)` of the Shade image
+ *                            (pixtrack/visualization/run_vis_on_poses.py:52-54, alpha_thresh 0) - what pxt_rgba_to_u8 makes of rgba
+ *   out->depth_nz [H][W]   : 1 where `uint8(depth * 255) != 0` - get_mask's plane before the morphology
+ *                            (pixtrack/pose_trackers/pixloc_tracker_r9.py:210-212); feed it to pxt_depth_mask_plane
+ *   camera_from_slot != 0  : view_host->cam is ignored; the 12 camera floats are read from pxt_ngp_camera_slot(ctx),
+ *                            which an earlier kernel of the same stream wrote (pxt_lm_refine_cam's epilogue). */
+typedef struct {
+  float* rgba;
+  float* depth_rgba;
+  uint8_t* rgb_u8;
+  uint8_t* depth_nz;
+} pxt_ngp_outputs;
+int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* view_host, int32_t mode, int32_t camera_from_slot,
+                         const pxt_ngp_outputs* out, uint64_t* stats, void* stream);
+float* pxt_ngp_camera_slot(pxt_ngp* ctx); /* device float[12], owned by the context */
+
 /* A render of >= 2^19 rays runs as n pipelines over equal slices of the rays, on the caller's
  * stream and n-1 internal side streams joined before the final resolve: the image is bit for bit
  * the same, the kernel chains overlap (the latency-bound march of one slice beside the L1-bound
@@ -299,6 +335,11 @@ int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, int32_t n, f
  * erode 5x5 x n_erode -> dilate 5x5 x n_dilate.  tmp: 2*H*W bytes. */
 int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int32_t n_erode,
                    int32_t n_dilate, uint8_t* mask_out, uint8_t* tmp, void* stream);
+/* The same mask from the `uint8(depth * 255) != 0` byte plane a render wrote itself (pxt_ngp_render_frame's depth_nz):
+ * bit for bit pxt_depth_mask of that render's float depth image.  tmp (2*H*W bytes) is only needed when
+ * 2 * (n_erode + n_dilate) > 16 and may be NULL otherwise. */
+int pxt_depth_mask_plane(const uint8_t* depth_nz, int32_t H, int32_t W, int32_t n_erode, int32_t n_dilate,
+                         uint8_t* mask_out, uint8_t* tmp, void* stream);
 /* get_nerf_image tail (run_vis_on_poses.py:52-54): alpha threshold, *255, ->uint8. */
 int pxt_rgba_to_u8(const float* rgba, int32_t H, int32_t W, float alpha_thresh, uint8_t* rgb_out,
                    void* stream);

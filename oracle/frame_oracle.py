@@ -51,6 +51,15 @@ def colmap_camera_to_pix(cam) -> torch.Tensor:
 
 
 def ngp_model(snapshot) -> NO.NgpModel:
+    """The oracle's model of a snapshot, built once per snapshot object (ngp_oracle.render_parallel keeps its worker
+    processes per model)."""
+    m = getattr(snapshot, "_oracle_model", None)
+    if m is None:
+        m = snapshot._oracle_model = _ngp_model(snapshot)
+    return m
+
+
+def _ngp_model(snapshot) -> NO.NgpModel:
     return NO.NgpModel(grid=snapshot.grid, mlp=snapshot.mlp_dict(), occupancy=snapshot.occupancy,
                        cascades=snapshot.cascades, aabb_scale=snapshot.aabb_scale, cone_angle=snapshot.cone_angle,
                        depth_scale=1.0 / snapshot.scale, linear_colors=bool(getattr(snapshot, "linear_colors", False)))

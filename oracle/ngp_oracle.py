@@ -278,9 +278,11 @@ class View:
     mode: int = 0  # 0 Shade, 1 Depth
 
 
-def generate_rays(v: View):
+def generate_rays(v: View, rows=None):
+    """Rays of the given image rows (an index array; default: all), row-major; every ray's arithmetic is per pixel."""
     W, H = v.width, v.height
-    px, py = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    ry = np.arange(H, dtype=np.float32) if rows is None else np.asarray(rows).astype(np.float32)
+    px, py = np.meshgrid(np.arange(W, dtype=np.float32), ry)
     u = ((px + F32(0.5)) / F32(W)).astype(np.float32)
     w_ = ((py + F32(0.5)) / F32(H)).astype(np.float32)
     dx = ((u - F32(0.5)) * F32(W) / F32(v.focal)).astype(np.float32).ravel()
@@ -313,105 +315,122 @@ def ray_aabb(o, d, lo, hi):
     return tmin, tmax, idir
 
 
-def render(m: NgpModel, v: View, return_stats: bool = False, rows: Tuple[int, int] = None):
-    """Returns float32 [H, W, 4] linear premultiplied RGBA.  ``rows = (r0, r1)``: only image rows r0 <= y < r1
-    ([r1 - r0, W, 4]; every ray is computed exactly as in the full render - rays are independent and keep their
-    global pixel index for the start jitter), the unit render_parallel deals to worker processes.
+def _row_list(v: View, rows) -> np.ndarray:
+    if rows is None:
+        return np.arange(v.height, dtype=np.int64)
+    if isinstance(rows, tuple) and len(rows) == 2:
+        return np.arange(int(rows[0]), int(rows[1]), dtype=np.int64)
+    return np.asarray(rows, np.int64).reshape(-1)
+
+
+def render(m: NgpModel, v: View, return_stats: bool = False, rows=None):
+    """Returns float32 [H, W, 4] linear premultiplied RGBA.  ``rows``: only these image rows - (r0, r1) for
+    r0 <= y < r1, or a list of row indices - as [len(rows), W, 4]; every ray is computed exactly as in the full render
+    (rays are independent and keep their global pixel index for the start jitter): the unit render_parallel deals to
+    worker processes.  The spp passes of a pixel are marched TOGETHER as independent rays of one batch (an eighth of the
+    numpy calls of a pass-by-pass loop) and summed in pass order at the end: the arithmetic of every ray and the
+    order of the spp mean are those of a sequential loop over the passes.
     With DEFAULT_PROCS > 1 (``$PXT_ORACLE_PROCS``; the fixture generators and bench.py's cpu_baseline set it) a
     full render is dealt to that many processes - same image, bit for bit."""
-    if rows is None and DEFAULT_PROCS > 1 and not _PAR:
+    if rows is None and DEFAULT_PROCS > 1 and not _PAR.get("worker"):
         return render_parallel(m, v, DEFAULT_PROCS, return_stats)
-    o, d, fwd = generate_rays(v)
-    r0, r1 = (0, v.height) if rows is None else (int(rows[0]), int(rows[1]))
-    sel = slice(r0 * v.width, r1 * v.width)
-    o, d = o[sel], d[sel]
-    n = o.shape[0]
+    rl = _row_list(v, rows)
+    o1, d1, fwd = generate_rays(v, rl)
+    n1 = o1.shape[0]
     half = F32(m.aabb_scale / 2.0)
     scene_lo, scene_hi = F32(0.5) - half, F32(0.5) + half
     lo = np.maximum(np.asarray(v.aabb_min, np.float32), scene_lo)
     hi = np.minimum(np.asarray(v.aabb_max, np.float32), scene_hi)
-    tmin, tmax, idir = ray_aabb(o, d, lo, hi)
-    hit = tmax > np.maximum(tmin, F32(0.0))
+    tmin1, tmax1, idir1 = ray_aabb(o1, d1, lo, hi)
+    hit1 = tmax1 > np.maximum(tmin1, F32(0.0))
     dt_lo, dt_hi = MIN_STEP, max_step(m)
-    out = np.zeros((n, 4), np.float32)
-    pix = np.arange(r0 * v.width, r1 * v.width, dtype=np.int64)
-    n_samples = 0
-    zdot = ((d[:, 0] * fwd[0] + d[:, 1] * fwd[1]).astype(np.float32) + d[:, 2] * fwd[2]).astype(np.float32)
+    pix1 = (rl[:, None] * v.width + np.arange(v.width, dtype=np.int64)[None, :]).reshape(-1)
+    zdot1 = ((d1[:, 0] * fwd[0] + d1[:, 1] * fwd[1]).astype(np.float32) + d1[:, 2] * fwd[2]).astype(np.float32)
     inv_s = F32(1.0 / m.aabb_scale)
-    for s in range(v.spp):
-        t = (np.maximum(tmin, F32(0.0)) + F32(1e-6)).astype(np.float32)
-        t = (t + start_jitter(pix, s) * calc_dt(t, m.cone_angle, dt_lo, dt_hi)).astype(np.float32)
-        alive = hit.copy()
-        T = np.ones(n, np.float32)
-        rgba = np.zeros((n, 4), np.float32)
-        while alive.any():
-            idx = np.nonzero(alive)[0]
-            # -- find the next occupied sample of every live ray
-            ti = t[idx]
-            searching = np.ones(idx.shape[0], bool)
-            found = np.zeros(idx.shape[0], bool)
-            while searching.any():
-                k = np.nonzero(searching)[0]
-                tk = ti[k]
-                pos = (o[idx[k]] + tk[:, None] * d[idx[k]]).astype(np.float32)
-                out_of_box = tk >= tmax[idx[k]]
-                dtk = calc_dt(tk, m.cone_angle, dt_lo, dt_hi)
-                mip = mip_from_dt(dtk, pos, m.cascades)
-                occ = occupied(m, pos, mip) & ~out_of_box
-                found[k[occ]] = True
-                searching[k[occ | out_of_box]] = False
-                adv = ~(occ | out_of_box)
-                if adv.any():
-                    ka = k[adv]
-                    ti[ka] = advance_to_next_voxel(tk[adv], pos[adv], d[idx[ka]], idir[idx[ka]], mip[adv],
-                                                   m.cone_angle, dt_lo, dt_hi)
-            t[idx] = ti
-            alive[idx[~found]] = False
-            idx = idx[found]
-            if idx.size == 0:
-                break
-            # -- evaluate + composite one sample per live ray
-            ti = t[idx]
-            pos = (o[idx] + ti[:, None] * d[idx]).astype(np.float32)
-            dti = calc_dt(ti, m.cone_angle, dt_lo, dt_hi)
-            unit = ((pos - scene_lo) * inv_s).astype(np.float32)
-            density, rgb = network(m, unit, d[idx])
-            n_samples += idx.size
-            if v.mode == 1:
-                depth = (ti * zdot[idx] * F32(m.depth_scale)).astype(np.float32)
-                rgb = np.repeat(depth[:, None], 3, 1)
-            alpha = (F32(1.0) - np.exp(-density * dti)).astype(np.float32)
-            wgt = (alpha * T[idx]).astype(np.float32)
-            rgba[idx, :3] += wgt[:, None] * rgb
-            rgba[idx, 3] += wgt
-            T[idx] = (T[idx] * (F32(1.0) - alpha)).astype(np.float32)
-            done = T[idx] < F32(v.min_transmittance)
-            if done.any():
-                di = idx[done]
-                rgba[di] = rgba[di] / rgba[di, 3:4]
-                alive[di] = False
-            t[idx] = (ti + dti).astype(np.float32)
-        if v.mode == 0 and not m.linear_colors:
-            rgba[:, :3] = srgb_to_linear(rgba[:, :3])
-        out += rgba
+    S = int(v.spp)
+    # ray r = s * n1 + i: pass s of pixel i
+    o, d, idir = np.tile(o1, (S, 1)), np.tile(d1, (S, 1)), np.tile(idir1, (S, 1))
+    tmax, zdot = np.tile(tmax1, S), np.tile(zdot1, S)
+    n = n1 * S
+    t0 = (np.maximum(tmin1, F32(0.0)) + F32(1e-6)).astype(np.float32)
+    dt0 = calc_dt(t0, m.cone_angle, dt_lo, dt_hi)
+    t = np.concatenate([(t0 + start_jitter(pix1, s) * dt0).astype(np.float32) for s in range(S)])
+    alive = np.tile(hit1, S)
+    T = np.ones(n, np.float32)
+    rgba = np.zeros((n, 4), np.float32)
+    n_samples = 0
+    while alive.any():
+        idx = np.nonzero(alive)[0]
+        # -- find the next occupied sample of every live ray
+        ti = t[idx]
+        searching = np.ones(idx.shape[0], bool)
+        found = np.zeros(idx.shape[0], bool)
+        while searching.any():
+            k = np.nonzero(searching)[0]
+            tk = ti[k]
+            pos = (o[idx[k]] + tk[:, None] * d[idx[k]]).astype(np.float32)
+            out_of_box = tk >= tmax[idx[k]]
+            dtk = calc_dt(tk, m.cone_angle, dt_lo, dt_hi)
+            mip = mip_from_dt(dtk, pos, m.cascades)
+            occ = occupied(m, pos, mip) & ~out_of_box
+            found[k[occ]] = True
+            searching[k[occ | out_of_box]] = False
+            adv = ~(occ | out_of_box)
+            if adv.any():
+                ka = k[adv]
+                ti[ka] = advance_to_next_voxel(tk[adv], pos[adv], d[idx[ka]], idir[idx[ka]], mip[adv],
+                                               m.cone_angle, dt_lo, dt_hi)
+        t[idx] = ti
+        alive[idx[~found]] = False
+        idx = idx[found]
+        if idx.size == 0:
+            break
+        # -- evaluate + composite one sample per live ray
+        ti = t[idx]
+        pos = (o[idx] + ti[:, None] * d[idx]).astype(np.float32)
+        dti = calc_dt(ti, m.cone_angle, dt_lo, dt_hi)
+        unit = ((pos - scene_lo) * inv_s).astype(np.float32)
+        density, rgb = network(m, unit, d[idx])
+        n_samples += idx.size
+        if v.mode == 1:
+            depth = (ti * zdot[idx] * F32(m.depth_scale)).astype(np.float32)
+            rgb = np.repeat(depth[:, None], 3, 1)
+        alpha = (F32(1.0) - np.exp(-density * dti)).astype(np.float32)
+        wgt = (alpha * T[idx]).astype(np.float32)
+        rgba[idx, :3] += wgt[:, None] * rgb
+        rgba[idx, 3] += wgt
+        T[idx] = (T[idx] * (F32(1.0) - alpha)).astype(np.float32)
+        done = T[idx] < F32(v.min_transmittance)
+        if done.any():
+            di = idx[done]
+            rgba[di] = rgba[di] / rgba[di, 3:4]
+            alive[di] = False
+        t[idx] = (ti + dti).astype(np.float32)
+    if v.mode == 0 and not m.linear_colors:
+        rgba[:, :3] = srgb_to_linear(rgba[:, :3])
+    out = np.zeros((n1, 4), np.float32)
+    for s in range(S):  # the sequential mean over the passes: ((r0 + r1) + r2) + ...
+        out += rgba[s * n1:(s + 1) * n1]
     out /= F32(v.spp)
     bg = np.asarray(v.background, np.float32)
     a = out[:, 3:4]
     out[:, :3] += bg[:3] * bg[3] * (1 - a)
     out[:, 3:4] = a + bg[3] * (1 - a)
-    img = out.reshape(r1 - r0, v.width, 4)
+    img = out.reshape(rl.shape[0], v.width, 4)
     if return_stats:
-        return img, {"samples": int(n_samples), "rays_hit": int(hit.sum()) * v.spp}
+        return img, {"samples": int(n_samples), "rays_hit": int(hit1.sum()) * v.spp}
     return img
 
 
 # ---- the same render on several host cores ------------------------------------------------------
 _PAR = {}
+_POOL = {}
 DEFAULT_PROCS = int(os.environ.get("PXT_ORACLE_PROCS", "1") or 1)
 
 
 def _worker_init():
     """One BLAS thread per worker process (the workers ARE the parallelism)."""
+    _PAR["worker"] = True
     try:
         import threadpoolctl
 
@@ -421,32 +440,52 @@ def _worker_init():
 
 
 def _render_rows_job(job):
-    r0, r1 = job
-    return r0, render(_PAR["m"], _PAR["v"], return_stats=True, rows=(r0, r1))
+    v, rows = job
+    return rows, render(_PAR["m"], v, return_stats=True, rows=rows)
+
+
+def close_pool():
+    """Ends the worker processes render_parallel keeps between calls."""
+    pool = _POOL.pop("pool", None)
+    _POOL.clear()
+    _PAR.pop("m", None)
+    if pool is not None:
+        pool.terminate()
+        pool.join()
 
 
 def render_parallel(m: NgpModel, v: View, procs: int, return_stats: bool = False, rows_per_job: int = 0):
-    """render() with the image rows dealt to ``procs`` forked worker processes (the model is shared copy-on-write).
-    Rays are independent, so the image and the counts are those of the serial render - bit for bit as long as the
-    BLAS rows of the MLP products do not depend on the batch they sit in (tests/test_oracle_kats.py asserts it here;
-    bench.py's cpu_baseline re-asserts it on the box it runs on)."""
+    """render() with the image rows dealt to ``procs`` forked worker processes.  The workers are forked once per
+    (model, procs) - they see the model copy-on-write - and kept for later calls (a frame needs two renders; forking
+    from a process with a GPU context mapped costs tens of ms per worker); close_pool() ends them.  Rays are
+    independent, so the image and the counts are those of the serial render - bit for bit (the small-batch GEMM
+    padding in _layer is what makes a sample's value independent of the batch it sits in;
+    tests/test_oracle_kats.py asserts the equality here, bench.py's cpu_baseline on the box it runs on)."""
     import multiprocessing as mp
 
     procs = max(1, int(procs))
     if procs == 1:
         return render(m, v, return_stats)
-    step = rows_per_job or max(1, v.height // (procs * 4))
-    jobs = [(r, min(r + step, v.height)) for r in range(0, v.height, step)]
-    _PAR["m"], _PAR["v"] = m, v
-    try:
-        with mp.get_context("fork").Pool(procs, initializer=_worker_init) as pool:
-            parts = pool.map(_render_rows_job, jobs, chunksize=1)
-    finally:
-        _PAR.clear()
+    # (the workers see the model and this module's switches as they were at the fork: all of it is in the key)
+    key = (id(m), procs, bool(m.linear_colors), m.cascades, float(m.cone_angle), tuple(sorted((k, str(x)) for k, x in VARIANT.items())))
+    if _POOL.get("key") != key:
+        close_pool()
+        _PAR["m"] = m
+        _POOL["pool"] = mp.get_context("fork").Pool(procs, initializer=_worker_init)
+        _POOL["key"] = key
+        _POOL["model"] = m  # (keeps id(m) from being recycled while the pool lives)
+    # one job per worker, rows dealt round-robin (rows k, k + P, k + 2P, ...): the object's rows - far more expensive than
+    # rows of background - spread evenly, and every job is one large batch (the march loop's cost per step is mostly
+    # Python / numpy call overhead).  ``rows_per_job`` > 0: contiguous bands of that many rows instead (tests).
+    if rows_per_job:
+        sets = [np.arange(r, min(r + rows_per_job, v.height)) for r in range(0, v.height, rows_per_job)]
+    else:
+        sets = [np.arange(k, v.height, procs) for k in range(min(procs, v.height))]
+    parts = _POOL["pool"].map(_render_rows_job, [(v, rs) for rs in sets], chunksize=1)
     img = np.empty((v.height, v.width, 4), np.float32)
     stats = {"samples": 0, "rays_hit": 0}
-    for r0, (part, st) in parts:
-        img[r0:r0 + part.shape[0]] = part
+    for rs, (part, st) in parts:
+        img[rs] = part
         stats["samples"] += st["samples"]
         stats["rays_hit"] += st["rays_hit"]
     return (img, stats) if return_stats else img

@@ -101,6 +101,14 @@ class NgpView(C.Structure):
     ]
 
 
+class NgpOutputs(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("depth_rgba", C.c_void_p), ("rgb_u8", C.c_void_p), ("depth_nz", C.c_void_p)]
+
+
+class LmCamera(C.Structure):
+    _fields_ = [("conv27", C.c_double * 27), ("cam_slot", C.c_void_p * 2), ("cam_out13", C.c_void_p)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); every symbol include/pixtrack_hip.h declares.
@@ -112,6 +120,10 @@ PROTOTYPES = {
     "pxt_lm_refine": (
         C.c_int,
         [_VP, _VP, _I32, C.POINTER(LmLevel), _I32, _VP, C.POINTER(LmConf), _VP, _VP, _VP, _VP],
+    ),
+    "pxt_lm_refine_cam": (
+        C.c_int,
+        [_VP, _VP, _I32, C.POINTER(LmLevel), _I32, _VP, C.POINTER(LmConf), _VP, _VP, _VP, C.POINTER(LmCamera), _VP],
     ),
     "pxt_lm_workspace_bytes": (_I64, []),
     "pxt_sample_sparse": (C.c_int, [_VP, _I32, _VP, C.POINTER(SampleLevel), _I32, _I32, _I32, _VP, _VP]),
@@ -143,11 +155,14 @@ PROTOTYPES = {
     "pxt_ngp_render": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP]),
     "pxt_ngp_render_both": (C.c_int, [_VP, C.POINTER(NgpView), _VP, _VP, _VP, _VP]),
     "pxt_ngp_render_both_from_pose": (C.c_int, [_VP, C.POINTER(NgpView), _VP, C.POINTER(C.c_double), _VP, _VP, _VP, _VP, _VP]),
+    "pxt_ngp_render_frame": (C.c_int, [_VP, C.POINTER(NgpView), _I32, _I32, C.POINTER(NgpOutputs), _VP, _VP]),
+    "pxt_ngp_camera_slot": (_VP, [_VP]),
     "pxt_ngp_set_pipelines": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_enable": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_read": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),
     "pxt_ngp_query": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _VP]),
     "pxt_depth_mask": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
+    "pxt_depth_mask_plane": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "pxt_rgba_to_u8": (C.c_int, [_VP, _I32, _I32, C.c_float, _VP, _VP]),
     "pxt_resize_linear": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I32, _I32, _VP]),
 }

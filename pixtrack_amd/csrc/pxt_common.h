@@ -100,4 +100,64 @@ __device__ inline float group_allreduce_sum(float v) {
   return v;
 }
 
+
+// ---- pose -> renderer camera -------------------------------------------------------------------------------
+// Pose (world -> camera, row-major R then t: the LM kernel's record) -> the NeRF renderer's camera (3x4, ngp
+// coordinates), in the float64 arithmetic of the host chain it stands in for: get_camera_in_world_from_pixpose
+// (pose_utils.py:24), sfm_to_nerf_pose (ingp_utils.py:47-63), instant-ngp's nerf_matrix_to_ngp.  The host recomputes
+// the camera when the pose reaches it and compares: a render that ran ahead of the host is used only if the 12 floats
+// are the same bits - hence no FMA contraction in here, whatever the file's flags (numpy does not fuse).
+struct PoseConv {
+  double centroid[3], scale3_over_avglen, Rn[16], totp[3], ngp_scale, ngp_offset[3];
+};
+__host__ inline PoseConv make_pose_conv(const double* conv27) {
+  PoseConv cv;
+  for (int i = 0; i < 3; ++i) cv.centroid[i] = conv27[i];
+  cv.scale3_over_avglen = conv27[3];
+  for (int i = 0; i < 16; ++i) cv.Rn[i] = conv27[4 + i];
+  for (int i = 0; i < 3; ++i) cv.totp[i] = conv27[20 + i];
+  cv.ngp_scale = conv27[23];
+  for (int i = 0; i < 3; ++i) cv.ngp_offset[i] = conv27[24 + i];
+  return cv;
+}
+__device__ inline void pose_to_camera_f64(const float* pose12, const PoseConv& cv, float* cam12) {
+#pragma clang fp contract(off)
+  double R[9], t[3];
+  for (int i = 0; i < 9; ++i) R[i] = (double)pose12[i];
+  for (int i = 0; i < 3; ++i) t[i] = (double)pose12[9 + i];
+  // camera in world: [R^T | (-R^T) t]
+  double c[16];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) c[4 * i + j] = R[3 * j + i];
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k) acc += (-R[3 * k + i]) * t[k];
+    c[4 * i + 3] = acc;
+  }
+  c[12] = c[13] = c[14] = 0.0; c[15] = 1.0;
+  // sfm_to_nerf_pose: camera y/z flip (columns 1, 2), rows 0 <-> 1, row 2 negated, recentre, scale, rotate, recentre
+  for (int i = 0; i < 4; ++i) { c[4 * i + 1] = -c[4 * i + 1]; c[4 * i + 2] = -c[4 * i + 2]; }
+  for (int j = 0; j < 4; ++j) { const double a = c[j]; c[j] = c[4 + j]; c[4 + j] = a; }
+  for (int j = 0; j < 4; ++j) c[8 + j] = -c[8 + j];
+  for (int i = 0; i < 3; ++i) { c[4 * i + 3] -= cv.centroid[i]; c[4 * i + 3] *= cv.scale3_over_avglen; }
+  double p[16];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += cv.Rn[4 * i + k] * c[4 * k + j];
+      p[4 * i + j] = acc;
+    }
+  for (int i = 0; i < 3; ++i) p[4 * i + 3] -= cv.totp[i];
+  // nerf_matrix_to_ngp: flip camera y/z, scale + offset the origin, rows (x, y, z) <- (y, z, x)
+  double m[12];
+  for (int i = 0; i < 3; ++i) {
+    m[4 * i + 0] = p[4 * i + 0];
+    m[4 * i + 1] = -p[4 * i + 1];
+    m[4 * i + 2] = -p[4 * i + 2];
+    m[4 * i + 3] = p[4 * i + 3] * cv.ngp_scale + cv.ngp_offset[i];
+  }
+  const int perm[3] = {1, 2, 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) cam12[4 * i + j] = (float)m[4 * perm[i] + j];
+}
+
 }  // namespace pxt

@@ -121,8 +121,13 @@ __device__ inline Row128 r_shr(Row128 a, int s) {
   return {(a.lo >> s) | (a.hi << (64 - s)), a.hi >> s};
 }
 
-__global__ __launch_bounds__(256) void depth_mask_bits_kernel(const float* __restrict__ rgba, int H, int W, int re,
+// PLANE: the input is the `!= 0` byte plane itself (written by the renderer's resolve kernel: pxt_ngp_render_frame's
+// depth_nz), not the float depth image - 1 byte instead of 16 per pixel on the chain between the render and the UNet.
+template <bool PLANE>
+__global__ __launch_bounds__(256) void depth_mask_bits_kernel(const void* __restrict__ src, int H, int W, int re,
                                                               int rd, uint8_t* __restrict__ out) {
+  const float* rgba = (const float*)src;
+  const uint8_t* plane = (const uint8_t*)src;
   __shared__ Row128 sA[kMH + 2 * 16], sB[kMH + 2 * 16];
   const int R = re + rd;                 // <= 16
   const int ah = kMH + 2 * R;            // rows y0 - R .. y0 + kMH + R - 1
@@ -139,8 +144,12 @@ __global__ __launch_bounds__(256) void depth_mask_bits_kernel(const float* __res
       const int xx = x0 - R + c;
       bool bit = true;
       if (c < kMW + 2 * R && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float f = rgba[4 * ((size_t)yy * W + xx)] * 255.0f;
-        bit = (((long long)f & 255) != 0);  // numpy float32 -> uint8 astype, then != 0
+        if (PLANE) {
+          bit = plane[(size_t)yy * W + xx] != 0;
+        } else {
+          const float f = rgba[4 * ((size_t)yy * W + xx)] * 255.0f;
+          bit = (((long long)f & 255) != 0);  // numpy float32 -> uint8 astype, then != 0
+        }
       }
       w[part] = __ballot(bit);
     }
@@ -280,8 +289,8 @@ extern "C" int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int
       hipLaunchKernelGGL(depth_mask_fused_kernel, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(64, 4), lds, s,
                          depth_rgba, H, W, re, rd, mask_out);
     else
-      hipLaunchKernelGGL(depth_mask_bits_kernel, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(256), 0, s,
-                         depth_rgba, H, W, re, rd, mask_out);
+      hipLaunchKernelGGL(depth_mask_bits_kernel<false>, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(256), 0, s,
+                         (const void*)depth_rgba, H, W, re, rd, mask_out);
     PXT_HIP_CHECK(hipGetLastError());
     return PXT_OK;
   }
@@ -296,6 +305,34 @@ extern "C" int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int
   for (int i = 0; i < n_dilate; ++i) {
     hipLaunchKernelGGL(morph5_kernel<false>, grd, blk, 0, s, a, H, W, b);
     uint8_t* t = a; a = b; b = t;
+  }
+  PXT_HIP_CHECK(hipMemcpyAsync(mask_out, a, n, hipMemcpyDeviceToDevice, s));
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int pxt_depth_mask_plane(const uint8_t* depth_nz, int32_t H, int32_t W, int32_t n_erode, int32_t n_dilate,
+                                    uint8_t* mask_out, uint8_t* tmp, void* stream) {
+  if (!depth_nz || !mask_out || H < 1 || W < 1 || n_erode < 0 || n_dilate < 0) return PXT_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = H * W;
+  const int re = 2 * n_erode, rd = 2 * n_dilate, R = re + rd;
+  if (R <= 16) {
+    hipLaunchKernelGGL(depth_mask_bits_kernel<true>, dim3((W + kMW - 1) / kMW, (H + kMH - 1) / kMH), dim3(256), 0, s,
+                       (const void*)depth_nz, H, W, re, rd, mask_out);
+    PXT_HIP_CHECK(hipGetLastError());
+    return PXT_OK;
+  }
+  if (!tmp) return PXT_E_ARG;  // larger structuring elements: the 5x5 passes one by one (2 * H * W bytes of scratch)
+  const uint8_t* a = depth_nz;
+  uint8_t* bufs[2] = {tmp, tmp + n};
+  int k = 0;
+  dim3 blk(64, 4), grd((W + 63) / 64, (H + 3) / 4);
+  for (int i = 0; i < n_erode + n_dilate; ++i) {
+    if (i < n_erode) hipLaunchKernelGGL(morph5_kernel<true>, grd, blk, 0, s, a, H, W, bufs[k]);
+    else hipLaunchKernelGGL(morph5_kernel<false>, grd, blk, 0, s, a, H, W, bufs[k]);
+    a = bufs[k];
+    k ^= 1;
   }
   PXT_HIP_CHECK(hipMemcpyAsync(mask_out, a, n, hipMemcpyDeviceToDevice, s));
   PXT_HIP_CHECK(hipGetLastError());

@@ -58,6 +58,11 @@ struct LmParams {
   float* log;
   unsigned long long* granules;  // [2][grid][kNAcc] {tag, value}
   unsigned* err;       // sticky error word
+  // the next render's camera, derived from the final pose in the epilogue (pxt_lm_refine_cam)
+  int cam_enabled;
+  PoseConv cam_conv;
+  float* cam_slot[2];
+  float* cam_out;
 };
 
 __device__ inline void robust_loss(int kind, float alpha, float scale, float x, float& loss,
@@ -642,6 +647,19 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
     // system-wide: a host that keeps `out` in pinned memory can poll this word instead of
     // waiting on an event (saves the ~25 us wake-up on the frame's critical path).
     __hip_atomic_store(&P.out[15], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ... and then the camera of the render queued behind this launch (one thread, float64: ~1 us after the record
+    // has left; the renderer's kernels start after this kernel ends, in stream order)
+    if (P.cam_enabled) {
+      float cam[12];
+      pose_to_camera_f64(s_T, P.cam_conv, cam);
+      for (int k = 0; k < 2; ++k)
+        if (P.cam_slot[k])
+          for (int i = 0; i < 12; ++i) P.cam_slot[k][i] = cam[i];
+      if (P.cam_out) {
+        for (int i = 0; i < 12; ++i) P.cam_out[i] = cam[i];
+        __hip_atomic_store(&P.cam_out[12], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -759,6 +777,13 @@ extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_
                              const pxt_lm_level* levels, int32_t n_levels, const float* T_init,
                              const pxt_lm_conf* conf, float* out, float* log, void* workspace,
                              void* stream) {
+  return pxt_lm_refine_cam(p3d, point_mask, n_points, levels, n_levels, T_init, conf, out, log, workspace, nullptr, stream);
+}
+
+extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_points,
+                                 const pxt_lm_level* levels, int32_t n_levels, const float* T_init,
+                                 const pxt_lm_conf* conf, float* out, float* log, void* workspace,
+                                 const pxt_lm_camera* cam, void* stream) {
   if (!p3d || !levels || !T_init || !conf || !out || !workspace) return PXT_E_ARG;
   if (n_levels < 1 || n_levels > PXT_MAX_LEVELS || n_points < 1) return PXT_E_ARG;
   if (conf->num_iters < 1 || conf->pad < 0) return PXT_E_ARG;
@@ -786,6 +811,17 @@ extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_
   P.conf = *conf;
   P.out = out;
   P.log = log;
+  P.cam_enabled = 0;
+  P.cam_slot[0] = P.cam_slot[1] = nullptr;
+  P.cam_out = nullptr;
+  if (cam) {
+    if (!cam->cam_slot[0] && !cam->cam_slot[1] && !cam->cam_out13) return PXT_E_ARG;
+    P.cam_enabled = 1;
+    P.cam_conv = make_pose_conv(cam->conv27);
+    P.cam_slot[0] = cam->cam_slot[0];
+    P.cam_slot[1] = cam->cam_slot[1];
+    P.cam_out = cam->cam_out13;
+  }
   char* ws = (char*)workspace;
   P.err = (unsigned*)ws;  // 256-byte control block, then the granule areas
   P.granules = (unsigned long long*)(ws + 256);

@@ -66,8 +66,10 @@ struct NgpParams {
   float min_T;
   int W, H, spp, mode;
   int srgb_to_linear;  // Shade: a finished ray's colour goes through srgb_to_linear before the spp mean (model.linear_colors == 0)
-  float* out;
-  float* out_depth;  // mode 2 only
+  float* out;        // float RGBA of the render's own mode (mode 2: the Shade image); may be null when an 8-bit output stands in
+  float* out_depth;  // mode 2: the Depth image (optional)
+  uint8_t* out_u8;   // optional [H][W][3]: (rgb * 255).astype(uint8) of the Shade image (modes 0, 2)
+  uint8_t* out_nz;   // optional [H][W]: uint8(depth * 255) != 0 of the Depth image (modes 1, 2): get_mask's plane
   unsigned long long* stats;
   long long enum_lo, enum_hi;  // the part of the ray enumeration this pipeline (slice) generates
 };
@@ -1154,56 +1156,18 @@ __global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const 
   }
 }
 
-// Pose (world -> camera, row-major R then t: the LM kernel's record) -> the renderer's camera, on the device, in
-// the float64 arithmetic of the host chain it stands in for: get_camera_in_world_from_pixpose (pose_utils.py:24),
-// sfm_to_nerf_pose (ingp_utils.py:47-63), nerf_matrix_to_ngp.  The host recomputes the camera when the pose
-// reaches it and compares: a render that ran ahead of the host is used only if the 12 floats are the same bits.
-struct PoseConv {
-  double centroid[3], scale3_over_avglen, Rn[16], totp[3], ngp_scale, ngp_offset[3];
-};
+// The camera of a render whose pose the host has not seen yet: pose_to_camera_f64 (pxt_common.h) in a one-thread launch
+// behind the LM kernel (pxt_ngp_render_both_from_pose), or - one dispatch less - in the LM kernel's own epilogue
+// (pxt_lm_refine_cam writes this context's camera slot; pxt_ngp_render_frame(camera_from_slot = 1) reads it).
 __global__ void ngp_pose_to_camera_kernel(const float* __restrict__ pose12, const PoseConv cv, float* __restrict__ cam_dev,
                                           float* __restrict__ cam_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double R[9], t[3];
-  for (int i = 0; i < 9; ++i) R[i] = (double)pose12[i];
-  for (int i = 0; i < 3; ++i) t[i] = (double)pose12[9 + i];
-  // camera in world: [R^T | (-R^T) t]
-  double c[16];
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) c[4 * i + j] = R[3 * j + i];
-    double acc = 0.0;
-    for (int k = 0; k < 3; ++k) acc += (-R[3 * k + i]) * t[k];
-    c[4 * i + 3] = acc;
+  float cam[12];
+  pose_to_camera_f64(pose12, cv, cam);
+  for (int i = 0; i < 12; ++i) {
+    cam_dev[i] = cam[i];
+    if (cam_out) cam_out[i] = cam[i];
   }
-  c[12] = c[13] = c[14] = 0.0; c[15] = 1.0;
-  // sfm_to_nerf_pose: camera y/z flip (columns 1, 2), rows 0 <-> 1, row 2 negated, recentre, scale, rotate, recentre
-  for (int i = 0; i < 4; ++i) { c[4 * i + 1] = -c[4 * i + 1]; c[4 * i + 2] = -c[4 * i + 2]; }
-  for (int j = 0; j < 4; ++j) { const double a = c[j]; c[j] = c[4 + j]; c[4 + j] = a; }
-  for (int j = 0; j < 4; ++j) c[8 + j] = -c[8 + j];
-  for (int i = 0; i < 3; ++i) { c[4 * i + 3] -= cv.centroid[i]; c[4 * i + 3] *= cv.scale3_over_avglen; }
-  double p[16];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      double acc = 0.0;
-      for (int k = 0; k < 4; ++k) acc += cv.Rn[4 * i + k] * c[4 * k + j];
-      p[4 * i + j] = acc;
-    }
-  for (int i = 0; i < 3; ++i) p[4 * i + 3] -= cv.totp[i];
-  // nerf_matrix_to_ngp: flip camera y/z, scale + offset the origin, rows (x, y, z) <- (y, z, x)
-  double m[12];
-  for (int i = 0; i < 3; ++i) {
-    m[4 * i + 0] = p[4 * i + 0];
-    m[4 * i + 1] = -p[4 * i + 1];
-    m[4 * i + 2] = -p[4 * i + 2];
-    m[4 * i + 3] = p[4 * i + 3] * cv.ngp_scale + cv.ngp_offset[i];
-  }
-  const int perm[3] = {1, 2, 0};
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 4; ++j) {
-      const float v = (float)m[4 * perm[i] + j];
-      cam_dev[4 * i + j] = v;
-      if (cam_out) cam_out[4 * i + j] = v;
-    }
   // cam_out[12] flips to 1 once the 12 floats are visible system-wide (the host polls it in pinned memory)
   if (cam_out) __hip_atomic_store(&cam_out[12], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1242,7 +1206,7 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         v[k] = (s0 + k < P.spp) ? src[s0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        vd[k] = (P.out_depth && s0 + k < P.spp) ? srcd[s0 + k] : 0.f;
+        vd[k] = (P.mode == 2 && s0 + k < P.spp) ? srcd[s0 + k] : 0.f;
       }
       if (P.mode != 1 && P.srgb_to_linear) {  // Shade colours only: mode 1's buffer holds depths
 #pragma unroll
@@ -1254,13 +1218,14 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
       for (int k = 0; k < 8; ++k) {  // sequential: ((v0 + v1) + v2) + ...
         if (s0 + k < P.spp) {
           ar += v[k].x; ag += v[k].y; ab += v[k].z; aa += v[k].w;
-          if (P.out_depth) ad += vd[k];
+          if (P.mode == 2) ad += vd[k];
         }
       }
     }
   }
   const float inv = 1.0f / (float)P.spp;
-  if (P.out_depth) {  // what a separate Depth-mode render would have written
+  float depth_x = 0.f;
+  if (P.mode == 2) {  // what a separate Depth-mode render would have written
     float4 od;
     od.w = aa * inv;
     od.x = od.y = od.z = ad * inv;
@@ -1268,7 +1233,8 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
     od.y += P.bg[1] * P.bg[3] * (1.0f - od.w);
     od.z += P.bg[2] * P.bg[3] * (1.0f - od.w);
     od.w = od.w + P.bg[3] * (1.0f - od.w);
-    *(float4*)(P.out_depth + 4 * (size_t)pix) = od;
+    if (P.out_depth) *(float4*)(P.out_depth + 4 * (size_t)pix) = od;
+    depth_x = od.x;
   }
   float4 o;
   o.w = aa * inv;
@@ -1276,7 +1242,18 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
   o.y = ag * inv + P.bg[1] * P.bg[3] * (1.0f - o.w);
   o.z = ab * inv + P.bg[2] * P.bg[3] * (1.0f - o.w);
   o.w = o.w + P.bg[3] * (1.0f - o.w);
-  *(float4*)(P.out + 4 * (size_t)pix) = o;
+  if (P.out) *(float4*)(P.out + 4 * (size_t)pix) = o;
+  if (P.mode == 1) depth_x = o.x;
+  // The 8-bit planes the tracker consumes, written here instead of by two more launches over the float images
+  // (get_nerf_image's `(rgb * 255).astype(uint8)` with alpha_thresh 0, run_vis_on_poses.py:52-54; get_mask's
+  // `uint8(depth * 255) != 0`, pixloc_tracker_r9.py:210-212): same float -> integer truncation, mod 256.
+  if (P.out_u8 && P.mode != 1) {
+    uint8_t* q = P.out_u8 + 3 * (size_t)pix;
+    q[0] = (uint8_t)((long long)(o.x * 255.0f) & 255);
+    q[1] = (uint8_t)((long long)(o.y * 255.0f) & 255);
+    q[2] = (uint8_t)((long long)(o.z * 255.0f) & 255);
+  }
+  if (P.out_nz && P.mode != 0) P.out_nz[pix] = (((long long)(depth_x * 255.0f) & 255) != 0) ? 1 : 0;
 }
 
 // Network query at caller-given points (unit tests / debugging): out[n] = (logit, r, g, b).
@@ -1535,8 +1512,13 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
 
 static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
                        uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
-                       float* cam_out = nullptr) {
-  if (!ctx || !v || !out_rgba) return PXT_E_ARG;
+                       float* cam_out = nullptr, uint8_t* out_u8 = nullptr, uint8_t* out_nz = nullptr,
+                       bool camera_from_slot = false) {
+  if (!ctx || !v) return PXT_E_ARG;
+  // every image the mode produces needs somewhere to go: its float form or its 8-bit stand-in
+  if (mode != 1 && !out_rgba && !out_u8) return PXT_E_ARG;
+  if (mode == 1 && !out_rgba && !out_nz) return PXT_E_ARG;
+  if (mode == 2 && !out_depth && !out_nz) return PXT_E_ARG;
   if (v->width < 1 || v->height < 1 || v->spp < 1 || !(v->focal > 0.f)) return PXT_E_ARG;
   NgpParams P;
   fill_model(ctx, P);
@@ -1545,6 +1527,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     if (!conv) return PXT_E_ARG;
     hipLaunchKernelGGL(ngp_pose_to_camera_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pose_src, *conv, ctx->cam_dev,
                        cam_out);
+    P.cam_dev = ctx->cam_dev;
+  } else if (camera_from_slot) {  // written by an earlier kernel of this stream (the LM kernel's epilogue)
     P.cam_dev = ctx->cam_dev;
   }
   P.focal = v->focal;
@@ -1555,6 +1539,8 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   P.W = v->width; P.H = v->height; P.spp = v->spp; P.mode = mode;
   P.out = out_rgba;
   P.out_depth = (mode == 2) ? out_depth : nullptr;
+  P.out_u8 = out_u8;
+  P.out_nz = out_nz;
   P.stats = (unsigned long long*)stats;
   // padded to whole 4x2 pixel blocks (the enumeration order of enum_ray)
   const size_t rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
@@ -1673,13 +1659,13 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
 
 extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, uint64_t* stats,
                               void* stream) {
-  if (!v || (v->mode != 0 && v->mode != 1)) return PXT_E_ARG;
+  if (!v || !out_rgba || (v->mode != 0 && v->mode != 1)) return PXT_E_ARG;
   return render_impl(ctx, v, v->mode, out_rgba, nullptr, stats, stream);
 }
 
 extern "C" int pxt_ngp_render_both(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, float* out_depth_rgba,
                                    uint64_t* stats, void* stream) {
-  if (!out_depth_rgba) return PXT_E_ARG;
+  if (!out_depth_rgba || !out_rgba) return PXT_E_ARG;
   return render_impl(ctx, v, 2, out_rgba, out_depth_rgba, stats, stream);
 }
 
@@ -1689,14 +1675,18 @@ extern "C" int pxt_ngp_render_both_from_pose(pxt_ngp* ctx, const pxt_ngp_view* v
                                              float* out_depth_rgba, uint64_t* stats, void* stream) {
   if (!v || !pose12 || !conv27) return PXT_E_ARG;
   if (!out_depth_rgba && v->mode != 0 && v->mode != 1) return PXT_E_ARG;
-  PoseConv cv;
-  for (int i = 0; i < 3; ++i) cv.centroid[i] = conv27[i];
-  cv.scale3_over_avglen = conv27[3];
-  for (int i = 0; i < 16; ++i) cv.Rn[i] = conv27[4 + i];
-  for (int i = 0; i < 3; ++i) cv.totp[i] = conv27[20 + i];
-  cv.ngp_scale = conv27[23];
-  for (int i = 0; i < 3; ++i) cv.ngp_offset[i] = conv27[24 + i];
+  if (!out_rgba) return PXT_E_ARG;
+  const PoseConv cv = make_pose_conv(conv27);
   return render_impl(ctx, v, out_depth_rgba ? 2 : v->mode, out_rgba, out_depth_rgba, stats, stream, pose12, &cv, cam_out13);
+}
+
+extern "C" float* pxt_ngp_camera_slot(pxt_ngp* ctx) { return ctx ? ctx->cam_dev : nullptr; }
+
+extern "C" int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* v, int32_t mode, int32_t camera_from_slot,
+                                    const pxt_ngp_outputs* out, uint64_t* stats, void* stream) {
+  if (!v || !out || mode < 0 || mode > 2) return PXT_E_ARG;
+  return render_impl(ctx, v, mode, out->rgba, out->depth_rgba, stats, stream, nullptr, nullptr, nullptr, out->rgb_u8,
+                     out->depth_nz, camera_from_slot != 0);
 }
 
 extern "C" int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n) {

@@ -515,6 +515,44 @@ class Testbed:
         self.n_renders += 1
         return out, cam_out
 
+    def camera_slot(self, side: bool = False) -> int:
+        """Device address of the context's 12-float camera slot (pxt_ngp_camera_slot): the LM kernel's epilogue writes
+        the next render's camera there (ops.lm_refine cam_slots) and render_frame_device(from_slot=True) reads it."""
+        ctx = self._side_ctx_int() if side else self._ctx_int()
+        return int(_lib.lib().pxt_ngp_camera_slot(ctx))
+
+    def render_frame_device(self, width: int, height: int, spp: int = 8, mode: int = 2, from_slot: bool = False,
+                            side: bool = False, pipelines: int = 0, want_float: bool = False):
+        """One render whose last kernel writes what the tracking loop consumes (pxt_ngp_render_frame): returns a dict with
+        ``rgb_u8`` uint8 [H, W, 3] (modes 0 / 2: get_nerf_image's image of the Shade render) and ``depth_nz`` uint8 [H, W]
+        (modes 1 / 2: get_mask's `uint8(depth * 255) != 0` plane), plus the float images ``rgba`` / ``depth`` when
+        ``want_float``.  mode 0 Shade, 1 Depth, 2 both from one march.  ``from_slot``: the camera is whatever the LM
+        kernel ahead in the stream wrote into camera_slot(side) - the render of a pose the host has not seen yet."""
+        assert self._ctx is not None, "load_snapshot first"
+        if not self.snap_to_pixel_centers:
+            raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
+        dev, out = self.device, {}
+        if mode != 1:
+            out["rgb_u8"] = torch.empty(height, width, 3, device=dev, dtype=torch.uint8)
+        if mode != 0:
+            out["depth_nz"] = torch.empty(height, width, device=dev, dtype=torch.uint8)
+        if want_float:
+            out["rgba"] = torch.empty(height, width, 4, device=dev, dtype=torch.float32)
+            if mode == 2:
+                out["depth"] = torch.empty(height, width, 4, device=dev, dtype=torch.float32)
+        ctx = self._side_ctx_int() if side else self._ctx_int()
+        if pipelines and not side:
+            _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, int(pipelines)), "pxt_ngp_set_pipelines")
+        try:
+            ops.ngp_render_frame(ctx, self._view_for(width, height), int(width), int(height), int(spp), int(mode),
+                                 bool(from_slot), out.get("rgba"), out.get("depth"), out.get("rgb_u8"),
+                                 out.get("depth_nz"), self.stats_accum)
+        finally:
+            if pipelines and not side:
+                _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, self._pipelines), "pxt_ngp_set_pipelines")
+        self.n_renders += 1
+        return out
+
     def _ctx_int(self) -> int:
         return int(self._ctx.value) if hasattr(self._ctx, "value") else int(self._ctx)
 

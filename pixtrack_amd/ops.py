@@ -36,7 +36,8 @@ SCHEMAS = {
         "(Tensor p3d, Tensor? point_mask, Tensor[] fmaps, Tensor[] frefs, int[] channels, float[] cameras, "
         "int[] ndist, float[] lambdas, float[] T_init, int num_iters, int pad, int loss, float loss_alpha, "
         "float loss_scale, float grad_stop, float dt_stop, float dR_stop, int min_valid, int n_workgroups, "
-        "Tensor(a!) record, Tensor(b!) workspace, bool want_log, int spin_limit=0) -> ()"),
+        "Tensor(a!) record, Tensor(b!) workspace, bool want_log, int spin_limit=0, float[]? cam_conv=None, "
+        "int[]? cam_slots=None, Tensor(c!)? cam_out=None) -> ()"),
     "sample_sparse": (
         "(Tensor p3d, float[] T, Tensor[] fmaps, int[] channels, float[] cameras, int[] ndist, int pad, "
         "bool normalize, Tensor(a!)[] outs, Tensor(b!) valid) -> ()"),
@@ -50,7 +51,11 @@ SCHEMAS = {
     "ngp_render_both_from_pose": (
         "(int ctx, float[] view, Tensor pose_record, float[] conv, int width, int height, int spp, int mode, "
         "Tensor(a!) rgba, Tensor(b!)? depth, Tensor(c!) cam_out, Tensor(d!)? stats) -> ()"),
+    "ngp_render_frame": (
+        "(int ctx, float[] view, int width, int height, int spp, int mode, bool camera_from_slot, Tensor(a!)? rgba, "
+        "Tensor(b!)? depth, Tensor(c!)? rgb_u8, Tensor(d!)? depth_nz, Tensor(e!)? stats) -> ()"),
     "depth_mask": "(Tensor depth_rgba, int n_erode, int n_dilate, Tensor(a!) mask, Tensor(b!) scratch) -> ()",
+    "depth_mask_plane": "(Tensor depth_nz, int n_erode, int n_dilate, Tensor(a!) mask) -> ()",
     "rgba_to_u8": "(Tensor rgba, float alpha_thresh, Tensor(a!) out) -> ()",
     "resize_linear": "(Tensor src, Tensor(a!) dst) -> ()",
     "conv3x3_nhwc_f16": "(Tensor x, Tensor weight, Tensor bias, bool relu, Tensor(a!) out) -> ()",
@@ -74,7 +79,7 @@ def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------- LM
 def _lm_refine(p3d, point_mask, fmaps, frefs, channels, cameras, ndist, lambdas, T_init, num_iters, pad, loss,
                loss_alpha, loss_scale, grad_stop, dt_stop, dR_stop, min_valid, n_workgroups, record, workspace,
-               want_log, spin_limit=0):
+               want_log, spin_limit=0, cam_conv=None, cam_slots=None, cam_out=None):
     L = _lib.lib()
     n_levels = len(fmaps)
     if not (1 <= n_levels <= _lib.PXT_MAX_LEVELS) or len(frefs) != n_levels or len(channels) != n_levels:
@@ -109,6 +114,26 @@ def _lm_refine(p3d, point_mask, fmaps, frefs, channels, cameras, ndist, lambdas,
         raise _lib.PxtError("lm_refine: point_mask must be contiguous uint8")
     base = record.data_ptr()
     T0 = (C.c_float * 12)(*[float(x) for x in T_init])
+    if cam_conv is not None:  # the kernel's epilogue also derives the next render's camera (pxt_lm_refine_cam)
+        if len(cam_conv) != 27:
+            raise _lib.PxtError("lm_refine: cam_conv holds 27 doubles (Testbed.pose_conversion)")
+        slots = [int(x) for x in (cam_slots or [])]
+        if len(slots) > 2 or (not slots and cam_out is None):
+            raise _lib.PxtError("lm_refine: at most two camera slots; at least one slot or cam_out")
+        cam = _lib.LmCamera()
+        cam.conv27[:] = [float(x) for x in cam_conv]
+        for k in range(2):
+            cam.cam_slot[k] = slots[k] if k < len(slots) and slots[k] else None
+        cam.cam_out13 = None
+        if cam_out is not None:
+            if cam_out.dtype != torch.float32 or cam_out.numel() < 13 or not (cam_out.is_cuda or cam_out.is_pinned()):
+                raise _lib.PxtError("lm_refine: cam_out must be a pinned host (or device) float32 tensor of >= 13 elements")
+            cam.cam_out13 = cam_out.data_ptr()
+        _lib.check(
+            L.pxt_lm_refine_cam(p3d.data_ptr(), _lib.dptr(point_mask), n, arr, n_levels, T0, C.byref(conf), base,
+                                base + 4 * nh if want_log else None, workspace.data_ptr(), C.byref(cam), _stream(p3d)),
+            "pxt_lm_refine_cam")
+        return
     _lib.check(
         L.pxt_lm_refine(p3d.data_ptr(), _lib.dptr(point_mask), n, arr, n_levels, T0, C.byref(conf), base,
                         base + 4 * nh if want_log else None, workspace.data_ptr(), _stream(p3d)),
@@ -244,7 +269,47 @@ def _ngp_render_both_from_pose(ctx, view, pose_record, conv, width, height, spp,
                                                         _stream(rgba)), "pxt_ngp_render_both_from_pose")
 
 
+def _ngp_render_frame(ctx, view, width, height, spp, mode, camera_from_slot, rgba, depth, rgb_u8, depth_nz, stats):
+    """pxt_ngp_render_frame: one render (mode 0 Shade / 1 Depth / 2 both in one march) whose last kernel also writes the
+    8-bit planes the tracker consumes - `rgb_u8` uint8 [H, W, 3] (get_nerf_image's image), `depth_nz` uint8 [H, W]
+    (get_mask's `uint8(depth * 255) != 0`) - so that the float images (`rgba`, `depth`) are optional; with
+    `camera_from_slot` the camera comes from the context's slot (written by lm_refine's epilogue: cam_slots)."""
+    width, height, mode = int(width), int(height), int(mode)
+    if mode not in (0, 1, 2):
+        raise _lib.PxtError("ngp_render_frame: mode is 0 (Shade), 1 (Depth) or 2 (both)")
+    for t, what in ((rgba, "rgba"), (depth, "depth")):
+        if t is not None:
+            _check_frame(t, width, height, what)
+    if rgb_u8 is not None and (rgb_u8.dtype != torch.uint8 or tuple(rgb_u8.shape) != (height, width, 3)
+                               or not rgb_u8.is_contiguous() or not rgb_u8.is_cuda):
+        raise _lib.PxtError("ngp_render_frame: rgb_u8 is a contiguous device uint8 [H, W, 3]")
+    if depth_nz is not None and (depth_nz.dtype != torch.uint8 or tuple(depth_nz.shape) != (height, width)
+                                 or not depth_nz.is_contiguous() or not depth_nz.is_cuda):
+        raise _lib.PxtError("ngp_render_frame: depth_nz is a contiguous device uint8 [H, W]")
+    ref = next((t for t in (rgba, depth, rgb_u8, depth_nz) if t is not None), None)
+    if ref is None:
+        raise _lib.PxtError("ngp_render_frame: no output")
+    o = _lib.NgpOutputs(_lib.dptr(rgba), _lib.dptr(depth), _lib.dptr(rgb_u8), _lib.dptr(depth_nz))
+    v = _view(view, width, height, spp, 0 if mode == 2 else mode)
+    _lib.check(_lib.lib().pxt_ngp_render_frame(ctx, C.byref(v), mode, int(bool(camera_from_slot)), C.byref(o),
+                                               _lib.dptr(stats), _stream(ref)), "pxt_ngp_render_frame")
+
+
 # ----------------------------------------------------------------------------------- image ops
+def _depth_mask_plane(depth_nz, n_erode, n_dilate, mask):
+    if depth_nz.dtype != torch.uint8 or depth_nz.dim() != 2 or not depth_nz.is_contiguous():
+        raise _lib.PxtError("depth_mask_plane: depth_nz is a contiguous uint8 [H, W]")
+    H, W = int(depth_nz.shape[0]), int(depth_nz.shape[1])
+    if mask.dtype != torch.uint8 or tuple(mask.shape) != (H, W):
+        raise _lib.PxtError("depth_mask_plane: mask is uint8 [H, W]")
+    tmp = None
+    if 2 * (int(n_erode) + int(n_dilate)) > 16:
+        tmp = torch.empty(2 * H * W, dtype=torch.uint8, device=depth_nz.device)
+    _lib.check(_lib.lib().pxt_depth_mask_plane(depth_nz.data_ptr(), H, W, int(n_erode), int(n_dilate), mask.data_ptr(),
+                                               _lib.dptr(tmp), _stream(depth_nz)), "pxt_depth_mask_plane")
+
+
+
 def _depth_mask(depth_rgba, n_erode, n_dilate, mask, scratch):
     _f32c(depth_rgba, "depth_rgba")
     H, W = int(depth_rgba.shape[0]), int(depth_rgba.shape[1])
@@ -282,7 +347,9 @@ _IMPLS = {
     "ngp_render": _ngp_render,
     "ngp_render_both": _ngp_render_both,
     "ngp_render_both_from_pose": _ngp_render_both_from_pose,
+    "ngp_render_frame": _ngp_render_frame,
     "depth_mask": _depth_mask,
+    "depth_mask_plane": _depth_mask_plane,
     "rgba_to_u8": _rgba_to_u8,
     "resize_linear": _resize_linear,
 }

@@ -245,9 +245,13 @@ class PixTrackOptimizer:
         workspace: torch.Tensor,
         mask: Optional[torch.Tensor] = None,
         want_log: bool = True,
+        camera=None,
     ) -> "PendingLM":
         """Enqueue the fused multi-level refinement (levels in EXECUTION order,
-        coarse -> fine).  Returns a handle; ``.result()`` synchronises."""
+        coarse -> fine).  Returns a handle; ``.result()`` synchronises.
+        ``camera`` = (conv27, [renderer camera slots], cam_out pinned record or None): the kernel's epilogue also
+        converts the final pose into the NeRF renderer's camera and stores it there (pxt_lm_refine_cam), so that a
+        render queued behind this launch needs no conversion launch."""
         _lib.require_gpu(p3d, "p3d")
         dev = p3d.device
         n_levels = len(levels)
@@ -272,7 +276,10 @@ class PixTrackOptimizer:
         ops.lm_refine(p3d, mask, [lp.fmap for lp in levels], [lp.fref for lp in levels], [int(lp.C) for lp in levels],
                       cams, ndist, lambdas, T0, conf.num_iters, conf.pad, conf.loss, conf.loss_alpha, conf.loss_scale,
                       conf.grad_stop, conf.dt_stop, conf.dR_stop, conf.min_valid, conf.n_workgroups, buf, workspace,
-                      bool(want_log), int(conf.spin_limit))
+                      bool(want_log), int(conf.spin_limit),
+                      None if camera is None else [float(x) for x in camera[0]],
+                      None if camera is None else [int(x) for x in camera[1]],
+                      None if camera is None else camera[2])
         keep = list(levels)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))

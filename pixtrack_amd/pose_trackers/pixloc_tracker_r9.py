@@ -126,6 +126,11 @@ class PixLocPoseTrackerR9(PoseTracker):
         # consumed only if the host, once it knows the pose, arrives at the same 12 camera floats; otherwise
         # (failed frame, cost gate, relocalisation, a different last bit) the frame renders as before.
         self.render_ahead = os.environ.get("PXT_RENDER_AHEAD", "1") != "0"
+        # Between-stage fusion (round 4): the renderer's last kernel writes the 8-bit reference image and the mask's
+        # `!= 0` plane itself (no rgba_to_u8 launch, no float images), and the camera of a queued render comes from the
+        # LM kernel's epilogue (no conversion launch).  PXT_FRAME_FUSION=0 keeps the separate launches (A/B, tests).
+        self.fused_frame_outputs = os.environ.get("PXT_FRAME_FUSION", "1") != "0"
+        self._ahead_cam = None   # the pinned camera record the LM epilogue of this frame writes
         self._ahead = None       # the render queued behind the last LM launch
         self._ahead_ok = None    # ... once verified: (pose object it is valid for, mask, uint8 reference image)
         self.renders_ahead_used = 0
@@ -275,6 +280,8 @@ class PixLocPoseTrackerR9(PoseTracker):
                 return mask
             self.renders_ahead_stale += 1
         self._ahead_ok = None
+        if self.fused_frame_outputs:
+            return self._mask_and_reference_fused(pose, from_slot=False)[0]
         if self._views_coincide():
             import math
 
@@ -307,6 +314,65 @@ class PixLocPoseTrackerR9(PoseTracker):
         ops.depth_mask(depth, 1, 5, mask, tmp)  # erode 5x5 once, dilate 5x5 five times (:211-213)
         return mask
 
+    def _mask_and_reference_fused(self, pose, from_slot: bool):
+        """The frame's mask and 8-bit reference image through pxt_ngp_render_frame: ONE march when the two views
+        coincide, otherwise the Depth render (query camera) on this stream and the Shade render (reference camera) on
+        a second stream through the testbed's second context.  ``from_slot``: the camera is the one the LM kernel ahead
+        in the stream derived from its final pose (render-ahead); otherwise the host's conversion of ``pose``.  Sets
+        ``_fused_reference`` when a pose object is given; returns (mask, ref_u8)."""
+        import math
+
+        tb, spp = self.testbed, int(self.spp)
+        if not from_slot:
+            tb.set_nerf_camera_matrix(np.asarray(self._nerf_pose(pose))[:3, :])
+        if self._views_coincide():
+            width, height, fl_x = self._coincide_cache[2]
+            tb.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
+            out = tb.render_frame_device(width, height, spp, mode=2, from_slot=from_slot)
+            ref_u8, nz = out["rgb_u8"], out["depth_nz"]
+        else:
+            def fov_of(cam):
+                w, h = (int(v) for v in cam.size)
+                return w, h, math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
+
+            width, height, fov_q = fov_of(self.camera)
+            rw, rh, fov_r = fov_of(self._reference_camera())
+            two = os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0"
+            if two:
+                main, side = self._two_streams()
+                self._ahead_fork.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(self._ahead_fork)
+                    tb.fov = fov_r
+                    ref_u8 = tb.render_frame_device(rw, rh, spp, mode=0, from_slot=from_slot, side=True)["rgb_u8"]
+                    self._ahead_join.record(side)
+                ref_u8.record_stream(main)
+            tb.fov = fov_q
+            nz = tb.render_frame_device(width, height, spp, mode=1, from_slot=from_slot,
+                                        pipelines=1 if two else 0)["depth_nz"]
+            if not two:
+                tb.fov = fov_r
+                ref_u8 = tb.render_frame_device(rw, rh, spp, mode=0, from_slot=from_slot)["rgb_u8"]
+        mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
+        ops.depth_mask_plane(nz, 1, 5, mask)  # erode 5x5 once, dilate 5x5 five times (:211-213)
+        if not self._views_coincide() and self.__dict__.get("_ahead_stream") is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._ahead_join)
+        if pose is not None:
+            self._fused_reference = (pose, ref_u8)
+        return mask, ref_u8
+
+    def _lm_camera(self):
+        """What the refiner hands to the LM launch of a frame whose next render will be queued behind it: the pose ->
+        camera conversion constants, the renderer camera slot(s) to fill, and a pinned record for the host's check."""
+        conv = self.__dict__.get("_pose_conv")
+        if conv is None:
+            conv = self._pose_conv = self.testbed.pose_conversion(self.nerf2sfm)
+        slots = [self.testbed.camera_slot()]
+        if not self._views_coincide() and os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0":
+            slots.append(self.testbed.camera_slot(side=True))
+        self._ahead_cam = self.testbed._next_cam_out()
+        return conv, slots, self._ahead_cam
+
     # ------------------------------------------------------------------ the next frame's render, ahead of the host
     def _two_streams(self):
         """(current stream, the stream the second of a frame's two renders runs on) + the fork / join events."""
@@ -320,6 +386,11 @@ class PixLocPoseTrackerR9(PoseTracker):
         whose camera a one-thread kernel derives from the LM kernel's pose record on the device."""
         import math
 
+        if self.fused_frame_outputs:  # camera from the LM epilogue's slot, 8-bit outputs from the resolve kernel
+            views = self._ahead_views_now()
+            mask, ref_u8 = self._mask_and_reference_fused(None, from_slot=True)
+            self._ahead = ([self._ahead_cam], mask, ref_u8, views)
+            return
         conv = self.__dict__.get("_pose_conv")
         if conv is None:
             conv = self._pose_conv = self.testbed.pose_conversion(self.nerf2sfm)
@@ -445,6 +516,7 @@ class PixLocPoseTrackerR9(PoseTracker):
                   and refiner.conf.multiscale == [1] and len(self.reference_ids) == 1)
         self._ahead = None
         refiner.after_lm_enqueued = self._render_ahead if (self.render_ahead and steady) else None
+        refiner.lm_camera = self._lm_camera if (self.render_ahead and steady and self.fused_frame_outputs) else None
         self.dynamic_id = self.get_dynamic_id(self.pose)
         rotation, translation = self.pose.numpy()
         rotation = R.from_matrix(rotation).as_matrix()
@@ -475,6 +547,7 @@ class PixLocPoseTrackerR9(PoseTracker):
             self.pose = ret["T_refined"]
         self.success = success
         refiner.after_lm_enqueued = None
+        refiner.lm_camera = None
         self._verify_render_ahead(success)
         ret["camera"] = self.camera
         ret["reference_ids"] = self.reference_ids

@@ -321,7 +321,11 @@ class PoseTrackerRefiner:
             packs.append(LevelPack(features_query[level], ref.packed[level], OUTPUT_DIMS[level],
                                    qcamera.scale(scales_query[level]), opt.dampingnet()))
         opt0 = self.optimizer[order[0]] if isinstance(self.optimizer, (list, tuple)) else self.optimizer
-        pending = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws, mask=ref.valid)
+        # (a tracker that will queue the next frame's render behind this launch asks for the camera of that render in
+        # the kernel's epilogue: pixloc_tracker_r9._lm_camera)
+        cam_provider = getattr(self, "lm_camera", None)
+        pending = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws, mask=ref.valid,
+                                                  camera=cam_provider() if cam_provider is not None else None)
         # the refinement is enqueued, its result not yet awaited: a caller may queue work behind it that reads the
         # pose record on the device (the tracker's next render, pixloc_tracker_r9._render_ahead)
         hook = getattr(self, "after_lm_enqueued", None)

@@ -125,3 +125,135 @@ def test_one_pipeline_render_with_the_box_filling_the_view(device):
     st = tb.read_stats()
     assert st["rays_hit"] > 0.75 * W * H * 8
     assert bool(torch.isfinite(out).all())
+
+
+def _testbed(device, W, H):
+    tb = Testbed(device=device)
+    tb.load_snapshot(make_synthetic_nerf(11))
+    tb.background_color = [255, 255, 255, 0.0]
+    tb.snap_to_pixel_centers = True
+    tb.nerf.rendering_min_transmittance = 1e-7
+    tb.render_aabb.min, tb.render_aabb.max = PREMIER_PROTEIN_AABB
+    tb.fov = math.degrees(2 * math.atan(W / (2 * 1.2 * W)))
+    return tb
+
+
+def test_render_frame_8bit_outputs_equal_the_separate_launches(device):
+    """pxt_ngp_render_frame (round 4, between-stage fusion): the resolve kernel's own uint8 image and `!= 0` plane are
+    bit for bit what rgba_to_u8 / depth_mask make of the float images of render_device / render_both_device - for
+    Shade, Depth and both-in-one-march, with and without the float images alongside, odd sizes included."""
+    from pixtrack_amd.ops import ops
+    from pixtrack_amd.synthetic import look_at_pose
+    from pixtrack_amd.visualization.run_vis_on_poses import rgba_to_u8
+
+    lo, hi = np.array(PREMIER_PROTEIN_AABB)
+    c = 0.5 * (lo + hi)
+    for (W, H), dist in (((160, 120), 1.7), ((203, 131), 1.2)):
+        tb = _testbed(device, W, H)
+        eye = c + np.array([0.9, 0.5, 0.3]) / np.linalg.norm([0.9, 0.5, 0.3]) * dist
+        R, _ = look_at_pose(eye, c, up=np.array([0, 1.0, 0]))
+        tb._cam_ngp = np.concatenate([R.T, eye[:, None]], 1)
+        rgba, depth = tb.render_both_device(W, H, 4)
+        want_u8 = rgba_to_u8(rgba, 0.0)
+        want_mask = torch.empty(H, W, dtype=torch.uint8, device=device)
+        ops.depth_mask(depth, 1, 5, want_mask, torch.empty(2 * H * W, dtype=torch.uint8, device=device))
+        want_nz = ((depth[..., 0] * 255.0).to(torch.int64) & 255) != 0
+        assert 0.02 < float(want_mask.float().mean()) < 0.98
+        for want_float in (False, True):
+            both = tb.render_frame_device(W, H, 4, mode=2, want_float=want_float)
+            assert torch.equal(both["rgb_u8"], want_u8) and torch.equal(both["depth_nz"].bool(), want_nz)
+            got_mask = torch.empty(H, W, dtype=torch.uint8, device=device)
+            ops.depth_mask_plane(both["depth_nz"], 1, 5, got_mask)
+            assert torch.equal(got_mask, want_mask)
+            if want_float:
+                assert torch.equal(both["rgba"], rgba) and torch.equal(both["depth"], depth)
+            shade = tb.render_frame_device(W, H, 4, mode=0, want_float=want_float)
+            assert torch.equal(shade["rgb_u8"], want_u8) and "depth_nz" not in shade
+            dep = tb.render_frame_device(W, H, 4, mode=1, want_float=want_float)
+            assert torch.equal(dep["depth_nz"].bool(), want_nz) and "rgb_u8" not in dep
+            if want_float:
+                assert torch.equal(shade["rgba"], rgba) and torch.equal(dep["rgba"], depth)
+        # larger structuring elements take the pass-by-pass route: same mask as the float entry point
+        m1 = torch.empty(H, W, dtype=torch.uint8, device=device)
+        m2 = torch.empty(H, W, dtype=torch.uint8, device=device)
+        ops.depth_mask(depth, 2, 8, m1, torch.empty(2 * H * W, dtype=torch.uint8, device=device))
+        ops.depth_mask_plane(both["depth_nz"], 2, 8, m2)
+        assert torch.equal(m1, m2)
+
+
+def test_lm_epilogue_camera_equals_the_conversion_kernel(device):
+    """pxt_lm_refine_cam: the camera the LM kernel's epilogue derives from its final pose (into the renderer's camera
+    slot and a pinned record) has the bits of the one-thread conversion kernel of pxt_ngp_render_both_from_pose, and
+    render_frame_device(from_slot=True) renders what that entry point renders."""
+    from pixtrack_amd import _lib
+    from pixtrack_amd.optimizer import LevelPack, PixTrackOptimizer, cstride_for
+    from pixtrack_amd.synthetic import make_lm_scene
+    from pixtrack_amd.visualization.run_vis_on_poses import rgba_to_u8
+
+    W, H = 160, 120
+    tb = _testbed(device, W, H)
+    rng = np.random.default_rng(4)
+    n2s = {"centroid": rng.normal(size=3) * 0.2, "avglen": 2.3, "R": np.eye(4), "totp": rng.normal(size=3) * 0.1}
+    n2s["R"][:3, :3] = Rotation.random(random_state=3).as_matrix()
+    conv = tb.pose_conversion(n2s)
+    sc = make_lm_scene(seed=1007, width=160, height=120, n_points=600, sigma_px=2.0)
+    packs = []
+    for level in reversed(range(3)):
+        fq = sc.feats_query[level]
+        Cc = fq.shape[0] - 1
+        fmap = torch.zeros(fq.shape[1], fq.shape[2], cstride_for(Cc))
+        fmap[..., :Cc] = torch.nn.functional.normalize(fq[:-1], dim=0).permute(1, 2, 0)
+        fmap[..., Cc] = fq[-1]
+        fr = sc.feats_ref[level]
+        fref = torch.zeros(fr.shape[0], cstride_for(Cc))
+        fref[:, :Cc] = torch.nn.functional.normalize(fr[:, :-1], dim=1)
+        fref[:, Cc] = fr[:, -1]
+        packs.append(LevelPack(fmap.to(device).contiguous(), fref.to(device).contiguous(), Cc,
+                               sc.camera.scale(sc.scales[level]), torch.full((6,), 1e-4)))
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    opt = PixTrackOptimizer(dict(num_iters=150, pad=1))
+    cam_rec = tb._next_cam_out()
+    pend = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws,
+                                           camera=(conv, [tb.camera_slot()], cam_rec))
+    fused = tb.render_frame_device(W, H, 2, mode=2, from_slot=True)  # queued behind the launch, like the tracker's
+    res = pend.result()
+    assert not res.failed
+    torch.cuda.synchronize()
+    got = cam_rec.numpy().copy()
+    assert got[12] == 1.0
+    # the reference: the conversion kernel on the same pose record
+    rgba, depth, cam_out = tb.render_both_from_pose_device(W, H, 2, pend.buf, conv)
+    torch.cuda.synchronize()
+    want = cam_out.numpy()
+    assert want[12] == 1.0 and np.array_equal(got[:12].view(np.uint32), want[:12].view(np.uint32))
+    assert torch.equal(fused["rgb_u8"], rgba_to_u8(rgba, 0.0))
+    assert torch.equal(fused["depth_nz"].bool(), ((depth[..., 0] * 255.0).to(torch.int64) & 255) != 0)
+    # a launch without camera outputs leaves the slot alone; no slot and no record is refused
+    with pytest.raises(Exception):
+        PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws, camera=(conv, [], None)).result()
+
+
+@pytest.mark.parametrize("coincide", [True, False])
+def test_tracking_is_identical_with_and_without_frame_fusion(device, coincide):
+    """PXT_FRAME_FUSION on / off (the resolve kernel's 8-bit outputs + the LM epilogue's camera against the separate
+    rgba_to_u8 / conversion launches), with the render-ahead on and off: the same poses, bit for bit."""
+    n = 12
+    assets = make_tracking_assets(seed=1002, width=320, height=240, n_frames=n)
+    hist = {}
+    for fusion in (True, False):
+        for ahead in (True, False):
+            tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+            tr.fuse_identical_views = coincide
+            tr.fused_frame_outputs = fusion
+            tr.render_ahead = ahead
+            frames = render_query_frames(assets, tr.testbed)
+            for i in range(n):
+                tr.run_single_frame((f"{i:06d}.png", frames[i]))
+            hist[(fusion, ahead)] = np.stack(
+                [np.concatenate([a.ravel() for a in tr.pose_history[f"{i:06d}.png"]["T_refined"].numpy()]) for i in range(n)])
+            if ahead:
+                assert tr.renders_ahead_used >= n - 3, (fusion, tr.renders_ahead_used, tr.renders_ahead_rejected)
+    base = hist[(False, False)]
+    for k, v in hist.items():
+        assert np.array_equal(v, base), k
