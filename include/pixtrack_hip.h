@@ -86,6 +86,9 @@ typedef struct {
   int32_t n_workgroups;     /* persistent grid size; 0 = library default */
   int32_t spin_limit;       /* polls before an inter-workgroup wait gives up with PXT_E_TIMEOUT; 0 = library default
                                (2^22, seconds).  Tests force a time-out with 1. */
+  int32_t path;             /* 0 = automatic: a level whose points fit the grid's lane groups keeps every point in
+                               registers for the whole level (one round); 2 = always the general several-rounds path
+                               (A/B, tests: both give the same poses to fp32 reduction order) */
 } pxt_lm_conf;
 
 /* Output record (device, floats):

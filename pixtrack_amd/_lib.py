@@ -54,6 +54,7 @@ class LmConf(C.Structure):
         ("min_valid", C.c_int32),
         ("n_workgroups", C.c_int32),
         ("spin_limit", C.c_int32),
+        ("path", C.c_int32),
     ]
 
 

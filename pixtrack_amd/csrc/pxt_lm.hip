@@ -133,6 +133,87 @@ __device__ inline float lm_group_sum(float v, bool wide) {
   return v;
 }
 
+// The same for a compile-time group width of 8, 16 or 32 lanes.
+template <int LG>
+__device__ inline float lm_group_sum_t(float v) {
+  v = lm_dpp_add(v, 0);
+  v = lm_dpp_add(v, 1);
+  v = lm_dpp_add(v, 2);
+  if (LG >= 16) v = lm_dpp_add(v, 3);
+  if (LG >= 32) v += __shfl_xor(v, 16, PXT_WAVE);
+  return v;
+}
+
+// Sum over the 16 lanes of a DPP row, every lane receiving the total (a fixed tree: the same bits in every workgroup).
+__device__ inline float lm_row16_sum(float v) {
+  v = lm_dpp_add(v, 0);
+  v = lm_dpp_add(v, 1);
+  v = lm_dpp_add(v, 2);
+  return lm_dpp_add(v, 3);
+}
+
+// One point's contribution to g (acc[0..5]), the upper triangle of H (acc[6..26]), the cost sum and the valid count,
+// from the six group-reduced scalars A = gradF^T r (2), B = gradF^T gradF (3) and its robust weight:
+// J = gradF (C x 2) * Jp (2 x 6)  =>  J^T r = Jp^T A,  J^T J = Jp^T B Jp.
+__device__ inline void lm_add_point(float* acc, float wgt, float rcost, const float* Jw, float px, float py, float pz,
+                                    float A0, float A1, float B00, float B01, float B11) {
+  // Jp = d(u,v)/d(delta) = Jw (2x3) * [I | -[p]x] (3x6), translation columns first.
+  float J0[6], J1[6];
+  J0[0] = Jw[0]; J0[1] = Jw[1]; J0[2] = Jw[2];
+  J1[0] = Jw[3]; J1[1] = Jw[4]; J1[2] = Jw[5];
+  // -[p]x = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
+  J0[3] = -Jw[1] * pz + Jw[2] * py;
+  J0[4] = Jw[0] * pz - Jw[2] * px;
+  J0[5] = -Jw[0] * py + Jw[1] * px;
+  J1[3] = -Jw[4] * pz + Jw[5] * py;
+  J1[4] = Jw[3] * pz - Jw[5] * px;
+  J1[5] = -Jw[3] * py + Jw[4] * px;
+  float M0[6], M1[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    M0[k] = B00 * J0[k] + B01 * J1[k];
+    M1[k] = B01 * J0[k] + B11 * J1[k];
+    acc[k] += wgt * (J0[k] * A0 + J1[k] * A1);
+  }
+  int idx = 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int l = k; l < 6; ++l) acc[idx++] += wgt * (J0[k] * M0[l] + J1[k] * M1[l]);
+  acc[27] += rcost;
+  acc[28] += 1.f;
+}
+
+// The same for a group that serves ONE point per iteration: the 29 values go straight to the group's LDS record
+// (no accumulator array: passed through the variant switch it would live in scratch).
+__device__ inline void lm_point_record(float* dst, bool leader, float wgt, float rcost, const float* Jw, float px, float py,
+                                       float pz, float A0, float A1, float B00, float B01, float B11) {
+  float J0[6], J1[6];
+  J0[0] = Jw[0]; J0[1] = Jw[1]; J0[2] = Jw[2];
+  J1[0] = Jw[3]; J1[1] = Jw[4]; J1[2] = Jw[5];
+  J0[3] = -Jw[1] * pz + Jw[2] * py;
+  J0[4] = Jw[0] * pz - Jw[2] * px;
+  J0[5] = -Jw[0] * py + Jw[1] * px;
+  J1[3] = -Jw[4] * pz + Jw[5] * py;
+  J1[4] = Jw[3] * pz - Jw[5] * px;
+  J1[5] = -Jw[3] * py + Jw[4] * px;
+  if (!leader) return;
+  float M0[6], M1[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    M0[k] = B00 * J0[k] + B01 * J1[k];
+    M1[k] = B01 * J0[k] + B11 * J1[k];
+    dst[k] = 0.f + wgt * (J0[k] * A0 + J1[k] * A1);
+  }
+  int idx = 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int l = k; l < 6; ++l) dst[idx++] = 0.f + wgt * (J0[k] * M0[l] + J1[k] * M1[l]);
+  dst[27] = rcost;
+  dst[28] = 1.f;
+}
+
 __device__ inline void lm_accumulate(const LmParams& P, const LmLevelDev& L, const float* T,
                                      float* acc, const int LG, unsigned long long* dbg = nullptr) {
   const bool wide = LG == 32;
@@ -259,31 +340,7 @@ __device__ inline void lm_accumulate(const LmParams& P, const LmLevelDev& L, con
     robust_loss(P.conf.loss, P.conf.loss_alpha, P.conf.loss_scale, s_cost, rcost, wl);
     const float wgt = wl * (wref * wq);
 
-    // Jp = d(u,v)/d(delta) = Jw (2x3) * [I | -[p]x] (3x6), translation columns first.
-    float J0[6], J1[6];
-    J0[0] = Jw[0]; J0[1] = Jw[1]; J0[2] = Jw[2];
-    J1[0] = Jw[3]; J1[1] = Jw[4]; J1[2] = Jw[5];
-    // -[p]x = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
-    J0[3] = -Jw[1] * pz + Jw[2] * py;
-    J0[4] = Jw[0] * pz - Jw[2] * px;
-    J0[5] = -Jw[0] * py + Jw[1] * px;
-    J1[3] = -Jw[4] * pz + Jw[5] * py;
-    J1[4] = Jw[3] * pz - Jw[5] * px;
-    J1[5] = -Jw[3] * py + Jw[4] * px;
-    float M0[6], M1[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      M0[k] = B00 * J0[k] + B01 * J1[k];
-      M1[k] = B01 * J0[k] + B11 * J1[k];
-      acc[k] += wgt * (J0[k] * A0 + J1[k] * A1);
-    }
-    int idx = 6;
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-#pragma unroll
-      for (int l = k; l < 6; ++l) acc[idx++] += wgt * (J0[k] * M0[l] + J1[k] * M1[l]);
-    acc[27] += rcost;
-    acc[28] += 1.f;
+    lm_add_point(acc, wgt, rcost, Jw, px, py, pz, A0, A1, B00, B01, B11);
 #if PXT_EXP_STAMPS
     if (dbg && dbg_round == 0) dbg[10] = __builtin_amdgcn_s_memtime();
     ++dbg_round;
@@ -291,6 +348,168 @@ __device__ inline void lm_accumulate(const LmParams& P, const LmLevelDev& L, con
   }
 #if PXT_EXP_STAMPS
   if (dbg) { dbg[11] = __builtin_amdgcn_s_memtime(); dbg[12] = dbg_round; }
+#endif
+}
+
+// ---- one-round levels: a group keeps ITS point for the whole level ------------------------------------------
+// When the level's points fit the grid's groups (2341 points against 128 workgroups x 8 waves x 64 / LG lanes), every
+// group serves at most one point, so what does not change between iterations - the point, its mask bit, its reference
+// descriptor and confidence - is loaded ONCE per level and kept in registers: an iteration's memory chain is then
+// pose (LDS) -> projection -> the 12-texel footprint, one round trip instead of two.  LG is picked per level so that
+// one round suffices (C = 128: 32 lanes while n <= 2048 groups, then 16 lanes x 2 channel quads, then 8 x 4), and
+// the points are dealt round-robin to the workgroups (point n -> workgroup n mod G), so every CU carries the same
+// number of points whatever n is (the contiguous deal left 54 of 128 workgroups without a point at n = 2341, LG = 16).
+template <int NF>
+struct LmPoint {
+  float X, Y, Z, wref;
+  float4 fr[NF];  // the reference descriptor stays in registers while it is 1-2 quads per lane (else it is re-read)
+  int n;
+  bool valid;
+};
+
+// local group index of this lane's group within the workgroup, spread over the waves first
+template <int LG>
+__device__ inline int lm_local_group() {
+  constexpr int GPW = PXT_WAVE / LG;
+  const int lane = threadIdx.x & (PXT_WAVE - 1), wave = threadIdx.x / PXT_WAVE;
+  return (lane / LG) * kLmWaves + wave;  // < GPW * kLmWaves
+}
+
+template <int LG, int CI>
+__device__ inline void lm_load_point(const LmParams& P, const LmLevelDev& L, LmPoint<2>& pt) {
+  const int sub = (threadIdx.x & (PXT_WAVE - 1)) & (LG - 1);
+  pt.n = lm_local_group<LG>() * (int)gridDim.x + (int)blockIdx.x;
+  pt.valid = pt.n < P.n;
+  pt.X = pt.Y = 0.f;
+  pt.Z = 1.f;
+  pt.wref = 0.f;
+  pt.fr[0] = pt.fr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pt.valid) {
+    pt.X = P.p3d[3 * pt.n];
+    pt.Y = P.p3d[3 * pt.n + 1];
+    pt.Z = P.p3d[3 * pt.n + 2];
+    if (P.mask) pt.valid = P.mask[pt.n] != 0;
+    const float* fr = L.fref + (size_t)pt.n * L.cs;
+    if (CI <= 2) {
+#pragma unroll
+      for (int k = 0; k < (CI <= 2 ? CI : 0); ++k) pt.fr[k] = *(const float4*)(fr + 4 * sub + 4 * LG * k);
+    }
+    pt.wref = fr[L.C];
+  }
+}
+
+template <int LG, int CI>
+__device__ inline void lm_accumulate_cached(const LmParams& P, const LmLevelDev& L, const float* T, const LmPoint<2>& pt,
+                                            float* grp_records, unsigned long long* dbg = nullptr) {
+  const int sub = (threadIdx.x & (PXT_WAVE - 1)) & (LG - 1);
+  float* const dst = grp_records + (threadIdx.x / LG) * kGrpStride;  // this group's record (the leader writes it)
+  const Cam cam = make_cam(L.cam, L.ndist);
+  const int W = L.w, H = L.h, C = L.C, cs = L.cs;
+  const float pad = (float)P.conf.pad;
+#if PXT_EXP_STAMPS
+  if (dbg) dbg[8] = __builtin_amdgcn_s_memtime();
+#endif
+  const float px = T[0] * pt.X + T[1] * pt.Y + T[2] * pt.Z + T[9];
+  const float py = T[3] * pt.X + T[4] * pt.Y + T[5] * pt.Z + T[10];
+  const float pz = T[6] * pt.X + T[7] * pt.Y + T[8] * pt.Z + T[11];
+  float u, v, Jw[6];
+  bool valid = project_point(cam, px, py, pz, u, v, Jw) && pt.valid;
+  valid = valid && (u >= pad) && (v >= pad) && (u <= (float)(W - 1) - pad) && (v <= (float)(H - 1) - pad);
+  if (valid) {  // group-uniform
+    const float fu = floorf(u), fv = floorf(v);
+    const int ix0 = (int)fu, iy0 = (int)fv;
+    const float ax = u - fu, ay = v - fv;
+    const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay, w11 = ax * ay;
+    int xi[4], yi[4];
+    float xm[4], ym[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = ix0 - 1 + k, yy = iy0 - 1 + k;
+      xm[k] = (xx >= 0 && xx < W) ? 1.f : 0.f;
+      ym[k] = (yy >= 0 && yy < H) ? 1.f : 0.f;
+      xi[k] = min(max(xx, 0), W - 1);
+      yi[k] = min(max(yy, 0), H - 1);
+    }
+    const float* row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) row[k] = L.fmap + (size_t)yi[k] * W * cs + 4 * sub;
+    float s_cost = 0.f, A0 = 0.f, A1 = 0.f, B00 = 0.f, B01 = 0.f, B11 = 0.f;
+    const float m01 = ym[0] * xm[1], m02 = ym[0] * xm[2];
+    const float m10 = ym[1] * xm[0], m11 = ym[1] * xm[1], m12 = ym[1] * xm[2], m13 = ym[1] * xm[3];
+    const float m20 = ym[2] * xm[0], m21 = ym[2] * xm[1], m22 = ym[2] * xm[2], m23 = ym[2] * xm[3];
+    const float m31 = ym[3] * xm[1], m32 = ym[3] * xm[2];
+    // confidence: bilinear sample of channel C (same address for the whole group)
+    const float q11 = (row[1] - 4 * sub)[(size_t)xi[1] * cs + C] * (ym[1] * xm[1]);
+    const float q12 = (row[1] - 4 * sub)[(size_t)xi[2] * cs + C] * (ym[1] * xm[2]);
+    const float q21 = (row[2] - 4 * sub)[(size_t)xi[1] * cs + C] * (ym[2] * xm[1]);
+    const float q22 = (row[2] - 4 * sub)[(size_t)xi[2] * cs + C] * (ym[2] * xm[2]);
+    // every load of a pair of channel quads is issued before the first use (up to 24 dwordx4 in flight per lane)
+    constexpr int CB = CI == 2 ? 2 : 1;
+#pragma unroll 1
+    for (int kb = 0; kb < CI; kb += CB) {
+    float4 t[CB][12], frl[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+      const int c0 = 4 * LG * (kb + k);
+      if (CI > 2) frl[k] = *(const float4*)(L.fref + (size_t)pt.n * cs + 4 * sub + c0);
+      t[k][0] = *(const float4*)(row[0] + (size_t)xi[1] * cs + c0);
+      t[k][1] = *(const float4*)(row[0] + (size_t)xi[2] * cs + c0);
+      t[k][2] = *(const float4*)(row[1] + (size_t)xi[0] * cs + c0);
+      t[k][3] = *(const float4*)(row[1] + (size_t)xi[1] * cs + c0);
+      t[k][4] = *(const float4*)(row[1] + (size_t)xi[2] * cs + c0);
+      t[k][5] = *(const float4*)(row[1] + (size_t)xi[3] * cs + c0);
+      t[k][6] = *(const float4*)(row[2] + (size_t)xi[0] * cs + c0);
+      t[k][7] = *(const float4*)(row[2] + (size_t)xi[1] * cs + c0);
+      t[k][8] = *(const float4*)(row[2] + (size_t)xi[2] * cs + c0);
+      t[k][9] = *(const float4*)(row[2] + (size_t)xi[3] * cs + c0);
+      t[k][10] = *(const float4*)(row[3] + (size_t)xi[1] * cs + c0);
+      t[k][11] = *(const float4*)(row[3] + (size_t)xi[2] * cs + c0);
+    }
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+      const float4 fr = CI <= 2 ? pt.fr[CI <= 2 ? k : 0] : frl[k];
+#define PXT_LM_CH(q)                                                                                              \
+  {                                                                                                               \
+    const float a01 = t[k][0].q * m01, a02 = t[k][1].q * m02, a10 = t[k][2].q * m10, a11 = t[k][3].q * m11,        \
+                a12 = t[k][4].q * m12, a13 = t[k][5].q * m13, a20 = t[k][6].q * m20, a21 = t[k][7].q * m21,        \
+                a22 = t[k][8].q * m22, a23 = t[k][9].q * m23, a31 = t[k][10].q * m31, a32 = t[k][11].q * m32;      \
+    const float F = w00 * a11 + w10 * a12 + w01 * a21 + w11 * a22;                                                \
+    const float Fxp = w00 * a12 + w10 * a13 + w01 * a22 + w11 * a23;                                              \
+    const float Fxm = w00 * a10 + w10 * a11 + w01 * a20 + w11 * a21;                                              \
+    const float Fyp = w00 * a21 + w10 * a22 + w01 * a31 + w11 * a32;                                              \
+    const float Fym = w00 * a01 + w10 * a02 + w01 * a11 + w11 * a12;                                              \
+    const float gx = 0.5f * (Fxp - Fxm), gy = 0.5f * (Fyp - Fym);                                                 \
+    const float r = F - fr.q;                                                                                     \
+    s_cost += r * r;                                                                                              \
+    A0 += r * gx;                                                                                                 \
+    A1 += r * gy;                                                                                                 \
+    B00 += gx * gx;                                                                                               \
+    B01 += gx * gy;                                                                                               \
+    B11 += gy * gy;                                                                                               \
+  }
+      PXT_LM_CH(x) PXT_LM_CH(y) PXT_LM_CH(z) PXT_LM_CH(w)
+#undef PXT_LM_CH
+    }
+    }
+    const float wq = w00 * q11 + w10 * q12 + w01 * q21 + w11 * q22;
+#if PXT_EXP_STAMPS
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[9] = __builtin_amdgcn_s_memtime(); }
+#endif
+    s_cost = lm_group_sum_t<LG>(s_cost);
+    A0 = lm_group_sum_t<LG>(A0);
+    A1 = lm_group_sum_t<LG>(A1);
+    B00 = lm_group_sum_t<LG>(B00);
+    B01 = lm_group_sum_t<LG>(B01);
+    B11 = lm_group_sum_t<LG>(B11);
+    float rcost, wl;
+    robust_loss(P.conf.loss, P.conf.loss_alpha, P.conf.loss_scale, s_cost, rcost, wl);
+    lm_point_record(dst, sub == 0, wl * (pt.wref * wq), rcost, Jw, px, py, pz, A0, A1, B00, B01, B11);
+  } else if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 29; ++i) dst[i] = 0.f;
+  }
+#if PXT_EXP_STAMPS
+  if (dbg) { dbg[10] = dbg[11] = __builtin_amdgcn_s_memtime(); dbg[12] = 1; }
 #endif
 }
 
@@ -323,9 +542,10 @@ __device__ inline bool solve6(const float* tot, const float* lambda, bool ok, fl
       for (int l = 0; l < 6; ++l) Hm[k][l] = (k == l) ? 1.f : 0.f;
     }
   }
-  // Cholesky H = L L^T, fully unrolled so every entry stays in a register.  One division per pivot: the
-  // column and both substitutions multiply by its reciprocal (this runs on ONE lane while the whole grid
-  // waits; an IEEE division is a ~15-instruction dependent sequence).
+  // Cholesky H = L L^T, fully unrolled so every entry stays in a register.  This runs on ONE lane while the whole grid
+  // waits, and its six pivots are a dependent chain: per pivot ONE hardware reciprocal square root refined by one
+  // Newton step (relative error ~1e-7, as good as sqrtf followed by a division, a third of their ~25 dependent
+  // instructions); the column and both substitutions multiply by it.
   float Lm[6][6], inv[6];
   bool chol_ok = true;
 #pragma unroll
@@ -334,9 +554,10 @@ __device__ inline bool solve6(const float* tot, const float* lambda, bool ok, fl
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
     chol_ok = chol_ok && (d > 0.f);
-    const float dj = sqrtf(d);
-    Lm[j][j] = dj;
-    inv[j] = 1.0f / dj;
+    const float r0 = __builtin_amdgcn_rsqf(d);
+    const float rj = r0 * (1.5f - (0.5f * d) * (r0 * r0));
+    Lm[j][j] = d * rj;
+    inv[j] = rj;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       float s = Hm[i][j];
@@ -409,8 +630,17 @@ __device__ inline void apply_delta(const float* delta, float* T, float& dR_deg, 
     Rd[3] = wz;  Rd[4] = 1.f; Rd[5] = -wx;
     Rd[6] = -wy; Rd[7] = wx;  Rd[8] = 1.f;
   } else {
-    const float x = wx / theta, y = wy / theta, z = wz / theta;
-    const float s = sinf(theta), c1 = 1.f - cosf(theta);
+    const float it = 1.0f / theta;
+    const float x = wx * it, y = wy * it, z = wz * it;
+    float s, c1;
+    if (theta < 0.25f) {  // an LM step: series to theta^9 / theta^10 (truncation < 1e-14 relative), no range reduction
+      const float q = theta * theta;
+      s = theta * (1.f + q * (-1.f / 6.f + q * (1.f / 120.f + q * (-1.f / 5040.f + q * (1.f / 362880.f)))));
+      c1 = q * (0.5f + q * (-1.f / 24.f + q * (1.f / 720.f + q * (-1.f / 40320.f + q * (1.f / 3628800.f)))));
+    } else {
+      s = sinf(theta);
+      c1 = 1.f - cosf(theta);
+    }
     // W = [[0,-z,y],[z,0,-x],[-y,x,0]],  W^2 = w w^T - I (unit w)
     Rd[0] = 1.f + c1 * (x * x - 1.f);
     Rd[1] = -s * z + c1 * (x * y);
@@ -437,196 +667,231 @@ __device__ inline void apply_delta(const float* delta, float* T, float& dR_deg, 
 
 #if PXT_EXP_STAMPS  // timing experiment (scripts/lm_stamps.py): s_memtime of workgroup 0's first lane at 8 points per iteration
 __device__ unsigned long long pxt_lm_stamps[256 * 16];
-#define LM_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && total_iters < 256) pxt_lm_stamps[total_iters * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LM_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && run.total_iters < 256) pxt_lm_stamps[run.total_iters * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define LM_STAMP(k)
 #endif
-__global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
-  __shared__ float s_grp[(kLmBlock / 8) * kGrpStride];
-  __shared__ float s_red[kLmMaxGrid * kNAcc];
-  __shared__ float s_tot[kNAcc];
-  __shared__ float s_part[(kLmBlock / kNAcc) * kNAcc];
-  __shared__ float s_T[12];
-  __shared__ int s_flags[4];  // 0 stop level, 1 failed, 2 abort
 
+constexpr int kRedStride = kNAcc + 1;  // padded: the 16 strided partial sums of a slot read distinct banks
+
+struct LmShared {
+  float grp[(kLmBlock / 8) * kGrpStride];   // the block's groups' sums (leaders park them)
+  float red[kLmMaxGrid * kRedStride];       // every workgroup's 32 sums of this epoch
+  float tot[kNAcc];
+  float T[12];
+  int flags[4];  // 0 stop level, 1 failed, 2 abort
+};
+
+struct LmRun {
+  unsigned epoch, base, launch_id, spin_limit;
+  int total_iters;
+  bool failed, aborted;
+};
+
+// One iteration after the accumulation: the group leaders' sums are in sh.grp (n_groups records).  Fold them, publish,
+// sweep every workgroup's granules, fold those, solve, update the pose, test the stop criteria.  Returns true when the
+// level is over (stop criteria met, failure or abort).  Four workgroup barriers.
+__device__ inline bool lm_step(const LmParams& P, const LmLevelDev& L, int li, int it, int n_groups, LmShared& sh, LmRun& run) {
   const int tid = threadIdx.x;
-  const int lane = tid & (PXT_WAVE - 1);
-  const int wave = tid / PXT_WAVE;
+  const int G = gridDim.x;
+  const int slot = tid >> 4, part = tid & 15;  // 32 slots x 16 parts: a slot's parts are one 16-lane DPP row
+  __syncthreads();  // (A) the leaders' records are in sh.grp
+  LM_STAMP(1);
+  // Publish: the data IS the flag (cdna_hip_programming.md G16 recipe R2).  Each of the workgroup's 32 sums travels as
+  // ONE aligned 8-byte {tag = base + epoch + 1, value} granule, written through (sc1) with no drain, no counter, no
+  // fence; EVERY workgroup then sweeps all G x 32 granules of this epoch until every tag matches: an iteration's only
+  // inter-workgroup traffic is one store and one (re-read) load round trip.  Tags count on from the workspace's
+  // previous launch (`base`); two areas alternate by epoch parity (a workgroup publishes epoch e + 1 only after it
+  // has read every granule of epoch e).
+  unsigned long long* const area = P.granules + (size_t)(run.epoch & 1u) * G * kNAcc;
+  const unsigned long long tag = (unsigned long long)(run.base + run.epoch + 1u) << 32;
+  {  // the workgroup's own sums in a fixed order: 16 strided partials per slot, then a fixed 16-lane DPP tree - the
+     // row's first lane stores the granule itself (round 3 went through LDS twice more and one wave published)
+    float v = 0.f;
+    if (slot < 29)
+      for (int q = part; q < n_groups; q += 16) v += sh.grp[q * kGrpStride + slot];
+    v = lm_row16_sum(v);
+    if (part == 0)
+      __hip_atomic_store(area + (size_t)blockIdx.x * kNAcc + slot, tag | (unsigned long long)__float_as_uint(v),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  LM_STAMP(2);
+  LM_STAMP(3);
+  {  // the sweep: every thread re-reads its own few granules (G * 32 / 512: 8 at G = 128) until they carry this epoch
+    const int n_gran = G * kNAcc;
+    unsigned spins = 0;
+    for (int i0 = 0; i0 < n_gran; i0 += 4 * kLmBlock) {
+      for (;;) {
+        bool ok = true;
+        unsigned long long x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * kLmBlock + tid;
+          x[k] = i < n_gran ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+          ok = ok && ((x[k] >> 32) == (tag >> 32));
+        }
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * kLmBlock + tid;
+            if (i < n_gran) sh.red[(i >> 5) * kRedStride + (i & 31)] = __uint_as_float((unsigned)x[k]);
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > run.spin_limit || (((spins & 255u) == 0u) && ld_relaxed_u32(P.err) == run.launch_id)) {
+          __hip_atomic_store(P.err, run.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sh.flags[2] = 1;  // (benign race: every writer stores 1)
+          i0 = n_gran;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();  // (B)
+  LM_STAMP(4);
+  if (sh.flags[2]) {
+    run.aborted = true;
+    return true;
+  }
+  LM_STAMP(5);
+  {  // fold in a FIXED order (bit-identical in every workgroup and every run): 16 strided partials per slot, the DPP tree
+    float v = 0.f;
+    for (int g = part; g < G; g += 16) v += sh.red[g * kRedStride + slot];
+    v = lm_row16_sum(v);
+    if (part == 0) sh.tot[slot] = v;
+  }
+  __syncthreads();  // (C)
+  LM_STAMP(6);
+  if (tid == 0) {
+    const float n_valid = sh.tot[28];
+    const bool fl = (sh.flags[1] != 0) || (n_valid < (float)P.conf.min_valid);
+    float delta[6];
+    const bool chol = solve6(sh.tot, L.lambda, !fl, delta);
+    float Tn[12];
+    for (int i = 0; i < 12; ++i) Tn[i] = sh.T[i];
+    float dR, dt;
+    apply_delta(delta, Tn, dR, dt);
+    for (int i = 0; i < 12; ++i) sh.T[i] = Tn[i];
+    float gn = 0.f;
+    for (int i = 0; i < 6; ++i) gn += sh.tot[i] * sh.tot[i];
+    gn = sqrtf(gn);
+    const bool small_step = (dt < P.conf.dt_stop) && (dR < P.conf.dR_stop);
+    const bool small_grad = gn < P.conf.grad_stop;
+    sh.flags[0] = (small_step || small_grad) ? 1 : 0;
+    sh.flags[1] = fl ? 1 : 0;
+    if (blockIdx.x == 0 && P.log) {
+      float* lg = P.log + ((size_t)li * P.conf.num_iters + it) * PXT_LM_LOG_STRIDE;
+      lg[0] = sh.tot[27] / n_valid;
+      lg[1] = n_valid;
+      lg[2] = dR;
+      lg[3] = dt;
+      lg[4] = gn;
+      lg[5] = chol ? 0.f : 1.f;
+      lg[6] = 0.f;
+      lg[7] = 0.f;
+      for (int i = 0; i < 12; ++i) lg[8 + i] = Tn[i];
+    }
+  }
+  __syncthreads();  // (D)
+  LM_STAMP(7);
+  ++run.epoch;
+  ++run.total_iters;
+  run.failed = sh.flags[1] != 0;
+  return sh.flags[0] != 0 || run.failed;
+}
+
+// Every lane of a group holds the same sums: the group leader parks them in LDS for lm_step's fold.
+template <int LG>
+__device__ inline void lm_park(const float* acc, LmShared& sh) {
+  if ((threadIdx.x & (LG - 1)) == 0) {
+    float* dst = sh.grp + (threadIdx.x / LG) * kGrpStride;
+#pragma unroll
+    for (int i = 0; i < 29; ++i) dst[i] = acc[i];
+  }
+}
+
+// The accumulation of one iteration in the level's variant: 0 the general path (any channel count, several rounds of
+// points per group), 1..4 one-round levels with the point in registers (LG, channel quads per lane) = (8, 1), (32, 1),
+// (16, 2), (8, 4).  One loop body for all of them, so that lm_step - with its solve - is instantiated once.
+__device__ inline void lm_accumulate_variant(int variant, const LmParams& P, const LmLevelDev& L, const float* T,
+                                             const LmPoint<2>& pt, LmShared& sh, unsigned long long* dbg) {
+  switch (variant) {
+    case 1: lm_accumulate_cached<8, 1>(P, L, T, pt, sh.grp, dbg); break;
+    case 2: lm_accumulate_cached<32, 1>(P, L, T, pt, sh.grp, dbg); break;
+    case 3: lm_accumulate_cached<16, 2>(P, L, T, pt, sh.grp, dbg); break;
+    case 4: lm_accumulate_cached<8, 4>(P, L, T, pt, sh.grp, dbg); break;
+    default: {
+      float acc[kNAcc];
+#pragma unroll
+      for (int i = 0; i < kNAcc; ++i) acc[i] = 0.f;
+      const int LGr = (L.C <= 32) ? 8 : 32;
+      lm_accumulate(P, L, T, acc, LGr, dbg);
+      if (LGr == 8) lm_park<8>(acc, sh); else lm_park<32>(acc, sh);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
+  __shared__ LmShared sh;
+  const int tid = threadIdx.x;
   const int G = gridDim.x;
 
-  if (tid < 12) s_T[tid] = P.T_init[tid];
+  if (tid < 12) sh.T[tid] = P.T_init[tid];
   if (tid == 0) {
-    s_flags[0] = 0;
-    s_flags[1] = 0;
-    s_flags[2] = 0;
+    sh.flags[0] = 0;
+    sh.flags[1] = 0;
+    sh.flags[2] = 0;
   }
   __syncthreads();
 
-  unsigned epoch = 0;
   // Tags continue where the workspace's previous launch stopped (control word 1, advanced by workgroup 0 at the end of
   // every launch - which it reaches only after every workgroup has published, hence read this word, at least once): what
   // earlier launches left in the granule areas never carries a tag of this one, so nothing has to be zeroed between
   // launches (the memset node before every launch was 5 us + a dependent-launch gap on the frame's serial chain).
-  const unsigned base = ld_relaxed_u32(P.err + 1);
-  const unsigned launch_id = base + 1u;  // what the error word holds when THIS launch timed out
-  const unsigned spin_limit = P.conf.spin_limit > 0 ? (unsigned)P.conf.spin_limit : kSpinLimit;
-  int total_iters = 0;
-  bool failed = false;
-  bool aborted = false;
+  LmRun run;
+  run.epoch = 0;
+  run.base = ld_relaxed_u32(P.err + 1);
+  run.launch_id = run.base + 1u;  // what the error word holds when THIS launch timed out
+  run.spin_limit = P.conf.spin_limit > 0 ? (unsigned)P.conf.spin_limit : kSpinLimit;
+  run.total_iters = 0;
+  run.failed = false;
+  run.aborted = false;
+  const int groups32 = G * kLmWaves * 2, groups16 = groups32 * 2, groups8 = groups32 * 4;
+  const bool one_round_ok = P.conf.path != 2;  // (2: always the general path - A/B and tests)
 
-  for (int li = 0; li < P.n_levels && !failed && !aborted; ++li) {
+  for (int li = 0; li < P.n_levels && !run.failed && !run.aborted; ++li) {
     const LmLevelDev& L = P.lv[li];
+    int variant = 0;
+    if (one_round_ok && L.C == 32 && P.n <= groups8) variant = 1;
+    else if (one_round_ok && L.C == 128 && P.n <= groups32) variant = 2;
+    else if (one_round_ok && L.C == 128 && P.n <= groups16) variant = 3;
+    else if (one_round_ok && L.C == 128 && P.n <= groups8) variant = 4;
+    LmPoint<2> pt;
+    pt.X = pt.Y = pt.Z = pt.wref = 0.f;
+    pt.fr[0] = pt.fr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    pt.n = 0;
+    pt.valid = false;
+    if (variant == 1) lm_load_point<8, 1>(P, L, pt);
+    else if (variant == 2) lm_load_point<32, 1>(P, L, pt);
+    else if (variant == 3) lm_load_point<16, 2>(P, L, pt);
+    else if (variant == 4) lm_load_point<8, 4>(P, L, pt);
+    const int n_groups = kLmBlock / (variant == 2 ? 32 : variant == 3 ? 16 : variant != 0 ? 8 : (L.C <= 32 ? 8 : 32));
     int iters_done = 0;
     for (int it = 0; it < P.conf.num_iters; ++it) {
       LM_STAMP(0);
       float T[12];
 #pragma unroll
-      for (int i = 0; i < 12; ++i) T[i] = s_T[i];
-
-      float acc[kNAcc];
-#pragma unroll
-      for (int i = 0; i < kNAcc; ++i) acc[i] = 0.f;
-      const int LGr = (L.C <= 32) ? 8 : 32;
+      for (int i = 0; i < 12; ++i) T[i] = sh.T[i];
+      unsigned long long* dbg = nullptr;
 #if PXT_EXP_STAMPS
-      lm_accumulate(P, L, T, acc, LGr, (blockIdx.x == 0 && threadIdx.x == 0 && total_iters < 256) ? pxt_lm_stamps + total_iters * 16 : nullptr);
-#else
-      lm_accumulate(P, L, T, acc, LGr);
+      if (blockIdx.x == 0 && threadIdx.x == 0 && run.total_iters < 256) dbg = pxt_lm_stamps + run.total_iters * 16;
 #endif
-
-      // Every lane of a group holds the same sums: the group leader parks them in
-      // LDS and 32 threads fold the groups of the block in a fixed order.
-      const int n_groups = kLmBlock / LGr;
-      if ((lane & (LGr - 1)) == 0) {
-        float* dst = s_grp + (tid / LGr) * kGrpStride;
-#pragma unroll
-        for (int i = 0; i < 29; ++i) dst[i] = acc[i];
-      }
-      __syncthreads();
-      LM_STAMP(1);
-
-      // Publish: the data IS the flag (cdna_hip_programming.md G16 recipe R2).  Each of the workgroup's sums
-      // travels as ONE aligned 8-byte {tag = epoch + 1, value} granule, written through (sc1) by wave 0 with no
-      // drain, no counter, no fence; EVERY workgroup then sweeps all G x 32 granules of this epoch (a few per
-      // thread) until every tag matches, so an iteration's only inter-workgroup traffic is one store and one (re-read)
-      // load round trip.  (The first version - partials, drain, arrive on a counter, spin, all-gather - was four
-      // dependent round trips, 8.1k of a 23k-cycle iteration; stamps.)  Tags count on from the workspace's previous
-      // launch (`base`), two areas alternate by epoch parity (a
-      // workgroup publishes epoch e + 1 only after it has read every granule of epoch e).
-      unsigned long long* const area = P.granules + (size_t)(epoch & 1u) * G * kNAcc;
-      const unsigned long long tag = (unsigned long long)(base + epoch + 1u) << 32;
-      {  // the workgroup's own sums, in a fixed order: 16 strided partials per slot, then the 16 in sequence
-        const int slot = tid & (kNAcc - 1), part = tid >> 5;
-        float s = 0.f;
-        if (slot < 29)
-          for (int q = part; q < n_groups; q += kLmBlock / kNAcc) s += s_grp[q * kGrpStride + slot];
-        s_part[part * kNAcc + slot] = s;
-      }
-      __syncthreads();
-      if (wave == 0) {
-        if (lane < kNAcc) {
-          float s = 0.f;
-#pragma unroll
-          for (int q = 0; q < kLmBlock / kNAcc; ++q) s += s_part[q * kNAcc + lane];
-          __hip_atomic_store(area + (size_t)blockIdx.x * kNAcc + lane, tag | (unsigned long long)__float_as_uint(s),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        LM_STAMP(2);
-        LM_STAMP(3);
-      }
-      {  // the sweep: every thread re-reads its own few granules (G * 32 / 512: 4 at G = 64) until they carry this epoch
-        const int n_gran = G * kNAcc;
-        unsigned spins = 0;
-        for (int i0 = 0; i0 < n_gran; i0 += 4 * kLmBlock) {
-          for (;;) {
-            bool ok = true;
-            unsigned long long x[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int i = i0 + k * kLmBlock + tid;
-              x[k] = i < n_gran ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-              ok = ok && ((x[k] >> 32) == (tag >> 32));
-            }
-            if (ok) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const int i = i0 + k * kLmBlock + tid;
-                if (i < n_gran) s_red[i] = __uint_as_float((unsigned)x[k]);
-              }
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > spin_limit || (((spins & 255u) == 0u) && ld_relaxed_u32(P.err) == launch_id)) {
-              __hip_atomic_store(P.err, launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              s_flags[2] = 1;  // (benign race: every writer stores 1)
-              i0 = n_gran;
-              break;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      LM_STAMP(4);
-      if (s_flags[2]) {
-        aborted = true;
-        break;
-      }
-      LM_STAMP(5);
-      // Fold in a FIXED order (bit-identical in every workgroup and every run): 16 strided partial sums per
-      // accumulator slot, then the 16 partials in sequence.  (One thread per slot walking all G partials
-      // was a chain of G dependent LDS reads: 5.1k cycles of a 27k-cycle iteration at G = 64.)
-      {
-        const int slot = tid & (kNAcc - 1), part = tid >> 5;  // kLmBlock / kNAcc = 16 parts
-        float s = 0.f;
-        for (int g = part; g < G; g += kLmBlock / kNAcc) s += s_red[g * kNAcc + slot];
-        s_part[part * kNAcc + slot] = s;
-      }
-      __syncthreads();
-      if (tid < kNAcc) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < kLmBlock / kNAcc; ++q) s += s_part[q * kNAcc + tid];
-        s_tot[tid] = s;
-      }
-      __syncthreads();
-      LM_STAMP(6);
-
-      if (tid == 0) {
-        const float n_valid = s_tot[28];
-        bool fl = (s_flags[1] != 0) || (n_valid < (float)P.conf.min_valid);
-        float delta[6];
-        const bool chol = solve6(s_tot, L.lambda, !fl, delta);
-        float Tn[12];
-        for (int i = 0; i < 12; ++i) Tn[i] = s_T[i];
-        float dR, dt;
-        apply_delta(delta, Tn, dR, dt);
-        for (int i = 0; i < 12; ++i) s_T[i] = Tn[i];
-        float gn = 0.f;
-        for (int i = 0; i < 6; ++i) gn += s_tot[i] * s_tot[i];
-        gn = sqrtf(gn);
-        const bool small_step = (dt < P.conf.dt_stop) && (dR < P.conf.dR_stop);
-        const bool small_grad = gn < P.conf.grad_stop;
-        s_flags[0] = (small_step || small_grad) ? 1 : 0;
-        s_flags[1] = fl ? 1 : 0;
-        if (blockIdx.x == 0 && P.log) {
-          float* lg = P.log + ((size_t)li * P.conf.num_iters + it) * PXT_LM_LOG_STRIDE;
-          lg[0] = s_tot[27] / n_valid;
-          lg[1] = n_valid;
-          lg[2] = dR;
-          lg[3] = dt;
-          lg[4] = gn;
-          lg[5] = chol ? 0.f : 1.f;
-          lg[6] = 0.f;
-          lg[7] = 0.f;
-          for (int i = 0; i < 12; ++i) lg[8 + i] = Tn[i];
-        }
-      }
-      __syncthreads();
-      LM_STAMP(7);
-      ++epoch;
+      lm_accumulate_variant(variant, P, L, T, pt, sh, dbg);
+      const bool stop = lm_step(P, L, li, it, n_groups, sh, run);
+      if (run.aborted) break;
       ++iters_done;
-      ++total_iters;
-      failed = s_flags[1] != 0;
-      if (s_flags[0]) break;
+      if (stop) break;
     }
     if (blockIdx.x == 0 && tid == 0) P.out[16 + li] = (float)iters_done;
   }
@@ -638,11 +903,11 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
     // starting at base + e + 1 would have accepted as its own epoch 0.  It can get at most one epoch
     // further than the slowest of the others (it needs THEIR granules of that epoch), so 8 is generous; the host
     // zeroes the workspace after a time-out as well (optimizer.py).
-    P.err[1] = base + epoch + 1u + (aborted ? 8u : 0u);
-    for (int i = 0; i < 12; ++i) P.out[i] = s_T[i];
-    P.out[12] = failed ? 1.f : 0.f;
-    P.out[13] = aborted ? (float)PXT_E_TIMEOUT : 0.f;
-    P.out[14] = (float)total_iters;
+    P.err[1] = run.base + run.epoch + 1u + (run.aborted ? 8u : 0u);
+    for (int i = 0; i < 12; ++i) P.out[i] = sh.T[i];
+    P.out[12] = run.failed ? 1.f : 0.f;
+    P.out[13] = run.aborted ? (float)PXT_E_TIMEOUT : 0.f;
+    P.out[14] = (float)run.total_iters;
     // out[15] flips to 1 once the record and the log (all written by this thread) are visible
     // system-wide: a host that keeps `out` in pinned memory can poll this word instead of
     // waiting on an event (saves the ~25 us wake-up on the frame's critical path).
@@ -651,7 +916,7 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
     // has left; the renderer's kernels start after this kernel ends, in stream order)
     if (P.cam_enabled) {
       float cam[12];
-      pose_to_camera_f64(s_T, P.cam_conv, cam);
+      pose_to_camera_f64(sh.T, P.cam_conv, cam);
       for (int k = 0; k < 2; ++k)
         if (P.cam_slot[k])
           for (int i = 0; i < 12; ++i) P.cam_slot[k][i] = cam[i];
@@ -826,7 +1091,14 @@ extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, in
   P.err = (unsigned*)ws;  // 256-byte control block, then the granule areas
   P.granules = (unsigned long long*)(ws + 256);
   int grid = conf->n_workgroups;
-  if (grid <= 0) grid = 128;  // scripts/bench_lm.py: 8.7 us per iteration at 128, 9.9 at 64, 10.2 at 256
+  if (grid <= 0) {
+    // Default: the smallest grid (a multiple of 32, 128 .. 256) whose 32-lane groups hold every point in ONE round
+    // (G x 8 waves x 2 groups): the level then keeps its points in registers with one channel quad per lane, the
+    // cheapest variant (scripts/bench_lm.py, round 4: 7.8 us per iteration against 8.7 with 16-lane groups at 128
+    // workgroups for the benchmark's 2341 points).  Beyond 256 workgroups the narrower groups take over.
+    grid = ((n_points + 15) / 16 + 31) / 32 * 32;
+    grid = grid < 128 ? 128 : (grid > kLmMaxGrid ? kLmMaxGrid : grid);
+  }
   if (grid > kLmMaxGrid) grid = kLmMaxGrid;
   // every workgroup spins until every granule of the epoch is tagged, so all of them must be resident at
   // once: never more workgroups than the device (or the partition / CU mask this process sees) can hold.
@@ -845,8 +1117,24 @@ extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, in
     if (grid > resident_cap[dev_id]) grid = resident_cap[dev_id];
   }
   hipStream_t s = (hipStream_t)stream;
+  // One workgroup per CU: 128 workgroups of 42 KB of LDS may be placed two to a CU, and a CU that carries two runs
+  // each at half speed while 127 others wait for it at the iteration's exchange ("spin until all arrived" 5.5 k of a
+  // 19.5 k-cycle iteration in scripts/lm_stamps.py).  Asking for more than half a CU's 160 KB of LDS makes the second
+  // one impossible; the pad is never touched.  (Only while the grid fits the CUs one to one.)
+  static const int pad_lds = [] { const char* e = getenv("PXT_LM_PAD_LDS"); return e ? atoi(e) : 0; }();
+  int n_cus = 0;
+  (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+  size_t dyn = 0;
+  if (pad_lds && grid <= n_cus) {
+    dyn = 84 * 1024 - sizeof(LmShared);
+    static bool attr_done = false;
+    if (!attr_done) {
+      PXT_HIP_CHECK(hipFuncSetAttribute((const void*)lm_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+      attr_done = true;
+    }
+  }
   // (no memset: the polled words - granule tags, error word - are compared with values only this launch writes)
-  hipLaunchKernelGGL(lm_refine_kernel, dim3(grid), dim3(kLmBlock), 0, s, P);
+  hipLaunchKernelGGL(lm_refine_kernel, dim3(grid), dim3(kLmBlock), dyn, s, P);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }

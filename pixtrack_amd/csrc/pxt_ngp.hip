@@ -1450,8 +1450,8 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
 // the largest slice.  (The first version sized them for half the rays whatever the number of pipelines: a
 // one-pipeline render - any render below 2^19 rays - whose camera sees the box in more than half of its pixels
 // wrote past them.)
-static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
-  size_t cap = (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile;
+static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe, size_t min_cap = 0) {
+  size_t cap = std::max(min_cap, (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile);
   if (ctx->scratch && ctx->scratch_rays >= rays && ctx->scratch_cap >= cap && ctx->scratch_pipes >= n_pipe) return PXT_OK;
   // grow only: a context that alternates between pipeline counts (bench: the isolated one-pipeline pass) keeps
   // the larger layout
@@ -1555,7 +1555,12 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   static const int env_pipes = [] { const char* e = getenv("PXT_NGP_PIPES"); return e ? atoi(e) : 2; }();
   const int want_pipes = ctx->pipelines > 0 ? ctx->pipelines : env_pipes;
   const int n_pipe = rays >= ((size_t)1 << 19) ? std::min(std::max(want_pipes, 1), pxt_ngp::kMaxPipes) : 1;
-  int rc = ensure_scratch(ctx, rays, n_pipe);
+  // PXT_NGP_SPLIT = percent of the rays the FIRST of two pipelines takes (default 50; experiment: the side stream's
+  // chain starts a fork event later and trails the caller's by 20-50 us per stage - does a larger first slice even
+  // them out?  Measured in round 4: profiles/r04_experiments.md)
+  static const int split_pct = [] { const char* e = getenv("PXT_NGP_SPLIT"); return e ? std::min(std::max(atoi(e), 10), 90) : 50; }();
+  int rc = ensure_scratch(ctx, rays, n_pipe,
+                          (n_pipe == 2 && split_pct != 50) ? rays * (size_t)std::max(split_pct, 100 - split_pct) / 100 + 3 * kTile : 0);
   if (rc != PXT_OK) return rc;
   if (n_pipe > 1 && !ctx->ev_fork) {
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1569,11 +1574,12 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   NgpParams Pp[pxt_ngp::kMaxPipes];
   const long long total = (long long)rays;
   const long long per = n_pipe > 1 ? ((total / n_pipe + kTile - 1) / kTile) * kTile : total;
+  const long long first = (n_pipe == 2 && split_pct != 50) ? ((total * split_pct / 100 + kTile - 1) / kTile) * kTile : per;
   for (int w = 0; w < n_pipe; ++w) {
     st[w] = w == 0 ? s0 : ctx->side[w];
     Pp[w] = P;
-    Pp[w].enum_lo = std::min(total, per * w);
-    Pp[w].enum_hi = (w == n_pipe - 1) ? total : std::min(total, per * (w + 1));
+    Pp[w].enum_lo = w == 0 ? 0 : std::min(total, n_pipe == 2 ? first : per * w);
+    Pp[w].enum_hi = (w == n_pipe - 1) ? total : std::min(total, n_pipe == 2 ? first : per * (w + 1));
   }
   if (n_pipe > 1) {
     PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));  // the side streams start after the caller's earlier work

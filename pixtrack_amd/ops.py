@@ -37,7 +37,7 @@ SCHEMAS = {
         "int[] ndist, float[] lambdas, float[] T_init, int num_iters, int pad, int loss, float loss_alpha, "
         "float loss_scale, float grad_stop, float dt_stop, float dR_stop, int min_valid, int n_workgroups, "
         "Tensor(a!) record, Tensor(b!) workspace, bool want_log, int spin_limit=0, float[]? cam_conv=None, "
-        "int[]? cam_slots=None, Tensor(c!)? cam_out=None) -> ()"),
+        "int[]? cam_slots=None, Tensor(c!)? cam_out=None, int lm_path=0) -> ()"),
     "sample_sparse": (
         "(Tensor p3d, float[] T, Tensor[] fmaps, int[] channels, float[] cameras, int[] ndist, int pad, "
         "bool normalize, Tensor(a!)[] outs, Tensor(b!) valid) -> ()"),
@@ -79,7 +79,7 @@ def _f32c(t: torch.Tensor, what: str) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------- LM
 def _lm_refine(p3d, point_mask, fmaps, frefs, channels, cameras, ndist, lambdas, T_init, num_iters, pad, loss,
                loss_alpha, loss_scale, grad_stop, dt_stop, dR_stop, min_valid, n_workgroups, record, workspace,
-               want_log, spin_limit=0, cam_conv=None, cam_slots=None, cam_out=None):
+               want_log, spin_limit=0, cam_conv=None, cam_slots=None, cam_out=None, lm_path=0):
     L = _lib.lib()
     n_levels = len(fmaps)
     if not (1 <= n_levels <= _lib.PXT_MAX_LEVELS) or len(frefs) != n_levels or len(channels) != n_levels:
@@ -104,6 +104,7 @@ def _lm_refine(p3d, point_mask, fmaps, frefs, channels, cameras, ndist, lambdas,
     conf.loss_alpha, conf.loss_scale = float(loss_alpha), float(loss_scale)
     conf.grad_stop, conf.dt_stop, conf.dR_stop = float(grad_stop), float(dt_stop), float(dR_stop)
     conf.min_valid, conf.n_workgroups, conf.spin_limit = int(min_valid), int(n_workgroups), int(spin_limit)
+    conf.path = int(lm_path)
     nh = 16 + _lib.PXT_MAX_LEVELS
     need = nh + (n_levels * int(num_iters) * _lib.PXT_LM_LOG_STRIDE if want_log else 0)
     if record.dtype != torch.float32 or record.numel() < need or not record.is_contiguous():

@@ -159,6 +159,7 @@ class PixTrackOptimizer:
         learned_damping=True,
         min_valid=10,
         n_workgroups=0,
+        lm_path=0,  # 0: automatic (one-round levels keep their points in registers); 2: always the general path
         spin_limit=0,  # polls before an inter-workgroup wait gives up (0: the library's default; tests force a time-out with 1)
     )
 
@@ -234,6 +235,7 @@ class PixTrackOptimizer:
         c.min_valid = int(self.conf.min_valid)
         c.n_workgroups = int(self.conf.n_workgroups)
         c.spin_limit = int(self.conf.get("spin_limit", 0))
+        c.path = int(self.conf.get("lm_path", 0))
         return c
 
     @staticmethod
@@ -279,7 +281,7 @@ class PixTrackOptimizer:
                       bool(want_log), int(conf.spin_limit),
                       None if camera is None else [float(x) for x in camera[0]],
                       None if camera is None else [int(x) for x in camera[1]],
-                      None if camera is None else camera[2])
+                      None if camera is None else camera[2], int(conf.path))
         keep = list(levels)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))

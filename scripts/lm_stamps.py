@@ -14,9 +14,10 @@ def l2n(x, dim):
 
 def main():
     dev = torch.device("cuda:0")
+    import os
     W, H, N = 640, 480, 2048
-    if len(sys.argv) > 1:
-        N = int(sys.argv[1])
+    if len(sys.argv) > 2:
+        N = int(sys.argv[2])
     sc = make_lm_scene(seed=1001, width=W, height=H, n_points=N, sigma_px=2.0)
     lam = [10.0 ** (-6 + torch.sigmoid(torch.full((6,), -2.0)) * 11) for _ in range(3)]
     packs = []
@@ -36,7 +37,8 @@ def main():
     ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=dev)
     import ctypes, numpy as np
     grid = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    conf = dict(num_iters=40, pad=1, n_workgroups=grid, grad_stop_criteria=0.0, dt_stop_criteria=0.0, dR_stop_criteria=0.0)
+    conf = dict(num_iters=40, pad=1, n_workgroups=grid, grad_stop_criteria=0.0, dt_stop_criteria=0.0, dR_stop_criteria=0.0,
+                lm_path=int(os.environ.get("PXT_LM_PATH", "0")))
     nc = PixTrackOptimizer(conf).native_conf()
     for want_log in (True, False):
         for _ in range(3):

@@ -112,7 +112,7 @@ int main() {
   for (int i = 0; i < 6; ++i) lv.lambda[i] = 1e-4f;
   pxt_lm_conf conf;
   conf.num_iters = num_iters; conf.pad = 1; conf.loss = 2; conf.loss_alpha = 0.f; conf.loss_scale = 0.1f;
-  conf.grad_stop = 1e-4f; conf.dt_stop = 5e-3f; conf.dR_stop = 5e-2f; conf.min_valid = 10; conf.n_workgroups = 0; conf.spin_limit = 0;
+  conf.grad_stop = 1e-4f; conf.dt_stop = 5e-3f; conf.dR_stop = 5e-2f; conf.min_valid = 10; conf.n_workgroups = 0; conf.spin_limit = 0; conf.path = 0;
   rc = pxt_lm_refine(d_p3d, d_valid, N, &lv, 1, T0, &conf, d_out, d_log, d_ws, stream);
   if (rc != PXT_OK) { std::printf("pxt_lm_refine -> %d (%s)\n", rc, pxt_last_error()); return 4; }
   CK(hipStreamSynchronize(stream));
