@@ -633,7 +633,7 @@ def main():
     # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes of this command
     # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be taken live here)
     traffic, traffic_src = None, None
-    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (3, 2)) if q.exists()), None)
+    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (4, 3, 2)) if q.exists()), None)
     if pmc is not None:
         recs = json.loads(pmc.read_text())
         rec = (recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
@@ -648,7 +648,7 @@ def main():
     # not HBM bytes - the fabric side moves ~0.35 x the algorithmic bytes - but the L1's miss path: requests to the L2
     # x their latency.  `l2` prices the kernel against the L2's own peak as well.
     l2 = None
-    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (3,)) if q.exists()), None)
+    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (4, 3)) if q.exists()), None)
     if l2f is not None:
         recs = json.loads(l2f.read_text())
         rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
@@ -719,7 +719,7 @@ def main():
     # other kernels' utilisation from the committed rocprofv3 SQ counter pass of this command
     # (profiles/r02_pmc_sq.json; scripts/pmc_sq_summary.py): matrix-pipe busy of the UNet convolutions,
     # VALU busy of the march (a serial DDA per ray: latency- and tail-bound, not VALU-bound)
-    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (3, 2)) if q.exists()), None)
+    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (4, 3, 2)) if q.exists()), None)
     if sq is not None:
         rec = json.loads(sq.read_text())
         pick = {}

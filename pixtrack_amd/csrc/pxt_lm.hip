@@ -1091,14 +1091,9 @@ extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, in
   P.err = (unsigned*)ws;  // 256-byte control block, then the granule areas
   P.granules = (unsigned long long*)(ws + 256);
   int grid = conf->n_workgroups;
-  if (grid <= 0) {
-    // Default: the smallest grid (a multiple of 32, 128 .. 256) whose 32-lane groups hold every point in ONE round
-    // (G x 8 waves x 2 groups): the level then keeps its points in registers with one channel quad per lane, the
-    // cheapest variant (scripts/bench_lm.py, round 4: 7.8 us per iteration against 8.7 with 16-lane groups at 128
-    // workgroups for the benchmark's 2341 points).  Beyond 256 workgroups the narrower groups take over.
-    grid = ((n_points + 15) / 16 + 31) / 32 * 32;
-    grid = grid < 128 ? 128 : (grid > kLmMaxGrid ? kLmMaxGrid : grid);
-  }
+  // 128 workgroups: scripts/bench_lm.py, round 4, N = 2341: 8.7 us per iteration at 64, 8.5 at 128, 8.5 at 192 (where every
+  // C = 128 level fits 32-lane groups in one round: the larger sweep costs what the cheaper variant saves), 8.8 at 256
+  if (grid <= 0) grid = 128;
   if (grid > kLmMaxGrid) grid = kLmMaxGrid;
   // every workgroup spins until every granule of the epoch is tagged, so all of them must be resident at
   // once: never more workgroups than the device (or the partition / CU mask this process sees) can hold.

@@ -214,12 +214,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int spli
 // wts: fp16 [32*NT][Cin] (rows >= C+1 are zero), bias fp32 [32*NT].
 // ---------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void head_mfma_kernel(const half_t* __restrict__ in, long long npix, int Cin,
-                                                        const half_t* __restrict__ wts,
-                                                        const float* __restrict__ bias, int Cout, int normalize,
-                                                        float* __restrict__ out, int cstride) {
+__device__ __forceinline__ void head_mfma_body(const half_t* __restrict__ in, long long npix, int Cin,
+                                               const half_t* __restrict__ wts, const float* __restrict__ bias, int Cout,
+                                               int normalize, float* __restrict__ out, int cstride, long long wave) {
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long p0 = wave * 32;
   if (p0 >= npix) return;
   const int r31 = lane & 31, khalf = lane >> 5;
@@ -277,6 +275,35 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const half_t* __restrict
       }
       *(float4*)(o + co) = v;
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void head_mfma_kernel(const half_t* __restrict__ in, long long npix, int Cin,
+                                                        const half_t* __restrict__ wts,
+                                                        const float* __restrict__ bias, int Cout, int normalize,
+                                                        float* __restrict__ out, int cstride) {
+  head_mfma_body<NT>(in, npix, Cin, wts, bias, Cout, normalize, out, cstride,
+                     ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+}
+
+// The two coarse heads of one image (strides 16 and 4: 38 + 600 waves at 640x480) in ONE launch of one-wave
+// workgroups: workgroups below a.waves serve job a, the rest job b (round 4: one dispatch less per pass).
+struct HeadJob {
+  const half_t* in;
+  long long npix;
+  int Cin;
+  const half_t* wts;
+  const float* bias;
+  int Cout, normalize;
+  float* out;
+  int cstride;
+  long long waves;
+};
+template <int NT>
+__global__ __launch_bounds__(64) void head_pair_kernel(const HeadJob a, const HeadJob b) {
+  const long long w = blockIdx.x;
+  if (w < a.waves) head_mfma_body<NT>(a.in, a.npix, a.Cin, a.wts, a.bias, a.Cout, a.normalize, a.out, a.cstride, w);
+  else head_mfma_body<NT>(b.in, b.npix, b.Cin, b.wts, b.bias, b.Cout, b.normalize, b.out, b.cstride, w - a.waves);
 }
 
 // ---------------------------------------------------------------------------
@@ -576,6 +603,7 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
       if (a.first.enabled) launch_v2<2, 2, 1, 4, false, 3, true>(a, grid, s);
       else launch_v2<2, 2, 1, 4, false>(a, grid, s);
       break;
+
     case 4: launch_v2<2, 2, 2, 2, false>(a, grid, s); break;
     default: launch_v2<1, 2, 1, 4, false>(a, grid, s); break;
   }
@@ -857,6 +885,22 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
     }
   };
 
+  // both coarse heads of a single image in one launch (after dec1 exists); PXT_UNET_MERGE_HEADS=0 keeps the two launches
+  static const bool merge_heads_env = [] { const char* e = getenv("PXT_UNET_MERGE_HEADS"); return e ? atoi(e) != 0 : true; }();
+  const bool merge_heads = merge_heads_env && B == 1 && ctx->head[1].cout + 1 > 64 && ctx->head[2].cout + 1 > 64 &&
+                           ctx->head[1].cout + 1 <= 160 && ctx->head[2].cout + 1 <= 160;
+  auto head_job = [&](int k) {
+    static const int head_src[3] = {0, 2, 4};
+    const UnetLayer& Lh = ctx->head[k];
+    const int i = head_src[k];
+    const int hh = (i == 4) ? P.h[4] : P.dh[3 - i], ww = (i == 4) ? P.w[4] : P.dw[3 - i];
+    HeadJob j;
+    j.in = pre[i]; j.npix = (long long)hh * ww; j.Cin = Lh.cin; j.wts = ctx->head_w[k]; j.bias = ctx->head_b[k];
+    j.Cout = Lh.cout; j.normalize = normalize[0]; j.out = out_maps[k]; j.cstride = out_cstride[k];
+    j.waves = (j.npix + 31) / 32;
+    return j;
+  };
+
   const half_t* skip[5];
   const half_t* cur = nullptr;
   bool pooled_by_conv = false;
@@ -922,9 +966,11 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
   }
   // decoder
   pre[4] = skip[4];
-  PXT_HIP_CHECK(hipEventRecord(ss.ev_enc4, s));
-  PXT_HIP_CHECK(hipStreamWaitEvent(ss.side, ss.ev_enc4, 0));
-  launch_head(2, ss.side);
+  if (!merge_heads) {
+    PXT_HIP_CHECK(hipEventRecord(ss.ev_enc4, s));
+    PXT_HIP_CHECK(hipStreamWaitEvent(ss.side, ss.ev_enc4, 0));
+    launch_head(2, ss.side);
+  }
   const half_t* prev = skip[4];
   bool head0_fused = false;
   int ph = P.h[4], pw = P.w[4], pc = ctx->conv[12].cout;
@@ -958,7 +1004,12 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
     if (d == 1) {  // dec1 feeds the stride-4 head
       PXT_HIP_CHECK(hipEventRecord(ss.ev_dec1, s));
       PXT_HIP_CHECK(hipStreamWaitEvent(ss.side, ss.ev_dec1, 0));
-      launch_head(1, ss.side);
+      if (merge_heads) {
+        const HeadJob ja = head_job(2), jb = head_job(1);
+        hipLaunchKernelGGL(head_pair_kernel<5>, dim3((unsigned)(ja.waves + jb.waves)), dim3(64), 0, ss.side, ja, jb);
+      } else {
+        launch_head(1, ss.side);
+      }
     }
   }
   g_conv_layer = 0;

@@ -2,7 +2,7 @@
 # Collects everything profiles/ holds for a round, each in its own rocprofv3 run (kernel trace, then one --pmc pass per
 # counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_* in a third), and writes the summaries under
 # gpurun_out/<rNN>/ (copy the ones to be judged into profiles/).
-r=${1:-r03}
+r=${1:-r04}
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(pwd)
 out=$root/gpurun_out/$r; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- $cmd > $out/${r}_bench_unde
 python $root/scripts/rocpd_summary.py $out/kt/kt_results.db > $out/${r}_kernel_stats.csv
 python $root/scripts/unet_timeline.py $out/kt/kt_results.db > $out/${r}_unet_timeline.txt 2>&1
 python $root/scripts/ngp_timeline.py $out/kt/kt_results.db > $out/${r}_ngp_timeline.txt 2>&1
+python $root/scripts/frame_timeline.py $out/kt/kt_results.db > $out/${r}_frame_timeline.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pf -o pf -- $cmd > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pw -o pw -- $cmd > $out/pmc_write.log 2>&1
 python $root/scripts/pmc_summary.py $out/pf/pf_results.db $out/pw/pw_results.db > $out/${r}_pmc_traffic.json
