@@ -169,6 +169,15 @@ int pxt_unet_destroy(pxt_unet* ctx);
 /* Scratch the forward pass needs for an H x W input. */
 int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int32_t W);
 
+/* Diagnostic for a NEW checkpoint (not on the frame's path): pixloc runs this network in fp32, this library stores its
+ * activations as fp16.  After a single-image pxt_unet_forward on `workspace`, writes for each of the 17 convolutions
+ * stats[2 * l] = largest |activation| (float) and stats[2 * l + 1] = number of non-finite values (uint32 bits) of the
+ * layer's output as it sits in the workspace; -1 for the two layers that are never materialised (the first one when it is
+ * computed inside the second one's staging, the last one when the fine head is fused).  A non-zero count, or a maximum
+ * near 65504, means the checkpoint needs rescaling (or bf16 storage) before its poses can be trusted. */
+int pxt_unet_activation_stats(pxt_unet* ctx, int32_t H, int32_t W, const void* workspace, float* stats_device /* [34] */,
+                              void* stream);
+
 /* image: HWC, 3 channels, values 0..255 (float32 if image_is_u8 == 0, else uint8).
  * mask: optional H x W uint8 (0/1) multiplied into the image first
  *       (pixloc_tracker_r9.py:224-225), NULL for none.

@@ -284,6 +284,20 @@ class UNet:
                                [bool(it[2]) for it in items], [o for per in outs for o in per], self._ws)
         return outs
 
+    def activation_stats(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        """Range check of the fp16 activations for one image (HWC 0..255 on the device): runs a single-image pass and
+        returns [(largest |activation|, number of non-finite values)] for the 17 convolutions (None for the two layers
+        that are never written to memory).  pixloc runs this network in fp32; with a real checkpoint, call this on a few
+        frames before trusting the poses: a count > 0 or a maximum near 65504 means fp16 storage overflows there."""
+        self.forward_packed(image, mask, normalize=False)
+        H, W = int(image.shape[0]), int(image.shape[1])
+        stats = torch.zeros(34, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().pxt_unet_activation_stats(self._ctx, H, W, self._ws.data_ptr(), stats.data_ptr(),
+                                                        _lib.stream_ptr(self.device)), "pxt_unet_activation_stats")
+        h = stats.cpu()
+        counts = h.view(torch.int32)
+        return [None if float(h[2 * l]) < 0 else (float(h[2 * l]), int(counts[2 * l + 1])) for l in range(17)]
+
     def __call__(self, data: Dict[str, torch.Tensor]) -> Dict[str, List[torch.Tensor]]:
         image = data["image"]  # 1 x 3 x H x W in [0, 1]
         assert image.dim() == 4 and image.shape[0] == 1 and image.shape[1] == 3

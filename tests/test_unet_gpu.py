@@ -232,3 +232,21 @@ def test_split_k_on_the_third_kernel(device, cfg, splits):
         assert torch.isfinite(got).all() and (got - ref).abs().max().item() < tol
         first = got if first is None else first
         assert torch.equal(got, first)
+
+
+def test_activation_stats_flag_an_fp16_overflow(device):
+    """UNet.activation_stats (pxt_unet_activation_stats): the range check a maintainer runs on a NEW checkpoint - pixloc
+    runs this network in fp32, the library stores activations as fp16.  Synthetic weights stay far inside the range; the
+    same weights with every 3x3 filter scaled by 12 overflow in the deeper layers, and the check says where."""
+    from pixtrack_amd.unet import UNet, make_synthetic_unet_weights
+
+    w = make_synthetic_unet_weights(7)
+    img = (torch.rand(120, 160, 3, generator=torch.Generator().manual_seed(3)) * 255).to(device)
+    st = UNet(w, device).activation_stats(img)
+    assert len(st) == 17 and st[0] is None and st[16] is None  # fused first layer / fused fine head: never in memory
+    seen = [s for s in st if s is not None]
+    assert len(seen) == 15 and all(n == 0 for _, n in seen) and all(1e-3 < m < 6.0e4 for m, _ in seen), st
+    big = {k: (v * 12.0 if (v.dim() == 4 and v.shape[-1] == 3) else v) for k, v in w.items()}
+    st2 = UNet(big, device).activation_stats(img)
+    bad = [l for l, s in enumerate(st2) if s is not None and s[1] > 0]
+    assert bad and min(bad) >= 2, st2  # the first layers still fit, the growth of 12x per layer overflows further down
