@@ -691,28 +691,23 @@ __device__ int pxt_ngp_stamp_round = 0;
 #define PXT_MARCH_STAMP_RAY
 #define PXT_MARCH_STAMP_END
 #endif
-// One thread per live ray.  The ray walks its lattice as a flat state machine - one lattice point per
-// loop trip, which is either taken as the ray's next sample or skipped to the far side of its empty
-// cell - so a wave makes max-over-lanes(samples + empty cells) trips.  (The first version nested the
-// empty-cell loop inside the loop over the K samples: a wave then made sum-over-k max-over-lanes trips,
-// every trip a dependent occupancy load; in-kernel stamps showed a median wave at 25 us, the slowest
-// at 110 us, and the launch waiting for those.)
-__global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  const int n = Wk.counters[round * kCtrStride];
-  const RayState& S = Wk.st[round & 1];
-  PXT_MARCH_STAMP_BEGIN
-  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
-    const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
-    float t = S.t[slot];
-    PXT_MARCH_STAMP_LOADED
-    const size_t s0 = (size_t)slot * kK;
-    int k = 0;
-    bool out = false;
+// A lane's next K = 8 samples with PN lattice points probed per trip.  The lattice t' = t + dt(t) does not depend on
+// what the cells hold, so a lane can compute PN points ahead, issue their PN occupancy loads together and then replay
+// the serial walk over the results - sample / skip to the border of the empty cell (at least one step, then every
+// point short of the border: advance_past_cell) / leave the box - bit for bit the one-point-per-trip loop, with a PN-th
+// of its dependent load round trips.  (The march is a latency chain: VALU busy 0.14, a trip = one dependent
+// occupancy load + ~100 VALU; the straggler kernel spreads the same idea over the 8 lanes of a ray, ngp_march_group.)
+// PN = 1 is the one-point loop itself.
+template <int PN>
+__device__ __forceinline__ void ngp_march_lane(const NgpParams& P, const NgpWork& Wk, const Ray& r, size_t s0, float& t,
+                                               bool& out) {
+  int k = 0;
+  out = false;
+  if (PN == 1) {
     while (k < kK) {
       if (t >= r.tmax) { out = true; break; }
       float pos[3], dt;
       int mip;
-      PXT_MARCH_TRIP
       if (probe_cell(P, r, t, pos, dt, mip)) {
         Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
         Wk.st_t[s0 + k] = t;
@@ -722,7 +717,66 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
         advance_past_cell(P, r, t, pos, mip);
       }
     }
-    for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    float pending = -INFINITY;  // the border of the empty cell being skipped
+    while (k < kK && !out) {
+      float tt[PN + 1];
+      tt[0] = t;
+#pragma unroll
+      for (int i = 0; i < PN; ++i) tt[i + 1] = tt[i] + calc_dt(tt[i], P.cone_angle, P.dt_lo, P.dt_hi);
+      bool occ[PN];
+      float target[PN];
+#pragma unroll
+      for (int i = 0; i < PN; ++i) {
+        occ[i] = false;
+        target[i] = -INFINITY;
+        if (tt[i] < r.tmax && tt[i] >= pending) {  // (the walk cannot reach the other points)
+          float pos[3], dt;
+          int mip;
+          occ[i] = probe_cell(P, r, tt[i], pos, dt, mip);
+          if (!occ[i]) target[i] = cell_exit_t(r, tt[i], pos, mip);
+        }
+      }
+      float t_next = tt[PN];
+      bool fin = false;
+#pragma unroll
+      for (int i = 0; i < PN; ++i) {
+        if (fin || tt[i] < pending) continue;  // done, or still inside the skipped cell
+        if (tt[i] >= r.tmax) { out = true; fin = true; t_next = tt[i]; continue; }
+        if (occ[i]) {
+          const float ts = tt[i];
+          Wk.spos[s0 + k] = make_float4(r.o[0] + ts * r.d[0], r.o[1] + ts * r.d[1], r.o[2] + ts * r.d[2],
+                                        calc_dt(ts, P.cone_angle, P.dt_lo, P.dt_hi));
+          Wk.st_t[s0 + k] = ts;
+          ++k;
+          if (k == kK) { fin = true; t_next = tt[i + 1]; }
+        } else {
+          pending = target[i];
+        }
+      }
+      t = t_next;
+    }
+  }
+  for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// One thread per live ray.  The ray walks its lattice as a flat state machine - one lattice point per
+// loop trip, which is either taken as the ray's next sample or skipped to the far side of its empty
+// cell - so a wave makes max-over-lanes(samples + empty cells) trips.  (The first version nested the
+// empty-cell loop inside the loop over the K samples: a wave then made sum-over-k max-over-lanes trips,
+// every trip a dependent occupancy load; in-kernel stamps showed a median wave at 25 us, the slowest
+// at 110 us, and the launch waiting for those.)
+template <int PN>
+__global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  const int n = Wk.counters[round * kCtrStride];
+  const RayState& S = Wk.st[round & 1];
+  PXT_MARCH_STAMP_BEGIN
+  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
+    const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
+    float t = S.t[slot];
+    PXT_MARCH_STAMP_LOADED
+    bool out;
+    ngp_march_lane<PN>(P, Wk, r, (size_t)slot * kK, t, out);
     S.t[slot] = t;
     Wk.exhausted[slot] = out ? 1 : 0;
     PXT_MARCH_STAMP_RAY
@@ -739,7 +793,7 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
 // FROM_INIT: the tile's items are enumerated rays generated in place (round 0: ray generation, box test,
 // compaction and the first march in one launch; every lane builds its own ray - the 8 passes of a pixel repeat
 // make_ray, which is cheaper than the launch it saves).
-template <bool FROM_INIT>
+template <bool FROM_INIT, int PN>
 __global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
@@ -800,23 +854,8 @@ __global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams 
       D.T[slot] = T_;
       D.acc[slot] = acc_;
       D.accd[slot] = accd_;
-      const size_t s0 = (size_t)slot * kK;
-      int k = 0;
-      bool out = false;
-      while (k < kK) {
-        if (t >= r.tmax) { out = true; break; }
-        float pos[3], dt;
-        int mip;
-        if (probe_cell(P, r, t, pos, dt, mip)) {
-          Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
-          Wk.st_t[s0 + k] = t;
-          t = t + dt;
-          ++k;
-        } else {
-          advance_past_cell(P, r, t, pos, mip);
-        }
-      }
-      for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool out;
+      ngp_march_lane<PN>(P, Wk, r, (size_t)slot * kK, t, out);
       D.t[slot] = t;
       Wk.exhausted[slot] = out ? 1 : 0;
     }
@@ -1510,6 +1549,37 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe, size_t min_cap 
   return PXT_OK;
 }
 
+// Lattice points a marching lane probes per trip (ngp_march_lane): PXT_NGP_PROBE = 1 / 2 / 4 / 8.  Default 1: probing
+// ahead is bit-exact and cuts a lane's dependent occupancy loads to a PN-th, but the march launches do not get shorter
+// (round 4, rocprofv3 kernel trace of bench.py: compact+march 38.7 / 55.4 us at PN = 1, 42.0 / 54.6 us at PN = 4; the
+// compaction-only kernel, which marches nothing, takes 23.7 us) - what these launches wait for is a CU slot beside the
+// other pipeline's shade workgroups, not their own rays (profiles/r04_experiments.md #15).
+static int march_probe() {
+  static const int pn = [] {
+    const char* e = getenv("PXT_NGP_PROBE");
+    const int v = e ? atoi(e) : 1;
+    return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 1;
+  }();
+  return pn;
+}
+template <bool FROM_INIT>
+static void launch_compact_march(int grid, hipStream_t st, const NgpParams& P, const NgpWork& W, int round) {
+  switch (march_probe()) {
+    case 1: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 1>), dim3(grid), dim3(256), 0, st, P, W, round); break;
+    case 2: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 2>), dim3(grid), dim3(256), 0, st, P, W, round); break;
+    case 8: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 8>), dim3(grid), dim3(256), 0, st, P, W, round); break;
+    default: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 4>), dim3(grid), dim3(256), 0, st, P, W, round); break;
+  }
+}
+static void launch_march(int grid, hipStream_t st, const NgpParams& P, const NgpWork& W, int round) {
+  switch (march_probe()) {
+    case 1: hipLaunchKernelGGL(ngp_march_kernel<1>, dim3(grid), dim3(256), 0, st, P, W, round); break;
+    case 2: hipLaunchKernelGGL(ngp_march_kernel<2>, dim3(grid), dim3(256), 0, st, P, W, round); break;
+    case 8: hipLaunchKernelGGL(ngp_march_kernel<8>, dim3(grid), dim3(256), 0, st, P, W, round); break;
+    default: hipLaunchKernelGGL(ngp_march_kernel<4>, dim3(grid), dim3(256), 0, st, P, W, round); break;
+  }
+}
+
 static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
                        uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
                        float* cam_out = nullptr, uint8_t* out_u8 = nullptr, uint8_t* out_nz = nullptr,
@@ -1600,7 +1670,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     if (!counters_clean)
       PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), st[w]));
     if (fuse_init && n_rounds > 0)  // ray generation + compaction + the first march
-      hipLaunchKernelGGL(ngp_compact_march_kernel<true>, dim3(2 * wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
+      launch_compact_march<true>(2 * wide, st[w], Pp[w], ctx->work[w], 0);
     else
       hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
   }
@@ -1608,7 +1678,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   for (int r = 0; r < n_rounds; ++r) {
     if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
       for (int w = 0; w < n_pipe; ++w)
-        hipLaunchKernelGGL(ngp_march_kernel, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        launch_march(wide, st[w], Pp[w], ctx->work[w], r);
     // the round's shade kernel (gathers + MLPs + compositing) is the one the timing events bracket (bench.py's roofline)
     for (int w = 0; w < n_pipe; ++w) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1637,7 +1707,7 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
     }
     for (int w = 0; w < n_pipe; ++w) {
       if (fuse_cm && r + 1 < n_rounds)  // compaction of round r + march of round r + 1 in one launch
-        hipLaunchKernelGGL(ngp_compact_march_kernel<false>, dim3(wide), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
+        launch_compact_march<false>(wide, st[w], Pp[w], ctx->work[w], r);
       else
         hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
     }
