@@ -441,8 +441,13 @@ thread_local int g_conv_layer = 0;  // index of the pyramid layer being launched
 
 // Split-K factor: only the smallest maps (conv5: 12 tiles per image pair) leave most of the 256 CUs
 // without a workgroup; measured on the 60x80 layers (160 workgroups) every split loses to no split.
-int choose_splits(int wgs, int n_chunks, bool upcat) {
+int choose_splits(int wgs, int n_chunks, bool upcat, int own = 1 << 30) {
   // (the decoder's 64-channel tiles run one workgroup per CU at 160 workgroups: split those too)
+  // A pass whose OWN layer has at most 64 workgroups (512 -> 512 at 57x57: the 1/16 level of a 921x921 reference
+  // render, 64 eight-wave workgroups walking 16 chunks each) is split in two even when a twin pass brings the count
+  // to 128: with real assets the twin is the smaller query pass, which is elsewhere in its pyramid by then
+  // (921x921 || 640x480 pair pass 1.325 -> 1.258 ms, profiles/r04_experiments.md #16; the benchmark's layers: unchanged)
+  if (!upcat && wgs >= 128 && own <= 64 && n_chunks >= 8) return 2;
   if (wgs >= (upcat ? 256 : 128)) return 1;
   int splits = (256 + wgs - 1) / wgs;
   splits = std::min(splits, std::max(1, n_chunks / 4));
@@ -484,7 +489,7 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   const int th = cfg_th(cfg);
   P.tiles = n_img * ((H + th - 1) / th) * ((W + 15) / 16);
   P.nb = cout / cfg_bnc(cfg);
-  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(g_conv_peers * P.tiles * P.nb, cin / 32, upcat)) : 1;
+  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(g_conv_peers * P.tiles * P.nb, cin / 32, upcat, P.tiles * P.nb)) : 1;
   if (kV2Cfgs[cfg].KS == 2) {  // every split must hold an even number of chunks: round the factor down to a divisor
     while (P.splits > 1 && (cin / 32) % (2 * P.splits) != 0) --P.splits;
   }
