@@ -79,7 +79,7 @@ class StageTimer:
         return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.events.items()}
 
 
-def cpu_baseline(assets, frames, first, ref_id, budget_s=110.0, max_frames=20, min_frames=5):
+def cpu_baseline(assets, frames, first, ref_id, budget_s=70.0, max_frames=20, min_frames=5):
     """The CPU oracle ("port" of the reference PyTorch-CPU path) on a bounded sample of the same
     workload, on the GPU box's host cores: whole frames of `oracle.frame_oracle.track_frame` at FULL size - depth
     render (mask) + RGB render (reference) + UNet x2 + sparse sampling + LM - frame `first + k` tracked from the
@@ -231,7 +231,7 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
 
     for key, fn in (("value_ycb_refshape", lambda: ycb_policy_extra(dev, refshape=True)),
                     ("value_r9_phone", lambda: r9_refshape_extra(dev, REF_CAMERA_PHONE, "1920x1440 (4:3 phone frames)")),
-                    ("value_r9_12mp", lambda: r9_refshape_extra(dev, REF_CAMERA_12MP, "4032x3024 (12-MP stills)", n=40))):
+                    ("value_r9_12mp", lambda: r9_refshape_extra(dev, REF_CAMERA_12MP, "4032x3024 (12-MP stills)", n=34))):
         try:
             out[key] = fn()
         except Exception as e:  # (reported, never fatal: the headline line must come out)
@@ -297,7 +297,7 @@ def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
             "reference_render_wh": [int(x) for x in tr._reference_camera().size], "what": what}
 
 
-def r9_refshape_extra(dev, ref_camera, label, n=50, lead=10):
+def r9_refshape_extra(dev, ref_camera, label, n=44, lead=10):
     """The r9 policy (configs[1]) with SfM camera 1 shaped as the reference's own assets have it instead of the
     "2 x query" stand-in: the reference render is `cameras[1] x 0.5` (pixloc_tracker_r9.py:145-152), a different
     camera than the 640x480 query, so a frame needs two renders of different views and two UNet passes of

