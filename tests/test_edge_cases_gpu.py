@@ -36,6 +36,15 @@ def test_entry_points_reject_bad_arguments(device):
     assert L.pxt_unet_create(None, 0, C.byref(C.c_void_p())) == -1
     assert L.pxt_ngp_render(None, None, None, None, None) == -1
     assert L.pxt_depth_mask(None, 4, 4, 1, 5, None, None, None) == -1
+    # round-4 entry points: a render with no output for an image its mode produces, a mask from no plane, an LM launch
+    # whose camera request names neither a slot nor a record
+    assert L.pxt_depth_mask_plane(None, 4, 4, 1, 5, None, None, None) == -1
+    assert L.pxt_ngp_render_frame(None, None, 0, 0, None, None, None) == -1
+    assert L.pxt_ngp_camera_slot(None) is None
+    assert L.pxt_unet_activation_stats(None, 64, 64, None, None, None) == -1
+    cam = _lib.LmCamera()
+    assert L.pxt_lm_refine_cam(p3d.data_ptr(), None, 16, lv, 1, T0, C.byref(conf), out.data_ptr(), None, ws.data_ptr(),
+                               C.byref(cam), None) == -1
     with pytest.raises(_lib.PxtError):
         _lib.check(-1, "probe")
 

@@ -187,3 +187,37 @@ def test_render_sequence_with_scratch_growth_and_pipeline_changes(device, snap):
     assert torch.equal(c, small[0]) and torch.equal(d, small[1])
     a, b = tb.render_both_device(*big)
     assert torch.equal(a, ref_rgba) and torch.equal(b, ref_depth)
+
+
+def test_shade_colour_space_flag_on_the_device(device, snap):
+    """`linear_colors` on the device: with ONE pass per pixel the Shade image of a snapshot trained on LDR images is
+    instant-ngp's srgb_to_linear of the image of the same snapshot flagged as trained in linear colours (the conversion
+    acts on the finished ray, before the spp mean); alpha and the Depth image do not depend on the flag; both agree with
+    the oracle's."""
+    import dataclasses
+    import math
+
+    W, H = 96, 72
+    cam = ngp_camera((0.9, 0.5, 0.3), 1.3)
+    imgs = {}
+    for flag in (False, True):
+        s2 = dataclasses.replace(snap, linear_colors=flag, k1=0.0)  # (other tests of this module set a lens on the shared snapshot)
+        tb = make_testbed(s2, device)
+        tb._cam_ngp = cam
+        tb.fov = math.degrees(2 * math.atan(W / (2 * 1.2 * W)))
+        tb.render_mode = RenderMode.Shade
+        shade = tb.render_device(W, H, 1, True).cpu().numpy()
+        tb.render_mode = RenderMode.Depth
+        depth = tb.render_device(W, H, 1, True).cpu().numpy()
+        imgs[flag] = (shade, depth)
+        m = oracle_model(s2)
+        v = NO.View(cam=cam, focal=1.2 * W, width=W, height=H, spp=1, aabb_min=tuple(PREMIER_PROTEIN_AABB[0]),
+                    aabb_max=tuple(PREMIER_PROTEIN_AABB[1]), mode=0)
+        ref = NO.render(m, v)
+        assert np.abs(shade - ref).max() < 1e-2 and np.abs(shade - ref).mean() < 5e-4
+    lin, conv = imgs[True][0], imgs[False][0]
+    assert lin[..., 3].max() > 0.9 and np.array_equal(lin[..., 3], conv[..., 3])
+    assert np.array_equal(imgs[True][1], imgs[False][1])  # Depth: never converted
+    want = NO.srgb_to_linear(lin[..., :3])
+    assert np.abs(conv[..., :3] - want).max() < 2e-6 + 1e-5 * want.max()
+    assert float(np.abs(conv[..., :3] - lin[..., :3]).max()) > 0.05  # (and the flag does something)
