@@ -864,41 +864,6 @@ extern "C" int64_t pxt_unet_workspace_bytes(const pxt_unet* ctx, int32_t H, int3
   return pxt_unet_workspace_bytes_batch(ctx, 1, H, W);
 }
 
-// TIMING EXPERIMENT ONLY (PXT_EXP_DEEP_NODEPS=1; results are garbage): the layers conv4_1 .. conv5_3 and dec0 of a pass
-// are launched on four extra streams with NO dependencies between them - the ceiling of what removing every launch
-// boundary of the deep part (a persistent chained launch) could gain, measured instead of argued
-// (scripts/refshape_plans.py, profiles/r04_experiments.md #17).
-static hipStream_t exp_nodeps_stream(int li, hipStream_t s, bool join) {
-  static const bool on = [] { const char* e = getenv("PXT_EXP_DEEP_NODEPS"); return e && atoi(e) != 0; }();
-  if (!on) return s;
-  static thread_local hipStream_t st[2][4] = {{nullptr}};
-  static thread_local hipEvent_t ev[2][4];
-  static thread_local int which = 0;  // (two passes of a pair alternate between two sets)
-  if (join) {
-    for (int i = 0; i < 4; ++i)
-      if (st[which][i]) { (void)hipEventRecord(ev[which][i], st[which][i]); (void)hipStreamWaitEvent(s, ev[which][i], 0); }
-    which ^= 1;
-    return s;
-  }
-  if (li < 7 || li > 13) return s;
-  const int k = li & 3;
-  if (!st[which][k]) {
-    (void)hipStreamCreateWithFlags(&st[which][k], hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&ev[which][k], hipEventDisableTiming);
-  }
-  if (li == 7) {  // the deep part starts when the pass reaches it
-    hipEvent_t e0;
-    (void)hipEventCreateWithFlags(&e0, hipEventDisableTiming);
-    (void)hipEventRecord(e0, s);
-    for (int i = 0; i < 4; ++i) {
-      if (!st[which][i]) { (void)hipStreamCreateWithFlags(&st[which][i], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ev[which][i], hipEventDisableTiming); }
-      (void)hipStreamWaitEvent(st[which][i], e0, 0);
-    }
-    (void)hipEventDestroy(e0);
-  }
-  return st[which][k];
-}
-
 static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* images,
                         const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H,
                         int32_t W, float* const* out_maps, const int32_t out_cstride[3],
@@ -1020,8 +985,8 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       half_t* pool_to = (last && b < 4) ? buf(P.enc_pool[b + 1]) : nullptr;
       g_conv_layer = li;
       const bool with_first = li == 1 && fuse_first;
-      int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o,
-                           exp_nodeps_stream(li, s, false), 1, with_first ? nullptr : (float*)(ws + P.splitk), B, nullptr, pool_to,
+      int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
+                           1, with_first ? nullptr : (float*)(ws + P.splitk), B, nullptr, pool_to,
                            pool_to ? &pooled_by_conv : nullptr, with_first ? 2 : 0, 0, nullptr, with_first ? &ff : nullptr,
                            P.splitk_bytes);
       if (rc != PXT_OK) return rc;
@@ -1060,9 +1025,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       head0_fused = true;
     }
     g_conv_layer = 13 + d;
-    if (d == 1) (void)exp_nodeps_stream(0, s, true);  // (timing experiment: the deep part's streams rejoin here)
-    int rc = launch_conv(L.cin, L.cout, ctx->conv_packed[13 + d], L.b, skip[sb], P.dh[d], P.dw[d], o,
-                         exp_nodeps_stream(13 + d, s, false), 1,
+    int rc = launch_conv(L.cin, L.cout, ctx->conv_packed[13 + d], L.b, skip[sb], P.dh[d], P.dw[d], o, s, 1,
                          fuse_head ? nullptr : (float*)(ws + P.splitk), B, &up, nullptr, nullptr, 0, 0,
                          fuse_head ? &fh : nullptr, nullptr, P.splitk_bytes);
     if (rc != PXT_OK) return rc;
