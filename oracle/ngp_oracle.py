@@ -454,6 +454,11 @@ def close_pool():
         pool.join()
 
 
+import atexit
+
+atexit.register(close_pool)  # (a pool left to the interpreter's shutdown dies noisily in Pool.__del__)
+
+
 def render_parallel(m: NgpModel, v: View, procs: int, return_stats: bool = False, rows_per_job: int = 0):
     """render() with the image rows dealt to ``procs`` forked worker processes.  The workers are forked once per
     (model, procs) - they see the model copy-on-write - and kept for later calls (a frame needs two renders; forking
