@@ -151,6 +151,90 @@ def load_weights(path) -> Dict[str, torch.Tensor]:
     return blob
 
 
+# ---------------------------------------------------------------------------------------------
+# fp16 range of a NEW checkpoint.  pixloc runs this network in fp32; the kernels here store activations as fp16
+# (max 65504).  A ReLU network is positively homogeneous layer by layer - ReLU, max-pool, bilinear up-sampling and
+# concatenation commute with a positive scale - so the activations of layer l can be stored divided by any c_l > 0 if
+# the layer's filters and bias are scaled by (scale of its input) / c_l and every consumer multiplies its input channels
+# back.  With powers of two that is EXACT in fp32 and in the fp16 weights: the network computes the same function, its
+# intermediate values sit where fp16 can hold them.  `auto_rescale_for_fp16` finds the c_l with UNet.activation_stats.
+_BLOCK_LAST = [1, 3, 6, 9, 12]  # index of each encoder block's last convolution (the skip / head sources)
+
+
+def rescale_unet_weights(w: Dict[str, torch.Tensor], c: List[float]) -> Dict[str, torch.Tensor]:
+    """The same network with layer l's activations stored divided by c[l] (17 positive factors, powers of two for
+    exactness; c = 1 everywhere returns equal tensors).  Heads absorb the factor of their source layer, so the
+    outputs are unchanged."""
+    names = conv_layer_names()
+    assert len(c) == len(names) == 17 and all(x > 0 for x in c)
+    out = dict(w)
+    for l in range(13):  # encoder: input = the previous layer's output (pooled or not), the image for layer 0
+        c_in = 1.0 if l == 0 else c[l - 1]
+        out[f"{names[l]}.weight"] = w[f"{names[l]}.weight"] * (c_in / c[l])
+        out[f"{names[l]}.bias"] = w[f"{names[l]}.bias"] / c[l]
+    prev_l, prev_ch = 12, SKIP_DIMS[-1]
+    for d in range(len(DECODER)):  # decoder d: input = concat[upsampled previous (c_prev), skip of block 3 - d (c_skip)]
+        l = 13 + d
+        skip_l = _BLOCK_LAST[3 - d]
+        W = w[f"dec{d}.weight"].clone()
+        W[:, :prev_ch] *= c[prev_l]
+        W[:, prev_ch:] *= c[skip_l]
+        out[f"dec{d}.weight"] = W
+        # BatchNorm after the convolution: y = (conv - mean) * gamma / sigma + beta; y / c = gamma / c, beta / c
+        out[f"dec{d}.bn_weight"] = w[f"dec{d}.bn_weight"] / c[l]
+        out[f"dec{d}.bn_bias"] = w[f"dec{d}.bn_bias"] / c[l]
+        prev_l, prev_ch = l, DECODER[d]
+    for k, src in enumerate((16, 14, 12)):  # heads: fine <- dec3, mid <- dec1, coarse <- enc4
+        out[f"adapt{k}.weight"] = w[f"adapt{k}.weight"] * c[src]
+        out[f"unc{k}.weight"] = w[f"unc{k}.weight"] * c[src]
+    return out
+
+
+def auto_rescale_for_fp16(w: Dict[str, torch.Tensor], device, images, target: float = 64.0, limit: float = 8192.0,
+                          max_rounds: int = 64):
+    """Power-of-two storage factors c[l] under which every observed layer of every calibration image (HWC 0..255
+    device tensors) stays finite and below `limit`, found by repeated UNet.activation_stats passes: the first layer that
+    overflows or exceeds the limit is scaled down (to ~`target` when its maximum is finite, by 256 when it is not) and
+    the network rebuilt.  Returns (rescaled weights, c).  The two layers that are never written to memory are not
+    observed: the first one keeps c = 1 (its input is the normalised image), the last decoder layer is scaled when the
+    outputs are non-finite although every observed layer is in range."""
+    import math
+
+    c = [1.0] * 17
+    for _ in range(max_rounds):
+        net = UNet(rescale_unet_weights(w, c), device)
+        worst = None
+        for img in images:
+            for l, s in enumerate(net.activation_stats(img)):
+                if s is None:
+                    continue
+                mx, bad = s
+                if bad > 0 or mx > limit:
+                    if worst is None or l < worst[0]:
+                        worst = (l, mx, bad)
+        if worst is None:
+            outs = [net.forward_packed(img, None, False) for img in images]
+            if not all(bool(torch.isfinite(o).all()) for per in outs for o in per):
+                # every observed layer is in range: it is the last decoder layer, whose fp16 output only ever exists in
+                # the fused fine head's registers - it follows its input's factor, then goes up in steps of 16
+                c[16] = max(c[16] * 16.0, c[15])
+                if c[16] > 2.0 ** 40:
+                    raise _lib.PxtError("auto_rescale_for_fp16: outputs stay non-finite although every observed layer is "
+                                        "in range")
+                continue
+            fixed = rescale_unet_weights(w, c)
+            too_big = [k for k, v in fixed.items() if k.endswith(".weight") and v.dim() == 4 and float(v.abs().max()) > 6.0e4]
+            if too_big:  # (the compensating factors live in fp16 weights: a cumulative factor beyond ~2^17 does not fit)
+                raise _lib.PxtError(f"auto_rescale_for_fp16: the compensated weights of {too_big} leave fp16's range "
+                                    f"(factors {c}); this checkpoint needs wider storage than fp16")
+            return fixed, c
+        l, mx, bad = worst
+        f = 256.0 if bad > 0 else 2.0 ** math.ceil(math.log2(mx / target))
+        for j in range(l, 17):  # every later layer follows (its compensated weights then stay what they were: a network
+            c[j] *= f           # whose magnitudes grow keeps growing, and no compensating factor piles up in fp16 weights)
+    raise _lib.PxtError(f"auto_rescale_for_fp16: no stable scaling after {max_rounds} rounds (factors {c})")
+
+
 def _align16(n: int) -> int:
     return (n + 15) // 16 * 16
 

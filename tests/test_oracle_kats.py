@@ -265,3 +265,20 @@ def test_render_box_with_swapped_corners_warns_once(monkeypatch):
     monkeypatch.setenv("PXT_STRICT_AABB", "1")
     tb3 = ingp_utils.initialize_ingp("x", box)
     assert tb3.render_aabb.min == [0.1, 0.9, 0.2] and tb3.render_aabb.max == [0.6, 0.3, 0.8]
+
+
+def test_kat6_power_of_two_rescale_leaves_the_network_unchanged():
+    """pixtrack_amd.unet.rescale_unet_weights: storing layer l's activations divided by a power of two c[l] (filters, bias /
+    BatchNorm and every consumer's input channels compensated) is the SAME function - checked bit for bit in fp32 on the
+    oracle, skip connections, up-sampling and all three heads included."""
+    from pixtrack_amd.unet import make_synthetic_unet_weights, rescale_unet_weights
+
+    w = make_synthetic_unet_weights(7, bn_trivial=False)
+    img = torch.rand(3, 75, 100, generator=torch.Generator().manual_seed(2))
+    f0, c0 = UO.unet_forward(w, img)
+    c = [2.0 ** ((i * 7) % 5 - 2) for i in range(17)]  # 1/4 .. 4, different for every layer
+    f1, c1 = UO.unet_forward(rescale_unet_weights(w, c), img)
+    for a, b in zip(f0 + c0, f1 + c1):
+        assert torch.equal(a, b)
+    ones = rescale_unet_weights(w, [1.0] * 17)
+    assert all(torch.equal(ones[k], w[k]) for k in w)

@@ -2,6 +2,7 @@
 against the fp32 PyTorch-CPU oracle.  Tolerances are those of fp16 storage (11-bit
 mantissa, the same mantissa as the TF32 convs the reference runs on Ampere)."""
 import ctypes as C
+import math
 
 import numpy as np
 import pytest
@@ -250,3 +251,33 @@ def test_activation_stats_flag_an_fp16_overflow(device):
     st2 = UNet(big, device).activation_stats(img)
     bad = [l for l, s in enumerate(st2) if s is not None and s[1] > 0]
     assert bad and min(bad) >= 2, st2  # the first layers still fit, the growth of 12x per layer overflows further down
+
+
+def test_auto_rescale_brings_an_overflowing_checkpoint_into_fp16_range(device):
+    """A checkpoint whose activations overflow fp16 storage (every 3x3 filter of the synthetic weights x 3.5: the deeper
+    layers reach 1e6 in fp32) gives non-finite maps as it is; after auto_rescale_for_fp16 - exact power-of-two storage
+    factors found with activation_stats - the HIP pyramid matches the fp32 oracle of the ORIGINAL overflowing weights."""
+    from pixtrack_amd.unet import auto_rescale_for_fp16
+
+    w = make_synthetic_unet_weights(7)
+    big = {k: (v * 3.5 if (v.dim() == 4 and v.shape[-1] == 3) else v) for k, v in w.items()}
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 255, size=(96, 128, 3)).astype(np.float32)
+    img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(img, 2, 0)) / 4
+    src = torch.from_numpy(img).to(device)
+    raw = UNet(big, device).forward_packed(src, None, normalize=True)
+    assert not all(bool(torch.isfinite(o).all()) for o in raw)
+    fixed, c = auto_rescale_for_fp16(big, device, [src])
+    assert max(c) >= 256.0 and all(math.log2(x) == int(math.log2(x)) for x in c)
+    outs = UNet(fixed, device).forward_packed(src, None, normalize=True)
+    feats, confs = UO.unet_forward(big, torch.from_numpy(img).permute(2, 0, 1) / 255.0)
+    for k, (o, ch) in enumerate(zip(outs, OUTPUT_DIMS)):
+        o = o.cpu()
+        assert torch.isfinite(o).all()
+        f_ref = feats[k].permute(1, 2, 0)
+        f_ref = f_ref / f_ref.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        cos = F.cosine_similarity(o[..., :ch], f_ref, dim=-1)
+        assert cos.min().item() > 0.9995, (k, cos.min().item())
+        # the confidences of this artificial network are saturated (logits of +-1e5: sigmoid is 0 or 1, and fp16 noise
+        # flips the few pixels whose logit happens to be near zero): equal on all but a sliver of the map
+        assert ((o[..., ch] - confs[k][0]).abs() > 5e-3).float().mean().item() < 0.01
