@@ -712,7 +712,9 @@ def main():
         "stage_ms_per_frame": {k: round(v[0] / max(n_diag // 2, 1), 4) for k, v in stage.items()},
         "frame_ms": {"p50": round(float(np.percentile(frame_ms, 50)), 4), "p90": round(float(np.percentile(frame_ms, 90)), 4),
                      "max": round(float(frame_ms.max()), 4), "argmax": int(frame_ms.argmax())},
-        "stage_ms_note": f"HIP-event times of a separate untimed pass over the next {n_diag // 2} frames",
+        "stage_ms_note": (f"HIP-event times of a separate untimed pass over the next {n_diag // 2} frames; `unet` ends when the "
+                          "reference pass ends on the caller's stream - the query pass is joined behind the sparse sampling "
+                          "(deferred join), so its last ~20-40 us are booked to `sample` / `lm`"),
         "roofline": roofline,
         **report,
     }

@@ -212,6 +212,15 @@ int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, const int32_
                           const uint8_t* const* masks, const int32_t H[2], const int32_t W[2],
                           float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
                           void* workspace, void* stream);
+/* Deferred join of the pair entry (round 4): with pxt_unet_set_defer_join(ctx, 1), pxt_unet_forward_pair (and the
+ * two-image pxt_unet_forward_batch that runs through it) returns with image 0's maps complete in the caller's stream
+ * order and image 1's pass still running on the library's side stream; the caller may enqueue work that needs image 0
+ * only - the tracker's sparse sampling of the REFERENCE maps (pixloc_pose_refiners.py:327-368) - and must call
+ * pxt_unet_pair_join(ctx, stream) before anything reads image 1's maps (it makes `stream` wait for that pass; a no-op
+ * when nothing is pending; the next forward call on the context joins by itself). */
+int pxt_unet_set_defer_join(pxt_unet* ctx, int32_t on);
+int pxt_unet_pair_join(pxt_unet* ctx, void* stream);
+
 
 /* One 3x3 convolution (pad 1) of the pyramid as a stand-alone call, for layer-by-layer
  * parity tests against torch.nn.functional.conv2d (SURVEY KAT-6) and for profiling:

@@ -135,6 +135,8 @@ PROTOTYPES = {
         C.c_int,
         [_VP, _VP, _I32, _VP, _I32, _I32, C.POINTER(_VP), C.POINTER(_I32), _I32, _VP, _VP],
     ),
+    "pxt_unet_set_defer_join": (C.c_int, [_VP, _I32]),
+    "pxt_unet_pair_join": (C.c_int, [_VP, _VP]),
     "pxt_unet_activation_stats": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
     "pxt_unet_workspace_bytes_batch": (_I64, [_VP, _I32, _I32, _I32]),
     "pxt_unet_forward_batch": (

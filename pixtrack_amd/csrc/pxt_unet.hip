@@ -390,6 +390,8 @@ struct pxt_unet {
   } sides[2];
   hipStream_t pass2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool defer_join = false;    // pxt_unet_set_defer_join: the pair entry leaves the second pass un-joined ...
+  bool join_pending = false;  // ... until pxt_unet_pair_join (or the next forward call) makes the caller's stream wait for it
   pxt::UnetLayer conv[pxt::kNumConv];
   pxt::UnetLayer head[pxt::kNumHeads];
 };
@@ -1059,6 +1061,7 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
                                       const int32_t* normalize, void* workspace, void* stream) {
   if (!ctx || !images || !image_is_u8 || !out_maps || !out_cstride || !normalize || !workspace) return PXT_E_ARG;
   static const int n_streams = [] { const char* e = getenv("PXT_UNET_STREAMS"); return e ? atoi(e) : 2; }();
+  if (ctx->join_pending) { PXT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0)); ctx->join_pending = false; }
   if (n_images != 2 || n_streams < 2)
     return forward_pass(ctx, n_images, images, image_is_u8, masks, H, W, out_maps, out_cstride, normalize, workspace,
                         stream, ctx->sides[0]);
@@ -1091,6 +1094,7 @@ extern "C" int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, c
     PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
   hipStream_t s = (hipStream_t)stream;
+  if (ctx->join_pending) { PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0)); ctx->join_pending = false; }
   PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s));  // the second pass starts after the caller's earlier work
   PXT_HIP_CHECK(hipStreamWaitEvent(ctx->pass2, ctx->ev_fork, 0));
   const uint8_t* const no_mask[1] = {nullptr};
@@ -1103,7 +1107,26 @@ extern "C" int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, c
     if (rc != PXT_OK) return rc;
   }
   PXT_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->pass2));
+  if (ctx->defer_join) {  // image 0's maps are complete in the caller's stream order; image 1's only after pxt_unet_pair_join
+    ctx->join_pending = true;
+    return PXT_OK;
+  }
   PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  return PXT_OK;
+}
+
+extern "C" int pxt_unet_set_defer_join(pxt_unet* ctx, int32_t on) {
+  if (!ctx) return PXT_E_ARG;
+  ctx->defer_join = on != 0;
+  return PXT_OK;
+}
+
+extern "C" int pxt_unet_pair_join(pxt_unet* ctx, void* stream) {
+  if (!ctx) return PXT_E_ARG;
+  if (ctx->join_pending) {
+    PXT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0));
+    ctx->join_pending = false;
+  }
   return PXT_OK;
 }
 

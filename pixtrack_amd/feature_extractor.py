@@ -27,6 +27,13 @@ class PixTrackFeatureExtractor:
         self.model = model
         self._staged = None   # (image, scale_image, mask, normalize) announced by stage()
         self._ready = None    # (image, scale_image, mask, normalize, maps, scales) computed alongside
+        # The frame's two passes run side by side; the announced (query) pass may still be running when the reference
+        # maps are handed back - the refiner samples the reference points from them meanwhile - and is joined when ITS
+        # maps are asked for (round 4; PXT_UNET_DEFER_JOIN=0: join inside the call, as before).
+        import os
+
+        self.defer_join = os.environ.get("PXT_UNET_DEFER_JOIN", "1") != "0" and hasattr(model, "set_defer_join")
+        self._join_pending = False
         self.last_input_wh = None  # (w, h) the UNet ran the last extract_packed image at (after the resize rule)
         assert hasattr(self.model, "scales")
         assert self.conf.resize_by in ["max", "max_force"], self.conf.resize_by
@@ -63,11 +70,18 @@ class PixTrackFeatureExtractor:
         extract_packed then runs both images through the UNet side by side
         (pxt_unet_forward_batch, or pxt_unet_forward_pair when their sizes differ) and keeps the staged result for the announced call.  Purely
         a scheduling hint: results are those of separate calls up to fp32 summation order."""
+        self._join()
         self._staged = (image, scale_image, mask, normalize)
         self._ready = None
 
     def unstage(self) -> None:
+        self._join()
         self._staged = self._ready = None
+
+    def _join(self) -> None:
+        if self._join_pending:
+            self.model.join()
+            self._join_pending = False
 
     def _prepare(self, image, scale_image, mask):
         """-> (HWC image on the device at the size the UNet runs it, mask still to apply, scale_resize).  An image above
@@ -92,6 +106,7 @@ class PixTrackFeatureExtractor:
         if self._ready is not None:
             r = self._ready
             self._ready = None
+            self._join()  # (the announced pass may have been left running beside the caller's work)
             if r[0] is image and r[1] == scale_image and r[2] is mask and r[3] == normalize:
                 return r[4], r[5]
         a_img, a_mask, a_sr = self._prepare(image, scale_image, mask)
@@ -103,9 +118,17 @@ class PixTrackFeatureExtractor:
             if st_image is not image:
                 # equal sizes: one batched call; two sizes: the pair entry - both images side by side either way
                 b_img, b_mask, b_sr = self._prepare(st_image, st_scale, st_mask)
-                both = self.model.forward_packed_batch([(a_img, a_mask, normalize), (b_img, b_mask, st_norm)])
+                if self.defer_join:
+                    self.model.set_defer_join(True)
+                try:
+                    both = self.model.forward_packed_batch([(a_img, a_mask, normalize), (b_img, b_mask, st_norm)])
+                finally:
+                    if self.defer_join:
+                        self.model.set_defer_join(False)
+                        self._join_pending = True
+                # (b_img / b_mask ride along: the side stream may still be reading them until the join)
                 self._ready = (st_image, st_scale, st_mask, st_norm, both[1],
-                               [(b_sr[0] / s, b_sr[1] / s) for s in self.model.scales])
+                               [(b_sr[0] / s, b_sr[1] / s) for s in self.model.scales], b_img, b_mask)
                 return both[0], scales
         return self.model.forward_packed(a_img, a_mask, normalize=normalize), scales
 

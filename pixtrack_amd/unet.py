@@ -368,6 +368,16 @@ class UNet:
                                [bool(it[2]) for it in items], [o for per in outs for o in per], self._ws)
         return outs
 
+    def set_defer_join(self, on: bool) -> None:
+        """With True, a two-image call returns with the FIRST image's maps complete in the current stream's order and
+        the second image's pass still running on the library's side stream: the caller may enqueue work on the first
+        image's maps and must call join() before anything reads the second image's (pxt_unet_set_defer_join)."""
+        _lib.check(_lib.lib().pxt_unet_set_defer_join(self._ctx, int(bool(on))), "pxt_unet_set_defer_join")
+
+    def join(self) -> None:
+        """Makes the current stream wait for a second pass left running by a deferred-join call (no-op otherwise)."""
+        _lib.check(_lib.lib().pxt_unet_pair_join(self._ctx, _lib.stream_ptr(self.device)), "pxt_unet_pair_join")
+
     def activation_stats(self, image: torch.Tensor, mask: Optional[torch.Tensor] = None):
         """Range check of the fp16 activations for one image (HWC 0..255 on the device): runs a single-image pass and
         returns [(largest |activation|, number of non-finite values)] for the 17 convolutions (None for the two layers

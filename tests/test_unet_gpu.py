@@ -281,3 +281,38 @@ def test_auto_rescale_brings_an_overflowing_checkpoint_into_fp16_range(device):
         # the confidences of this artificial network are saturated (logits of +-1e5: sigmoid is 0 or 1, and fp16 noise
         # flips the few pixels whose logit happens to be near zero): equal on all but a sliver of the map
         assert ((o[..., ch] - confs[k][0]).abs() > 5e-3).float().mean().item() < 0.01
+
+
+def test_deferred_join_of_the_pair_pass(device):
+    """pxt_unet_set_defer_join / pxt_unet_pair_join: the pair call returns with the first image's maps complete in stream
+    order and the second pass still running; after join() both equal what the joined call produces, bit for bit - and
+    the extractor's staged path (reference first, announced query second) uses it and joins when the query's maps are
+    asked for."""
+    from pixtrack_amd.feature_extractor import PixTrackFeatureExtractor
+
+    net = UNet(make_synthetic_unet_weights(7), device)
+    g = torch.Generator().manual_seed(9)
+    a = (torch.rand(240, 320, 3, generator=g) * 255).to(torch.uint8).to(device)
+    b = (torch.rand(192, 256, 3, generator=g) * 255).to(device)
+    m = (torch.rand(192, 256, generator=g) > 0.3).to(torch.uint8).to(device)
+    want = net.forward_packed_batch([(a, None, False), (b, m, True)])
+    want = [[t.clone() for t in per] for per in want]
+    net.set_defer_join(True)
+    got = net.forward_packed_batch([(a, None, False), (b, m, True)])
+    net.set_defer_join(False)
+    first = [t.clone() for t in got[0]]  # (current-stream work on image 0's maps: legal before the join)
+    net.join()
+    torch.cuda.synchronize()
+    for x, y in zip(first + got[1], want[0] + want[1]):
+        assert torch.equal(x, y)
+    net.join()  # nothing pending: a no-op
+    ex = PixTrackFeatureExtractor(net, device)
+    assert ex.defer_join
+    ex.stage(b, 1, m, True)
+    ref_maps, _ = ex.extract_packed(a, 1, None, False)
+    assert ex._join_pending
+    q_maps, _ = ex.extract_packed(b, 1, m, True)
+    assert not ex._join_pending
+    torch.cuda.synchronize()
+    for x, y in zip(list(ref_maps) + list(q_maps), want[0] + want[1]):
+        assert torch.equal(x, y)
