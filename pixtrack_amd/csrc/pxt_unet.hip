@@ -485,6 +485,13 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
     }
     else if (cout % 64 == 0) cfg = 2;
     else cfg = 6;
+    // Round 4 experiment (profiles/r04_experiments.md #18; PXT_CONV_POOL14=1): the pooled layers (last convolution of
+    // encoder blocks 1-3) on the third kernel's 8-row x 128-channel tile.  With a device synchronisation after every pair
+    // pass it is worth 4 % of the pass (0.826 against 0.860 ms, five interleaved runs) - and NOTHING in the frame loop,
+    // where the host runs ahead of the device (bench.py: 680 / 680 / 682 against 682 / 682 / 683 frames/s, UNet stage 0.677
+    // against 0.675 ms): what it shortens is the pass's start-up while the host is still enqueueing.  Off by default.
+    static const bool pool14 = [] { const char* e = getenv("PXT_CONV_POOL14"); return e ? atoi(e) != 0 : false; }();
+    if (pool14 && wants_pool && cout % 128 == 0) cfg = 14;
   }
   if (cfg_valid(cfg) && kV2Cfgs[cfg].KS == 2 && (upcat || (cin / 32) % 2 != 0)) cfg = cfg == 18 ? 15 : 11;
   P.cfg = cfg;
