@@ -318,3 +318,32 @@ def test_forced_timeout_then_workspace_reuse(device):
         assert timed_out >= 1, "a one-poll spin bound did not time out on a 128-workgroup grid"
         again = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, good.native_conf(), ws).result()
         assert torch.equal(again.T.as12(), fresh.T.as12()) and again.iters == fresh.iters
+
+
+@pytest.mark.parametrize("npts", [700, 2341, 3000, 5000])
+def test_one_round_levels_equal_the_general_path(device, npts):
+    """Round 4: a level whose points fit the grid's lane groups keeps them in registers (32-, 16- or 8-lane groups by
+    point count: 700 / 2341 / 3000 / 5000 points at 128 workgroups take the 32-, 16-, 16- and 8-lane variants on the
+    C = 128 levels); `lm_path = 2` forces the general several-rounds path.  Same sums in another association: the two
+    must agree to fp32 reduction noise, far inside the 1e-3 parity bar, and both must be repeatable bit for bit."""
+    sc = make_lm_scene(seed=1008, width=320, height=240, n_points=npts, sigma_px=2.0)
+    lam = lambdas(CONSTS)
+    packs = []
+    for level in reversed(range(3)):
+        fmap, fref, Cc, cam = pack_level(sc, level, device, sc.camera)
+        packs.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    res = {}
+    for path in (0, 2):
+        opt = PixTrackOptimizer(dict(num_iters=150, pad=1, lm_path=path))
+        a = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws).result()
+        b = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws).result()
+        assert not a.failed and torch.equal(a.T.as12(), b.T.as12())
+        res[path] = a
+    # (entry-wise: acos of a float32 rotation's trace resolves no angle below ~4e-4 rad)
+    dR = float((res[0].T.R - res[2].T.R).abs().max())
+    assert dR < 1e-5 and float((res[0].T.t - res[2].T.t).norm()) < 1e-5, (dR, res[0].iters, res[2].iters)
+    assert res[0].iters == res[2].iters
+    assert res[0].costs[0][0] == pytest.approx(res[2].costs[0][0], rel=1e-5)
+    assert O.rotation_angle_rad(res[0].T.R.double(), torch.from_numpy(sc.R_gt)) < 5e-3
