@@ -186,10 +186,10 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
         tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets)
         setup(tr)
         fr = [make_frame(frames[i]) for i in range(n_timed_end)]
+        gc.collect()  # (before the warm-up frames: no idle GPU between them and the timed ones)
+        gc.disable()
         for i in range(warmup):
             tr.run_single_frame((names[i], fr[i]))
-        gc.collect()
-        gc.disable()
         try:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -350,14 +350,14 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
     names = {i: f"{i:06d}.png" for i in mine}
     rng = np.random.default_rng(77 + rank)
     # warm-up: the first frames of the first segment, then the tracker is reset for the timed pass
+    import gc
+
+    gc.collect()  # (before the warm-up frames: no idle GPU between them and the timed ones)
+    gc.freeze()
+    gc.disable()
     if mine:
         for i in mine[: max(1, min(args.warmup, len(mine)))]:
             tracker.run_single_frame((names[i], frames[i]))
-    import gc
-
-    gc.collect()
-    gc.freeze()
-    gc.disable()
     if ws > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -527,6 +527,15 @@ def main():
     timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")
     tracker.testbed.stats_accum = torch.zeros(4, dtype=torch.int64, device=dev)
 
+    # the frame loop allocates a few hundred small Python objects per frame; a generation-2 collection in the middle of
+    # it is a 10 ms stall of the host that feeds the GPU.  Collected and frozen BEFORE the warm-up frames (round 4): done
+    # between warm-up and the timed region it left the GPU idle for tens of ms right before the first timed frame, which
+    # then ran 0.75 ms slower than every other one (`frame_ms.argmax` = 0 in rounds 1-3: 2.5 % of the driver's K = 20 window).
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for i in range(args.warmup):
         tracker.run_single_frame((names[i], frames[i]))
     torch.cuda.synchronize()
@@ -537,13 +546,6 @@ def main():
     # region, sampled so that the marker packets do not slow what they measure
     tracker.testbed.timing_enable(4)
 
-    # the frame loop allocates a few hundred small Python objects per frame; a generation-2
-    # collection in the middle of it is a 10 ms stall of the host that feeds the GPU
-    import gc
-
-    gc.collect()
-    gc.freeze()
-    gc.disable()
     if ws > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()

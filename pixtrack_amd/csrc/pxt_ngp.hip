@@ -1775,6 +1775,14 @@ extern "C" int pxt_ngp_timing_enable(pxt_ngp* ctx, int32_t enable) {
   if (!ctx) return PXT_E_ARG;
   ctx->timing = enable > 0 ? enable : 0;
   ctx->renders = 0;
+  // the event pairs of the first timed renders exist before any of them runs: creating a dozen events inside a render's
+  // enqueue is host time on the frame's critical path (the instrument must not slow the first frame it measures)
+  while (ctx->timing > 0 && ctx->pool.size() < 24) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    PXT_HIP_CHECK(hipEventCreate(&e0));
+    PXT_HIP_CHECK(hipEventCreate(&e1));
+    ctx->pool.emplace_back(e0, e1);
+  }
   return PXT_OK;
 }
 
