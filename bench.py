@@ -19,11 +19,14 @@ pyramid, ONE video cut into per-rank frame segments that cold-start, stitched by
 The timed loop carries only the roofline's instrumentation (HIP events around the dominant
 kernel's launches of every 4th render, one sample-count atomic per workgroup); per-stage times
 and the dominant kernel's isolated timing come from a separate untimed pass over the next 20
-frames.  The per-frame cost varies along the synthetic orbit (longer rays as the object turns:
-render 0.66 ms on the first frames, 0.70-0.79 later), so `value` depends a little on K: 647-670
-frames/s at the driver's K = 20, 642-655 over the 200 frames that follow (`extras.value_k200`);
-`extras.value_two_renders` (543-557) is the real-asset case in which the mask and the reference
-image need two renders.  The pool's boxes differ by ~5 % for one commit.
+frames.  Garbage is collected and frozen BEFORE the warm-up frames (collected between them and the
+timed region it left the GPU idle and the first timed frame 0.75 ms slow).  The per-frame cost
+varies along the synthetic orbit (longer rays as the object turns: render 0.66 ms on the first
+frames, 0.70-0.79 later), so `value` depends a little on K: 680-692 frames/s at the driver's K = 20
+and at K = 60, 652-665 over 200 frames (`extras.value_k200`); `extras.value_two_renders` (549-552) is
+the real-asset case in which the mask and the reference image need two renders, and
+`extras.value_ycb_refshape` / `value_r9_phone` / `value_r9_12mp` (410 / 407 / 248) run the reference's
+own reference-image shapes (921x921, 960x720, 2016x1512 -> 1024x768).  The pool's boxes differ by ~5 %.
 
 N > 1 without a launcher (`python bench.py --gpus 8`) spawns its own N ranks under
 torch.distributed.run; a world size that differs from --gpus, or fewer GPUs than ranks with the
