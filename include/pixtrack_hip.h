@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (8), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (9), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -113,7 +113,8 @@ int pxt_lm_refine(const float* p3d, const uint8_t* point_mask /* may be NULL */,
  * (get_camera_in_world_from_pixpose -> sfm_to_nerf_pose -> nerf_matrix_to_ngp, float64, pixtrack/utils/pose_utils.py:24,
  * pixtrack/utils/ingp_utils.py:47-63) and stores the 12 camera floats into up to two renderer camera slots
  * (pxt_ngp_camera_slot) and, optionally, a host-visible record cam_out13 (12 floats, then 1.0 stored last with
- * system-scope release).  A render enqueued behind this launch with pxt_ngp_render_frame(camera_from_slot = 1) then needs
+ * system-scope release; -1.0 instead, with the slots left untouched, when the refinement failed or timed out: the
+ * camera record and the slots are valid only if out[12] == out[13] == 0).  A render enqueued behind this launch with pxt_ngp_render_frame(camera_from_slot = 1) then needs
  * no conversion launch of its own (pxt_ngp_render_both_from_pose's one-thread kernel).  cam_host == NULL: pxt_lm_refine. */
 typedef struct {
   double conv27[27];   /* nerf2sfm centroid (3), 3 / avglen, R (4x4 row-major), totp (3), snapshot scale, offset (3) */
@@ -123,6 +124,34 @@ typedef struct {
 int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_points, const pxt_lm_level* levels_host,
                       int32_t n_levels, const float* T_init_host, const pxt_lm_conf* conf_host, float* out, float* log,
                       void* workspace, const pxt_lm_camera* cam_host, void* stream);
+
+/* K independent refinements in ONE persistent launch - K objects tracked in lock-step on one GPU (BASELINE configs[3]:
+ * the eight objects of /root/reference/config/*.sh, one tracker per object as
+ * pixtrack/pose_trackers/pixloc_tracker_r9.py:287-318 builds it; on fewer than 8 GPUs a rank carries 8 / N of them).
+ * Each problem is exactly one pxt_lm_refine_cam call - own points, levels, initial pose, output record, log, workspace
+ * (pxt_lm_workspace_bytes() each, all different) and optional camera record - and is solved by its own share of the
+ * grid: workgroup i works on problem i mod K, so the problems never wait for each other and an iteration's
+ * inter-workgroup exchange and single-lane solve are paid once per iteration for all K.  conf_host is shared;
+ * conf_host->n_workgroups is the grid PER PROBLEM (0 = library default: 256 / K rounded down to a multiple of 8, at
+ * most 128).  A problem's result is bit-identical to pxt_lm_refine_cam with the same n_workgroups (the fixed-order
+ * folds depend on the number of workgroups only).  batch_workspace: device, pxt_lm_batch_workspace_bytes(K); it holds
+ * the K parameter records, copied there from pinned staging memory ahead of the launch in `stream`. */
+#define PXT_LM_MAX_BATCH 16
+typedef struct {
+  const float* p3d;
+  const uint8_t* point_mask; /* may be NULL */
+  int32_t n_points;
+  const pxt_lm_level* levels_host;
+  int32_t n_levels;
+  const float* T_init_host;    /* 12 floats */
+  float* out;                  /* device or pinned host, 16 + PXT_MAX_LEVELS */
+  float* log;                  /* device or pinned host, or NULL */
+  void* workspace;             /* device, pxt_lm_workspace_bytes(); one per problem */
+  const pxt_lm_camera* cam_host; /* or NULL */
+} pxt_lm_problem;
+int64_t pxt_lm_batch_workspace_bytes(int32_t n_problems);
+int pxt_lm_refine_batch(const pxt_lm_problem* problems_host, int32_t n_problems, const pxt_lm_conf* conf_host,
+                        void* batch_workspace, void* stream);
 
 /* Bytes of scratch pxt_lm_refine needs (control words + tagged partial sums), independent of N.  One workspace serves
  * one launch at a time; its content carries over between launches (the tags of a launch continue above those of the
@@ -196,12 +225,19 @@ int pxt_unet_forward(pxt_unet* ctx, const void* image, int32_t image_is_u8, cons
  * normalize[i] as in pxt_unet_forward; out_maps[3*i + l] = image i, level l.  Each image's
  * result is independent of its batch neighbours; a layer's split-K factor depends on the
  * batch size, so a batched map equals the single-image one up to fp32 summation order. */
-#define PXT_UNET_MAX_BATCH 8
+#define PXT_UNET_MAX_BATCH 16
 int64_t pxt_unet_workspace_bytes_batch(const pxt_unet* ctx, int32_t n_images, int32_t H, int32_t W);
 int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* images,
                            const int32_t* image_is_u8, const uint8_t* const* masks, int32_t H, int32_t W,
                            float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
                            void* workspace, void* stream);
+
+/* How a batch of MORE than two images plans its layers.  0 (default): tile configuration and split-K factor chosen for
+ * the batch as launched (large batches need no split-K: the fastest).  1: every layer takes the plan a SINGLE image of
+ * the tracker's two-stream pair pass takes, whatever the batch size, so each image's maps are bit for bit the maps the
+ * one-object tracker computes for it (a layer's fp32 summation order is its tile's K walk and its split-K partition).
+ * Used by the lock-step multi-object tracker's parity tests; workspace sizes cover both. */
+int pxt_unet_set_batch_plan(pxt_unet* ctx, int32_t per_image_plan);
 
 /* Two images of possibly DIFFERENT sizes (H[i] x W[i]) as two single-image passes side by side on two streams - a frame's
  * reference render (reference camera x reference_scale, pixloc_pose_refiners.py:145-152) and its masked query

@@ -20,7 +20,9 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 8
+ABI_VERSION = 9
+PXT_LM_MAX_BATCH = 16
+PXT_UNET_MAX_BATCH = 16
 
 
 class PxtError(RuntimeError):
@@ -110,6 +112,12 @@ class LmCamera(C.Structure):
     _fields_ = [("conv27", C.c_double * 27), ("cam_slot", C.c_void_p * 2), ("cam_out13", C.c_void_p)]
 
 
+class LmProblem(C.Structure):
+    _fields_ = [("p3d", C.c_void_p), ("point_mask", C.c_void_p), ("n_points", C.c_int32),
+                ("levels_host", C.POINTER(LmLevel)), ("n_levels", C.c_int32), ("T_init_host", C.POINTER(C.c_float)),
+                ("out", C.c_void_p), ("log", C.c_void_p), ("workspace", C.c_void_p), ("cam_host", C.POINTER(LmCamera))]
+
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); every symbol include/pixtrack_hip.h declares.
@@ -127,6 +135,8 @@ PROTOTYPES = {
         [_VP, _VP, _I32, C.POINTER(LmLevel), _I32, _VP, C.POINTER(LmConf), _VP, _VP, _VP, C.POINTER(LmCamera), _VP],
     ),
     "pxt_lm_workspace_bytes": (_I64, []),
+    "pxt_lm_batch_workspace_bytes": (_I64, [_I32]),
+    "pxt_lm_refine_batch": (C.c_int, [C.POINTER(LmProblem), _I32, C.POINTER(LmConf), _VP, _VP]),
     "pxt_sample_sparse": (C.c_int, [_VP, _I32, _VP, C.POINTER(SampleLevel), _I32, _I32, _I32, _VP, _VP]),
     "pxt_unet_create": (C.c_int, [_VP, _I64, C.POINTER(_VP)]),
     "pxt_unet_destroy": (C.c_int, [_VP]),
@@ -136,6 +146,7 @@ PROTOTYPES = {
         [_VP, _VP, _I32, _VP, _I32, _I32, C.POINTER(_VP), C.POINTER(_I32), _I32, _VP, _VP],
     ),
     "pxt_unet_set_defer_join": (C.c_int, [_VP, _I32]),
+    "pxt_unet_set_batch_plan": (C.c_int, [_VP, _I32]),
     "pxt_unet_pair_join": (C.c_int, [_VP, _VP]),
     "pxt_unet_activation_stats": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
     "pxt_unet_workspace_bytes_batch": (_I64, [_VP, _I32, _I32, _I32]),

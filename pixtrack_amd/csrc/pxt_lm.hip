@@ -29,6 +29,8 @@
 //    G16 R2; results are bit-identical across workgroups and across runs).
 #include "pxt_common.h"
 
+#include <algorithm>
+
 namespace pxt {
 
 constexpr int kLmBlock = 512;
@@ -45,6 +47,12 @@ struct LmLevelDev {
   float cam[10];
   int ndist;
   float lambda[6];
+};
+
+// Which workgroups work on a problem: G of them, this one being number b.  The single-problem kernel's grid IS the
+// problem's (G = gridDim.x, b = blockIdx.x); the batched kernel deals its grid to the problems (pxt_lm_refine_batch).
+struct LmGrid {
+  int G, b;
 };
 
 struct LmParams {
@@ -214,7 +222,7 @@ __device__ inline void lm_point_record(float* dst, bool leader, float wgt, float
   dst[28] = 1.f;
 }
 
-__device__ inline void lm_accumulate(const LmParams& P, const LmLevelDev& L, const float* T,
+__device__ inline void lm_accumulate(const LmParams& P, const LmGrid grid, const LmLevelDev& L, const float* T,
                                      float* acc, const int LG, unsigned long long* dbg = nullptr) {
   const bool wide = LG == 32;
   int dbg_round = 0;
@@ -223,8 +231,8 @@ __device__ inline void lm_accumulate(const LmParams& P, const LmLevelDev& L, con
   const int sub = lane & (LG - 1);
   const int grp = wide ? (lane >> 5) : (lane >> 3);
   const int wave = threadIdx.x / PXT_WAVE;
-  const int wave_global = blockIdx.x * kLmWaves + wave;
-  const int stride = gridDim.x * kLmWaves * GPW;
+  const int wave_global = grid.b * kLmWaves + wave;
+  const int stride = grid.G * kLmWaves * GPW;
   const Cam cam = make_cam(L.cam, L.ndist);
   const int W = L.w, H = L.h, C = L.C, cs = L.cs;
   const float pad = (float)P.conf.pad;
@@ -376,9 +384,9 @@ __device__ inline int lm_local_group() {
 }
 
 template <int LG, int CI>
-__device__ inline void lm_load_point(const LmParams& P, const LmLevelDev& L, LmPoint<2>& pt) {
+__device__ inline void lm_load_point(const LmParams& P, const LmGrid grid, const LmLevelDev& L, LmPoint<2>& pt) {
   const int sub = (threadIdx.x & (PXT_WAVE - 1)) & (LG - 1);
-  pt.n = lm_local_group<LG>() * (int)gridDim.x + (int)blockIdx.x;
+  pt.n = lm_local_group<LG>() * grid.G + grid.b;
   pt.valid = pt.n < P.n;
   pt.X = pt.Y = 0.f;
   pt.Z = 1.f;
@@ -667,7 +675,7 @@ __device__ inline void apply_delta(const float* delta, float* T, float& dR_deg, 
 
 #if PXT_EXP_STAMPS  // timing experiment (scripts/lm_stamps.py): s_memtime of workgroup 0's first lane at 8 points per iteration
 __device__ unsigned long long pxt_lm_stamps[256 * 16];
-#define LM_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && run.total_iters < 256) pxt_lm_stamps[run.total_iters * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LM_STAMP(k) do { if (grid.b == 0 && blockIdx.x == 0 && threadIdx.x == 0 && run.total_iters < 256) pxt_lm_stamps[run.total_iters * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define LM_STAMP(k)
 #endif
@@ -691,9 +699,10 @@ struct LmRun {
 // One iteration after the accumulation: the group leaders' sums are in sh.grp (n_groups records).  Fold them, publish,
 // sweep every workgroup's granules, fold those, solve, update the pose, test the stop criteria.  Returns true when the
 // level is over (stop criteria met, failure or abort).  Four workgroup barriers.
-__device__ inline bool lm_step(const LmParams& P, const LmLevelDev& L, int li, int it, int n_groups, LmShared& sh, LmRun& run) {
+__device__ inline bool lm_step(const LmParams& P, const LmGrid grid, const LmLevelDev& L, int li, int it, int n_groups,
+                               LmShared& sh, LmRun& run) {
   const int tid = threadIdx.x;
-  const int G = gridDim.x;
+  const int G = grid.G;
   const int slot = tid >> 4, part = tid & 15;  // 32 slots x 16 parts: a slot's parts are one 16-lane DPP row
   __syncthreads();  // (A) the leaders' records are in sh.grp
   LM_STAMP(1);
@@ -712,7 +721,7 @@ __device__ inline bool lm_step(const LmParams& P, const LmLevelDev& L, int li, i
       for (int q = part; q < n_groups; q += 16) v += sh.grp[q * kGrpStride + slot];
     v = lm_row16_sum(v);
     if (part == 0)
-      __hip_atomic_store(area + (size_t)blockIdx.x * kNAcc + slot, tag | (unsigned long long)__float_as_uint(v),
+      __hip_atomic_store(area + (size_t)grid.b * kNAcc + slot, tag | (unsigned long long)__float_as_uint(v),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   LM_STAMP(2);
@@ -780,7 +789,7 @@ __device__ inline bool lm_step(const LmParams& P, const LmLevelDev& L, int li, i
     const bool small_grad = gn < P.conf.grad_stop;
     sh.flags[0] = (small_step || small_grad) ? 1 : 0;
     sh.flags[1] = fl ? 1 : 0;
-    if (blockIdx.x == 0 && P.log) {
+    if (grid.b == 0 && P.log) {
       float* lg = P.log + ((size_t)li * P.conf.num_iters + it) * PXT_LM_LOG_STRIDE;
       lg[0] = sh.tot[27] / n_valid;
       lg[1] = n_valid;
@@ -814,8 +823,8 @@ __device__ inline void lm_park(const float* acc, LmShared& sh) {
 // The accumulation of one iteration in the level's variant: 0 the general path (any channel count, several rounds of
 // points per group), 1..4 one-round levels with the point in registers (LG, channel quads per lane) = (8, 1), (32, 1),
 // (16, 2), (8, 4).  One loop body for all of them, so that lm_step - with its solve - is instantiated once.
-__device__ inline void lm_accumulate_variant(int variant, const LmParams& P, const LmLevelDev& L, const float* T,
-                                             const LmPoint<2>& pt, LmShared& sh, unsigned long long* dbg) {
+__device__ inline void lm_accumulate_variant(int variant, const LmParams& P, const LmGrid grid, const LmLevelDev& L,
+                                             const float* T, const LmPoint<2>& pt, LmShared& sh, unsigned long long* dbg) {
   switch (variant) {
     case 1: lm_accumulate_cached<8, 1>(P, L, T, pt, sh.grp, dbg); break;
     case 2: lm_accumulate_cached<32, 1>(P, L, T, pt, sh.grp, dbg); break;
@@ -826,16 +835,16 @@ __device__ inline void lm_accumulate_variant(int variant, const LmParams& P, con
 #pragma unroll
       for (int i = 0; i < kNAcc; ++i) acc[i] = 0.f;
       const int LGr = (L.C <= 32) ? 8 : 32;
-      lm_accumulate(P, L, T, acc, LGr, dbg);
+      lm_accumulate(P, grid, L, T, acc, LGr, dbg);
       if (LGr == 8) lm_park<8>(acc, sh); else lm_park<32>(acc, sh);
     }
   }
 }
 
-__global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
-  __shared__ LmShared sh;
+// One problem's whole refinement on the workgroups `grid` names (every thread of every one of them runs this).
+__device__ __forceinline__ void lm_refine_problem(const LmParams& P, const LmGrid grid, LmShared& sh) {
   const int tid = threadIdx.x;
-  const int G = gridDim.x;
+  const int G = grid.G;
 
   if (tid < 12) sh.T[tid] = P.T_init[tid];
   if (tid == 0) {
@@ -872,10 +881,10 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
     pt.fr[0] = pt.fr[1] = make_float4(0.f, 0.f, 0.f, 0.f);
     pt.n = 0;
     pt.valid = false;
-    if (variant == 1) lm_load_point<8, 1>(P, L, pt);
-    else if (variant == 2) lm_load_point<32, 1>(P, L, pt);
-    else if (variant == 3) lm_load_point<16, 2>(P, L, pt);
-    else if (variant == 4) lm_load_point<8, 4>(P, L, pt);
+    if (variant == 1) lm_load_point<8, 1>(P, grid, L, pt);
+    else if (variant == 2) lm_load_point<32, 1>(P, grid, L, pt);
+    else if (variant == 3) lm_load_point<16, 2>(P, grid, L, pt);
+    else if (variant == 4) lm_load_point<8, 4>(P, grid, L, pt);
     const int n_groups = kLmBlock / (variant == 2 ? 32 : variant == 3 ? 16 : variant != 0 ? 8 : (L.C <= 32 ? 8 : 32));
     int iters_done = 0;
     for (int it = 0; it < P.conf.num_iters; ++it) {
@@ -885,18 +894,18 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
       for (int i = 0; i < 12; ++i) T[i] = sh.T[i];
       unsigned long long* dbg = nullptr;
 #if PXT_EXP_STAMPS
-      if (blockIdx.x == 0 && threadIdx.x == 0 && run.total_iters < 256) dbg = pxt_lm_stamps + run.total_iters * 16;
+      if (grid.b == 0 && blockIdx.x == 0 && threadIdx.x == 0 && run.total_iters < 256) dbg = pxt_lm_stamps + run.total_iters * 16;
 #endif
-      lm_accumulate_variant(variant, P, L, T, pt, sh, dbg);
-      const bool stop = lm_step(P, L, li, it, n_groups, sh, run);
+      lm_accumulate_variant(variant, P, grid, L, T, pt, sh, dbg);
+      const bool stop = lm_step(P, grid, L, li, it, n_groups, sh, run);
       if (run.aborted) break;
       ++iters_done;
       if (stop) break;
     }
-    if (blockIdx.x == 0 && tid == 0) P.out[16 + li] = (float)iters_done;
+    if (grid.b == 0 && tid == 0) P.out[16 + li] = (float)iters_done;
   }
 
-  if (blockIdx.x == 0 && tid == 0) {
+  if (grid.b == 0 && tid == 0) {
     // The next launch's tags start above every tag of this one.  After a time-out that needs a margin: workgroup 0
     // leaves at epoch e, but a workgroup that lagged may still complete epoch e (every other granule is tagged by
     // then) and publish epoch e + 1 with tag base + e + 2 before it sees the error word - which a next launch
@@ -914,7 +923,12 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
     __hip_atomic_store(&P.out[15], 1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // ... and then the camera of the render queued behind this launch (one thread, float64: ~1 us after the record
     // has left; the renderer's kernels start after this kernel ends, in stream order)
-    if (P.cam_enabled) {
+    // A refinement that failed or timed out leaves the slots alone and marks the record -1: whatever render was queued
+    // behind this launch then runs on the slot's OLD camera, and a caller of the C ABI sees in the camera record itself
+    // that it must not be used (the Python tracker drops it on `success == False` as before).
+    if (P.cam_enabled && (run.failed || run.aborted)) {
+      if (P.cam_out) __hip_atomic_store(&P.cam_out[12], -1.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (P.cam_enabled) {
       float cam[12];
       pose_to_camera_f64(sh.T, P.cam_conv, cam);
       for (int k = 0; k < 2; ++k)
@@ -926,6 +940,24 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
+  __shared__ LmShared sh;
+  lm_refine_problem(P, LmGrid{(int)gridDim.x, (int)blockIdx.x}, sh);
+}
+
+// K independent problems in ONE persistent launch (pxt_lm_refine_batch): workgroup i works on problem i mod K as that
+// problem's workgroup i / K.  Every problem has its own granule areas, error word, stop test and output record, so the
+// problems never wait for each other - a problem that stops early simply retires its workgroups - and an iteration's
+// exchange (~2.5 us), single-lane solve (~1.1 us) and barriers are paid once per iteration for K problems instead of K
+// times in a row.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, so with K = 8 a problem's
+// workgroups share one XCD (its L2 then holds that problem's maps); nothing depends on it.  The problems' parameter
+// records live in device memory (8 x ~1 KB exceeds the kernel-argument segment): uniform scalar loads.
+__global__ __launch_bounds__(kLmBlock) void lm_refine_batch_kernel(const LmParams* __restrict__ params, const int K) {
+  __shared__ LmShared sh;
+  const int p = (int)blockIdx.x % K;
+  lm_refine_problem(params[p], LmGrid{(int)gridDim.x / K, (int)blockIdx.x / K}, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -1045,14 +1077,15 @@ extern "C" int pxt_lm_refine(const float* p3d, const uint8_t* point_mask, int32_
   return pxt_lm_refine_cam(p3d, point_mask, n_points, levels, n_levels, T_init, conf, out, log, workspace, nullptr, stream);
 }
 
-extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_points,
-                                 const pxt_lm_level* levels, int32_t n_levels, const float* T_init,
-                                 const pxt_lm_conf* conf, float* out, float* log, void* workspace,
-                                 const pxt_lm_camera* cam, void* stream) {
+namespace {
+
+// Host records -> the kernel's parameter block (shared by the single-problem and the batched entry).
+int lm_fill_params(LmParams& P, const float* p3d, const uint8_t* point_mask, int32_t n_points, const pxt_lm_level* levels,
+                   int32_t n_levels, const float* T_init, const pxt_lm_conf* conf, float* out, float* log, void* workspace,
+                   const pxt_lm_camera* cam) {
   if (!p3d || !levels || !T_init || !conf || !out || !workspace) return PXT_E_ARG;
   if (n_levels < 1 || n_levels > PXT_MAX_LEVELS || n_points < 1) return PXT_E_ARG;
   if (conf->num_iters < 1 || conf->pad < 0) return PXT_E_ARG;
-  LmParams P;
   P.p3d = p3d;
   P.mask = point_mask;
   P.n = n_points;
@@ -1090,46 +1123,106 @@ extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, in
   char* ws = (char*)workspace;
   P.err = (unsigned*)ws;  // 256-byte control block, then the granule areas
   P.granules = (unsigned long long*)(ws + 256);
+  return PXT_OK;
+}
+
+// Every workgroup of a problem spins until every granule of the epoch is tagged, so all of them must be resident at
+// once: never more workgroups than the device (or the partition / CU mask this process sees) can hold.  Several
+// trackers of one process may run their LM kernels side by side (tests: three), so a launch takes at most half of
+// the resident slots.  Cached per thread and device.
+int lm_resident_cap(int* cap) {
+  static thread_local int resident_cap[16] = {0};
+  int dev_id = 0;
+  PXT_HIP_CHECK(hipGetDevice(&dev_id));
+  *cap = 1 << 30;
+  if (dev_id < 0 || dev_id >= 16) return PXT_OK;
+  if (resident_cap[dev_id] == 0) {
+    int per_cu = 0, cus = 0;
+    PXT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lm_refine_batch_kernel, kLmBlock, 0));
+    PXT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
+    resident_cap[dev_id] = per_cu * cus > 1 ? per_cu * cus / 2 : 1;
+  }
+  *cap = resident_cap[dev_id];
+  return PXT_OK;
+}
+
+// Pinned staging records of the batched entry, a ring of four per thread and device: a slot is reused only after the
+// copy that read it has completed (its event), which by then is several launches old.
+struct LmStageSlot {
+  LmParams* host = nullptr;
+  hipEvent_t copied = nullptr;
+};
+constexpr int kLmStageSlots = 4;
+
+}  // namespace
+
+extern "C" int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_points,
+                                 const pxt_lm_level* levels, int32_t n_levels, const float* T_init,
+                                 const pxt_lm_conf* conf, float* out, float* log, void* workspace,
+                                 const pxt_lm_camera* cam, void* stream) {
+  LmParams P;
+  const int rc = lm_fill_params(P, p3d, point_mask, n_points, levels, n_levels, T_init, conf, out, log, workspace, cam);
+  if (rc != PXT_OK) return rc;
   int grid = conf->n_workgroups;
   // 128 workgroups: scripts/bench_lm.py, round 4, N = 2341: 8.7 us per iteration at 64, 8.5 at 128, 8.5 at 192 (where every
   // C = 128 level fits 32-lane groups in one round: the larger sweep costs what the cheaper variant saves), 8.8 at 256
   if (grid <= 0) grid = 128;
   if (grid > kLmMaxGrid) grid = kLmMaxGrid;
-  // every workgroup spins until every granule of the epoch is tagged, so all of them must be resident at
-  // once: never more workgroups than the device (or the partition / CU mask this process sees) can hold.
-  // Several trackers of one process may run their LM kernels side by side (tests: three), so a tracker takes
-  // at most half of the resident slots.
-  static thread_local int resident_cap[16] = {0};
+  int cap = 0;
+  if (const int rcap = lm_resident_cap(&cap)) return rcap;
+  if (grid > cap) grid = cap;
+  // (no memset: the polled words - granule tags, error word - are compared with values only this launch writes)
+  hipLaunchKernelGGL(lm_refine_kernel, dim3(grid), dim3(kLmBlock), 0, (hipStream_t)stream, P);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
+
+extern "C" int64_t pxt_lm_batch_workspace_bytes(int32_t n_problems) {
+  if (n_problems < 1 || n_problems > PXT_LM_MAX_BATCH) return PXT_E_ARG;
+  return (int64_t)((size_t)n_problems * sizeof(LmParams) + 255) / 256 * 256;
+}
+
+extern "C" int pxt_lm_refine_batch(const pxt_lm_problem* problems, int32_t n_problems, const pxt_lm_conf* conf,
+                                   void* batch_workspace, void* stream) {
+  if (!problems || !conf || !batch_workspace) return PXT_E_ARG;
+  if (n_problems < 1 || n_problems > PXT_LM_MAX_BATCH) return PXT_E_ARG;
+  const int K = n_problems;
+  for (int a = 0; a < K; ++a)  // every problem spins on ITS OWN granules: two problems on one workspace would read each other's
+    for (int b = a + 1; b < K; ++b)
+      if (problems[a].workspace == problems[b].workspace || problems[a].out == problems[b].out) return PXT_E_ARG;
+  static thread_local LmStageSlot stage[16][kLmStageSlots];
+  static thread_local int stage_next[16] = {0};
   int dev_id = 0;
   PXT_HIP_CHECK(hipGetDevice(&dev_id));
-  if (dev_id >= 0 && dev_id < 16) {
-    if (resident_cap[dev_id] == 0) {
-      int per_cu = 0, cus = 0;
-      PXT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lm_refine_kernel, kLmBlock, 0));
-      PXT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
-      resident_cap[dev_id] = per_cu * cus > 1 ? per_cu * cus / 2 : 1;
-    }
-    if (grid > resident_cap[dev_id]) grid = resident_cap[dev_id];
+  if (dev_id < 0 || dev_id >= 16) return PXT_E_ARG;
+  LmStageSlot& slot = stage[dev_id][stage_next[dev_id]];
+  stage_next[dev_id] = (stage_next[dev_id] + 1) % kLmStageSlots;
+  if (!slot.host) {
+    PXT_HIP_CHECK(hipHostMalloc((void**)&slot.host, PXT_LM_MAX_BATCH * sizeof(LmParams), hipHostMallocDefault));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming));
+  } else {
+    PXT_HIP_CHECK(hipEventSynchronize(slot.copied));
   }
+  for (int k = 0; k < K; ++k) {
+    const pxt_lm_problem& q = problems[k];
+    const int rc = lm_fill_params(slot.host[k], q.p3d, q.point_mask, q.n_points, q.levels_host, q.n_levels, q.T_init_host, conf,
+                                  q.out, q.log, q.workspace, q.cam_host);
+    if (rc != PXT_OK) return rc;
+  }
+  // Workgroups per problem: the chip's 256 CUs dealt to the problems, one workgroup per CU (a 32-workgroup grid runs an
+  // iteration within 5 % of the 128-workgroup one: profiles/r04_bench_lm.log), a multiple of 8, at most 128.
+  int per = conf->n_workgroups;
+  if (per <= 0) per = std::max(8, std::min(128, 256 / K / 8 * 8));
+  if (per > kLmMaxGrid) per = kLmMaxGrid;
+  int cap = 0;
+  if (const int rcap = lm_resident_cap(&cap)) return rcap;
+  // The problems' workgroups are interleaved in dispatch order, so a grid that does not fit the device would leave EVERY
+  // problem partly resident, each spinning on members that never start: the whole grid must be resident at once.
+  if (per * K > cap) per = std::max(1, cap / K);
   hipStream_t s = (hipStream_t)stream;
-  // One workgroup per CU: 128 workgroups of 42 KB of LDS may be placed two to a CU, and a CU that carries two runs
-  // each at half speed while 127 others wait for it at the iteration's exchange ("spin until all arrived" 5.5 k of a
-  // 19.5 k-cycle iteration in scripts/lm_stamps.py).  Asking for more than half a CU's 160 KB of LDS makes the second
-  // one impossible; the pad is never touched.  (Only while the grid fits the CUs one to one.)
-  static const int pad_lds = [] { const char* e = getenv("PXT_LM_PAD_LDS"); return e ? atoi(e) : 0; }();
-  int n_cus = 0;
-  (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-  size_t dyn = 0;
-  if (pad_lds && grid <= n_cus) {
-    dyn = 84 * 1024 - sizeof(LmShared);
-    static bool attr_done = false;
-    if (!attr_done) {
-      PXT_HIP_CHECK(hipFuncSetAttribute((const void*)lm_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-      attr_done = true;
-    }
-  }
-  // (no memset: the polled words - granule tags, error word - are compared with values only this launch writes)
-  hipLaunchKernelGGL(lm_refine_kernel, dim3(grid), dim3(kLmBlock), dyn, s, P);
+  PXT_HIP_CHECK(hipMemcpyAsync(batch_workspace, slot.host, (size_t)K * sizeof(LmParams), hipMemcpyHostToDevice, s));
+  PXT_HIP_CHECK(hipEventRecord(slot.copied, s));
+  hipLaunchKernelGGL(lm_refine_batch_kernel, dim3(per * K), dim3(kLmBlock), 0, s, (const LmParams*)batch_workspace, K);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }

@@ -390,6 +390,7 @@ struct pxt_unet {
   } sides[2];
   hipStream_t pass2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool plan_as_single = false;  // pxt_unet_set_batch_plan
   bool defer_join = false;    // pxt_unet_set_defer_join: the pair entry leaves the second pass un-joined ...
   bool join_pending = false;  // ... until pxt_unet_pair_join (or the next forward call) makes the caller's stream wait for it
   pxt::UnetLayer conv[pxt::kNumConv];
@@ -440,6 +441,11 @@ struct ConvPlan { int cfg, tiles, nb, splits; };
 // share a CU.
 thread_local int g_conv_peers = 1;
 thread_local int g_conv_layer = 0;  // index of the pyramid layer being launched (0: a stand-alone call)
+// pxt_unet_set_batch_plan(ctx, 1): a batch's layers take the tile configuration and the split-K factor a SINGLE image of
+// the frame's two-stream pair pass would take (n_img = 1, two passes sharing the chip), whatever the batch size - so an
+// image's maps are bit for bit those of the one-object tracker (the summation order of a layer is its tile's K walk and
+// its split-K partition, nothing else).  0: planned for the batch as launched (fewer splits, the fastest).
+thread_local bool g_plan_as_single = false;
 
 // Split-K factor: only the smallest maps (conv5: 12 tiles per image pair) leave most of the 256 CUs
 // without a workgroup; measured on the 60x80 layers (160 workgroups) every split loses to no split.
@@ -459,9 +465,10 @@ int choose_splits(int wgs, int n_chunks, bool upcat, int own = 1 << 30) {
 ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split, int force_cfg = 0,
                    int force_splits = 0, bool upcat = false, bool wants_pool = false) {
   ConvPlan P;
+  const int plan_img = g_plan_as_single ? 1 : n_img, plan_peers = g_plan_as_single ? 2 : g_conv_peers;
   auto wgs_of = [&](int cfg) {
     const int th = cfg_th(cfg);
-    return g_conv_peers * n_img * ((H + th - 1) / th) * ((W + 15) / 16) * (cout / cfg_bnc(cfg));
+    return plan_peers * plan_img * ((H + th - 1) / th) * ((W + 15) / 16) * (cout / cfg_bnc(cfg));
   };
   int cfg = force_cfg;
   if (!cfg_valid(cfg) || cout % cfg_bnc(cfg) != 0) {
@@ -498,7 +505,8 @@ ConvPlan plan_conv(int n_img, int H, int W, int cin, int cout, bool allow_split,
   const int th = cfg_th(cfg);
   P.tiles = n_img * ((H + th - 1) / th) * ((W + 15) / 16);
   P.nb = cout / cfg_bnc(cfg);
-  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(g_conv_peers * P.tiles * P.nb, cin / 32, upcat, P.tiles * P.nb)) : 1;
+  const int plan_tiles = P.tiles / n_img * plan_img;
+  P.splits = allow_split ? (force_splits > 0 ? std::min(force_splits, std::max(1, cin / 32)) : choose_splits(plan_peers * plan_tiles * P.nb, cin / 32, upcat, plan_tiles * P.nb)) : 1;
   if (kV2Cfgs[cfg].KS == 2) {  // every split must hold an even number of chunks: round the factor down to a divisor
     while (P.splits > 1 && (cin / 32) % (2 * P.splits) != 0) --P.splits;
   }
@@ -518,12 +526,16 @@ inline int upcat_cfg(int cout, int H, int W) {
 size_t splitk_bytes(int n_img, int H, int W, int cin, int cout, bool upcat = false) {
   int splits = 1;
   const int peers_before = g_conv_peers;
-  for (int peers = 1; peers <= 2; ++peers)
-    for (int pool = 0; pool < (upcat ? 1 : 2); ++pool) {
-      g_conv_peers = peers;
-      splits = std::max(splits, plan_conv(n_img, H, W, cin, cout, true, upcat ? upcat_cfg(cout, H, W) : 0, 0, upcat, pool != 0).splits);
-    }
+  const bool single_before = g_plan_as_single;
+  for (int single = 0; single < 2; ++single)
+    for (int peers = 1; peers <= 2; ++peers)
+      for (int pool = 0; pool < (upcat ? 1 : 2); ++pool) {
+        g_conv_peers = peers;
+        g_plan_as_single = single != 0;
+        splits = std::max(splits, plan_conv(n_img, H, W, cin, cout, true, upcat ? upcat_cfg(cout, H, W) : 0, 0, upcat, pool != 0).splits);
+      }
   g_conv_peers = peers_before;
+  g_plan_as_single = single_before;
   return splits > 1 ? (size_t)splits * n_img * H * W * cout * sizeof(float) : 0;
 }
 
@@ -1069,9 +1081,11 @@ extern "C" int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const voi
   if (!ctx || !images || !image_is_u8 || !out_maps || !out_cstride || !normalize || !workspace) return PXT_E_ARG;
   static const int n_streams = [] { const char* e = getenv("PXT_UNET_STREAMS"); return e ? atoi(e) : 2; }();
   if (ctx->join_pending) { PXT_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_join, 0)); ctx->join_pending = false; }
-  if (n_images != 2 || n_streams < 2)
+  if (n_images != 2 || n_streams < 2) {
+    struct PlanMode { PlanMode(bool on) { g_plan_as_single = on; } ~PlanMode() { g_plan_as_single = false; } } plan_guard(ctx->plan_as_single && n_images > 2);
     return forward_pass(ctx, n_images, images, image_is_u8, masks, H, W, out_maps, out_cstride, normalize, workspace,
                         stream, ctx->sides[0]);
+  }
   const int32_t Hs[2] = {H, H}, Ws[2] = {W, W};
   return pxt_unet_forward_pair(ctx, images, image_is_u8, masks, Hs, Ws, out_maps, out_cstride, normalize, workspace, stream);
 }
@@ -1119,6 +1133,12 @@ extern "C" int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, c
     return PXT_OK;
   }
   PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  return PXT_OK;
+}
+
+extern "C" int pxt_unet_set_batch_plan(pxt_unet* ctx, int32_t per_image_plan) {
+  if (!ctx) return PXT_E_ARG;
+  ctx->plan_as_single = per_image_plan != 0;
   return PXT_OK;
 }
 

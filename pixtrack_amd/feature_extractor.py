@@ -34,6 +34,7 @@ class PixTrackFeatureExtractor:
 
         self.defer_join = os.environ.get("PXT_UNET_DEFER_JOIN", "1") != "0" and hasattr(model, "set_defer_join")
         self._join_pending = False
+        self._preloaded = []  # [(image, scale_image, mask, normalize, maps, scales)] handed over by preload()
         self.last_input_wh = None  # (w, h) the UNet ran the last extract_packed image at (after the resize rule)
         assert hasattr(self.model, "scales")
         assert self.conf.resize_by in ["max", "max_force"], self.conf.resize_by
@@ -74,9 +75,23 @@ class PixTrackFeatureExtractor:
         self._staged = (image, scale_image, mask, normalize)
         self._ready = None
 
+    def preload(self, image, scale_image: int, mask, normalize: bool, maps, scales) -> None:
+        """Hands over the pyramid of an extraction that WILL be requested with exactly these arguments - computed
+        elsewhere, in a batched pass over the images of several trackers (pose_trackers/multi_object_tracker.py: the
+        reference renders and masked queries of K objects in one pxt_unet_forward_batch).  The matching extract_packed
+        call returns it; anything else is computed as usual.  Cleared by unstage()."""
+        self._preloaded.append((image, scale_image, mask, normalize, maps, scales))
+
+    def prepared(self, image, scale_image: int = 1, mask=None):
+        """(HWC device image at the size the UNet runs it, mask still to apply, per-level scales): what a batched pass
+        needs to run this extraction elsewhere (see preload)."""
+        a_img, a_mask, a_sr = self._prepare(image, scale_image, mask)
+        return a_img, a_mask, [(a_sr[0] / s, a_sr[1] / s) for s in self.model.scales]
+
     def unstage(self) -> None:
         self._join()
         self._staged = self._ready = None
+        self._preloaded.clear()
 
     def _join(self) -> None:
         if self._join_pending:
@@ -103,6 +118,11 @@ class PixTrackFeatureExtractor:
     def extract_packed(self, image, scale_image: int = 1, mask: Optional[torch.Tensor] = None,
                        normalize: bool = False):
         """-> (maps [h,w,cstride] x3 on device, scales [(sx,sy)] x3)."""
+        for k, r in enumerate(self._preloaded):
+            if r[0] is image and r[1] == scale_image and r[2] is mask and r[3] == normalize:
+                del self._preloaded[k]
+                self.last_input_wh = (int(r[4][0].shape[1]), int(r[4][0].shape[0]))
+                return r[4], r[5]
         if self._ready is not None:
             r = self._ready
             self._ready = None

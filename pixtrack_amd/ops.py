@@ -38,6 +38,15 @@ SCHEMAS = {
         "float loss_scale, float grad_stop, float dt_stop, float dR_stop, int min_valid, int n_workgroups, "
         "Tensor(a!) record, Tensor(b!) workspace, bool want_log, int spin_limit=0, float[]? cam_conv=None, "
         "int[]? cam_slots=None, Tensor(c!)? cam_out=None, int lm_path=0) -> ()"),
+    # K problems in one persistent launch (pxt_lm_refine_batch): per-problem tensors as lists, per-level tensors and
+    # records flattened problem-major (n_levels[k] entries each), conf shared; n_workgroups is per problem
+    "lm_refine_batch": (
+        "(Tensor[] p3d, Tensor?[] point_masks, int[] n_levels, Tensor[] fmaps, Tensor[] frefs, int[] channels, "
+        "float[] cameras, int[] ndist, float[] lambdas, float[] T_init, int num_iters, int pad, int loss, float loss_alpha, "
+        "float loss_scale, float grad_stop, float dt_stop, float dR_stop, int min_valid, int n_workgroups, "
+        "Tensor(a!)[] records, Tensor(b!)[] workspaces, Tensor(c!) batch_workspace, bool want_log, int spin_limit=0, "
+        "float[]? cam_conv=None, int[]? cam_slots=None, Tensor(d!)[]? cam_outs=None, int lm_path=0, "
+        "int[]? cam_enabled=None) -> ()"),
     "sample_sparse": (
         "(Tensor p3d, float[] T, Tensor[] fmaps, int[] channels, float[] cameras, int[] ndist, int pad, "
         "bool normalize, Tensor(a!)[] outs, Tensor(b!) valid) -> ()"),
@@ -139,6 +148,86 @@ def _lm_refine(p3d, point_mask, fmaps, frefs, channels, cameras, ndist, lambdas,
         L.pxt_lm_refine(p3d.data_ptr(), _lib.dptr(point_mask), n, arr, n_levels, T0, C.byref(conf), base,
                         base + 4 * nh if want_log else None, workspace.data_ptr(), _stream(p3d)),
         "pxt_lm_refine")
+
+
+def _lm_refine_batch(p3d, point_masks, n_levels, fmaps, frefs, channels, cameras, ndist, lambdas, T_init, num_iters, pad,
+                     loss, loss_alpha, loss_scale, grad_stop, dt_stop, dR_stop, min_valid, n_workgroups, records,
+                     workspaces, batch_workspace, want_log, spin_limit=0, cam_conv=None, cam_slots=None, cam_outs=None,
+                     lm_path=0, cam_enabled=None):
+    L = _lib.lib()
+    K = len(p3d)
+    n_levels = [int(x) for x in n_levels]
+    nl_tot = sum(n_levels)
+    if not (1 <= K <= _lib.PXT_LM_MAX_BATCH) or len(n_levels) != K or len(records) != K or len(workspaces) != K \
+            or len(point_masks) != K or len(T_init) != 12 * K:
+        raise _lib.PxtError(f"lm_refine_batch: {K} problems (1..{_lib.PXT_LM_MAX_BATCH}) need one record, workspace, mask slot "
+                            "and 12 pose floats each")
+    if len(fmaps) != nl_tot or len(frefs) != nl_tot or len(channels) != nl_tot or len(cameras) != 10 * nl_tot \
+            or len(lambdas) != 6 * nl_tot or len(ndist) != nl_tot:
+        raise _lib.PxtError("lm_refine_batch: per level one fmap, fref, channel count, ndist, 10 camera and 6 lambda floats")
+    conf = _lib.LmConf()
+    conf.num_iters, conf.pad, conf.loss = int(num_iters), int(pad), int(loss)
+    conf.loss_alpha, conf.loss_scale = float(loss_alpha), float(loss_scale)
+    conf.grad_stop, conf.dt_stop, conf.dR_stop = float(grad_stop), float(dt_stop), float(dR_stop)
+    conf.min_valid, conf.n_workgroups, conf.spin_limit = int(min_valid), int(n_workgroups), int(spin_limit)
+    conf.path = int(lm_path)
+    nh = 16 + _lib.PXT_MAX_LEVELS
+    if cam_conv is not None and (len(cam_conv) != 27 * K or len(cam_slots or []) != 2 * K
+                                 or (cam_outs is not None and len(cam_outs) != K)):
+        raise _lib.PxtError("lm_refine_batch: cam_conv holds 27 doubles, cam_slots 2 pointers (0 = none) per problem")
+    probs = (_lib.LmProblem * K)()
+    keep = []  # ctypes records the problem array points to
+    li = 0
+    for k in range(K):
+        _f32c(p3d[k], "p3d")
+        n = int(p3d[k].shape[0])
+        nl = n_levels[k]
+        if not (1 <= nl <= _lib.PXT_MAX_LEVELS):
+            raise _lib.PxtError(f"lm_refine_batch: problem {k} has {nl} levels")
+        arr = (_lib.LmLevel * nl)()
+        for i in range(nl):
+            fm, fr = _f32c(fmaps[li], "fmap"), _f32c(frefs[li], "fref")
+            h, w, cs = fm.shape
+            if tuple(fr.shape) != (n, cs):
+                raise _lib.PxtError(f"lm_refine_batch: fref of problem {k} level {i} is {tuple(fr.shape)}, expected {(n, cs)}")
+            arr[i].fmap, arr[i].fref = fm.data_ptr(), fr.data_ptr()
+            arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, int(channels[li]), cs
+            arr[i].cam[:] = cameras[10 * li:10 * li + 10]
+            arr[i].ndist = int(ndist[li])
+            arr[i].lambda_[:] = lambdas[6 * li:6 * li + 6]
+            li += 1
+        rec = records[k]
+        need = nh + (nl * int(num_iters) * _lib.PXT_LM_LOG_STRIDE if want_log else 0)
+        if rec.dtype != torch.float32 or rec.numel() < need or not rec.is_contiguous() or not (rec.is_cuda or rec.is_pinned()):
+            raise _lib.PxtError(f"lm_refine_batch: record {k} needs {need} contiguous float32 values in device or pinned memory")
+        mk = point_masks[k]
+        if mk is not None and (mk.dtype != torch.uint8 or not mk.is_contiguous() or mk.numel() != n):
+            raise _lib.PxtError("lm_refine_batch: point masks are contiguous uint8 [n_points]")
+        T0 = (C.c_float * 12)(*[float(x) for x in T_init[12 * k:12 * k + 12]])
+        q = probs[k]
+        q.p3d, q.point_mask, q.n_points = p3d[k].data_ptr(), _lib.dptr(mk), n
+        q.levels_host, q.n_levels, q.T_init_host = arr, nl, T0
+        q.out = rec.data_ptr()
+        q.log = rec.data_ptr() + 4 * nh if want_log else None
+        q.workspace = workspaces[k].data_ptr()
+        cam = None
+        if cam_conv is not None and (cam_enabled is None or cam_enabled[k]):
+            cam = _lib.LmCamera()
+            cam.conv27[:] = [float(x) for x in cam_conv[27 * k:27 * k + 27]]
+            for j in range(2):
+                cam.cam_slot[j] = int(cam_slots[2 * k + j]) or None
+            cam.cam_out13 = None
+            if cam_outs is not None:
+                co = cam_outs[k]
+                if co.dtype != torch.float32 or co.numel() < 13 or not (co.is_cuda or co.is_pinned()):
+                    raise _lib.PxtError("lm_refine_batch: cam_outs are pinned host (or device) float32 tensors of >= 13 elements")
+                cam.cam_out13 = co.data_ptr()
+            q.cam_host = C.pointer(cam)
+        keep.append((arr, T0, cam))
+    if batch_workspace.numel() * batch_workspace.element_size() < int(L.pxt_lm_batch_workspace_bytes(K)):
+        raise _lib.PxtError("lm_refine_batch: batch_workspace smaller than pxt_lm_batch_workspace_bytes(K)")
+    _lib.check(L.pxt_lm_refine_batch(probs, K, C.byref(conf), batch_workspace.data_ptr(), _stream(p3d[0])),
+               "pxt_lm_refine_batch")
 
 
 # ------------------------------------------------------------------------------------ sampling
@@ -342,6 +431,7 @@ def _resize_linear(src, dst):
 
 _IMPLS = {
     "lm_refine": _lm_refine,
+    "lm_refine_batch": _lm_refine_batch,
     "sample_sparse": _sample_sparse,
     "unet_forward_batch": _unet_forward_batch,
     "conv3x3_nhwc_f16": _conv3x3,

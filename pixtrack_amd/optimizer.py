@@ -287,6 +287,63 @@ class PixTrackOptimizer:
         done.record(torch.cuda.current_stream(dev))
         return PendingLM(buf, want_log, n_levels, conf.num_iters, (p3d, mask, keep, workspace), done)
 
+    @staticmethod
+    def refine_levels_batch(problems: Sequence[dict], conf: _lib.LmConf, batch_workspace: torch.Tensor,
+                            want_log: bool = True) -> List["PendingLM"]:
+        """K independent refinements in ONE persistent launch (pxt_lm_refine_batch): ``problems`` are
+        PoseTrackerRefiner.lm_problem records (ref.p3d / ref.valid, packs, T_init, workspace, camera) of K objects
+        tracked in lock-step; ``conf`` is shared (conf.n_workgroups = grid per problem, 0 = 256 / K).  Returns one
+        result handle per problem; each problem's result is that of refine_levels with the same grid."""
+        K = len(problems)
+        assert 1 <= K <= _lib.PXT_LM_MAX_BATCH
+        dev = problems[0]["ref"].p3d.device
+        nh = 16 + _lib.PXT_MAX_LEVELS
+        p3ds, masks, n_levels, fmaps, frefs, chans, cams, ndist, lambdas, T0, recs, wss = [], [], [], [], [], [], [], [], [], [], [], []
+        # (a problem may carry the camera record of a render queued behind the launch - the tracker's steady frames - or
+        # not: a frame after a failure)
+        cam_conv, cam_slots, cam_outs, cam_on = [], [], [], []
+        with_cam = any(pr.get("camera") is not None for pr in problems)
+        bufs = _pinned_records([nh + (len(pr["packs"]) * conf.num_iters * _lib.PXT_LM_LOG_STRIDE if want_log else 0)
+                                for pr in problems])
+        for pr, buf in zip(problems, bufs):
+            ref, levels = pr["ref"], pr["packs"]
+            _lib.require_gpu(ref.p3d, "p3d")
+            p3ds.append(ref.p3d.to(torch.float32).contiguous())
+            masks.append(None if ref.valid is None else ref.valid.to(dev, torch.uint8).contiguous())
+            n_levels.append(len(levels))
+            for lp in levels:
+                assert lp.fref.shape == (ref.p3d.shape[0], lp.fmap.shape[2])
+                fmaps.append(lp.fmap)
+                frefs.append(lp.fref)
+                chans.append(int(lp.C))
+                cams += lp.camera.as10().tolist()
+                ndist.append(int(lp.camera._data.shape[-1] - 6))
+                lambdas += lp.lambda_.float().tolist()
+            T = pr["T_init"]
+            T0 += T.as12().detach().cpu().reshape(-1).tolist() if hasattr(T, "as12") else [float(x) for x in T]
+            buf[:nh].zero_()
+            recs.append(buf)
+            wss.append(pr["workspace"])
+            if with_cam:
+                if pr.get("camera") is not None:
+                    conv, slots, cam_out = pr["camera"]
+                    cam_on.append(1)
+                else:
+                    conv, slots, cam_out = [0.0] * 27, [0, 0], None
+                    cam_on.append(0)
+                cam_conv += [float(x) for x in conv]
+                cam_slots += ([int(x) for x in slots] + [0, 0])[:2]
+                cam_outs.append(cam_out if cam_out is not None else _pinned_record(16))
+        ops.lm_refine_batch(p3ds, masks, n_levels, fmaps, frefs, chans, cams, ndist, lambdas, T0, conf.num_iters, conf.pad,
+                            conf.loss, conf.loss_alpha, conf.loss_scale, conf.grad_stop, conf.dt_stop, conf.dR_stop,
+                            conf.min_valid, conf.n_workgroups, recs, wss, batch_workspace, bool(want_log),
+                            int(conf.spin_limit), cam_conv if with_cam else None, cam_slots if with_cam else None,
+                            cam_outs if with_cam else None, int(conf.path), cam_on if with_cam else None)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return [PendingLM(buf, want_log, nl, conf.num_iters, (p3d, mk, list(pr["packs"]), ws), done)
+                for buf, nl, p3d, mk, pr, ws in zip(recs, n_levels, p3ds, masks, problems, wss)]
+
     def run(self, p3D, F_ref, F_query, T_init: Pose, camera: Camera, mask=None, W_ref_query=None):
         """One pyramid level, pixloc calling convention:
         p3D [N,3] (numpy or tensor), F_ref [N,C], F_query [C,h,w], W_ref_query =
@@ -351,6 +408,18 @@ def _pinned_record(n_floats: int) -> torch.Tensor:
     buf = ring[0][ring[1]]
     ring[1] ^= 1
     return buf
+
+
+def _pinned_records(sizes: Sequence[int]) -> List[torch.Tensor]:
+    """The K records of one batched launch: distinct pinned buffers, two sets alternating per (sizes) signature."""
+    pool = _PINNED.__dict__.setdefault("batch_pool", {})
+    key = tuple(int(x) for x in sizes)
+    ring = pool.get(key)
+    if ring is None:
+        ring = pool[key] = [[[torch.zeros(n, dtype=torch.float32).pin_memory() for n in key] for _ in range(2)], 0]
+    bufs = ring[0][ring[1]]
+    ring[1] ^= 1
+    return bufs
 
 
 class PendingLM:

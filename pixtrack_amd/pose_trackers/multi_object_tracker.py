@@ -1,0 +1,192 @@
+"""MultiObjectTracker -- K objects tracked in lock-step on ONE GPU.
+
+The reference tracks one object per process: `pixloc_tracker_r9.py:287-318` builds one
+``PixLocPoseTrackerR9`` from one ``config/<object>.sh`` and runs it over one video.  BASELINE configs[3]
+("8 objects from config/*.sh tracked concurrently") on fewer than 8 GPUs means several such trackers per
+GPU.  Running them one after the other (or as processes sharing the GPU) leaves the small stages of a
+frame as they are: every tracker's deep UNet layers fill a third of the chip, every tracker's LM launch
+pays its own inter-workgroup exchange and single-lane solve per iteration.  Here the K trackers keep
+their own state and policy - each one IS a PixLocPoseTrackerR9, advanced through the same per-frame
+methods - and only the device work of a frame step is merged:
+
+* the 2 K images of a step (K reference renders, K masked queries) go through the UNet in ONE batched
+  pass (``pxt_unet_forward_batch``): the 30x40 / 60x80 / decoder layers get 2 K x the workgroups;
+* the K refinements run in ONE persistent launch (``pxt_lm_refine_batch``): workgroup i works on
+  problem i mod K, an iteration's exchange and solve are paid once for all K;
+* renders stay one renderer context per object (each object has its own NeRF), the render of step
+  t + 1 queued behind the batched LM launch with the camera from the LM epilogue's slot, as in the
+  one-object tracker.
+
+A tracker in cold start (image scales [4, 1]: two dependent refinements) runs that frame by itself
+through ``run_single_frame``; everything else is lock-step.  Per object the results are those of the
+one-object tracker: bit for bit with ``per_image_plan=True`` and ``lm_workgroups`` equal to the solo
+grid (the UNet layers then take a single image's tile / split-K plan, the LM folds the same number of
+partials); with the defaults (batch-planned layers: no split-K where the batch fills the chip; 256 / K
+workgroups per problem) equal up to fp32 summation order.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from .. import _lib
+from ..optimizer import PixTrackOptimizer
+from ..tracker import DebugTracker
+from .pixloc_tracker_r9 import PixLocPoseTrackerR9
+
+
+class MultiObjectTracker:
+    def __init__(self, trackers: Sequence[PixLocPoseTrackerR9], lm_workgroups: int = 0, per_image_plan: bool = False,
+                 max_unet_batch: int = _lib.PXT_UNET_MAX_BATCH):
+        if not trackers:
+            raise ValueError("MultiObjectTracker needs at least one tracker")
+        self.trackers: List[PixLocPoseTrackerR9] = list(trackers)
+        self.device = self.trackers[0].device
+        for tr in self.trackers:
+            if tr.device != self.device:
+                raise _lib.PxtError("lock-step trackers share one device")
+        # one UNet context runs every image of a step: the trackers must hold the same checkpoint
+        # (pixloc_megadepth is one network for all objects; reference pixloc_pose_refiners.py:49-60)
+        self.model = self.trackers[0].localizer.extractor.model
+        sig = getattr(self.model, "weights_signature", None)
+        for tr in self.trackers[1:]:
+            if getattr(tr.localizer.extractor.model, "weights_signature", None) != sig:
+                raise _lib.PxtError("lock-step trackers must share one UNet checkpoint")
+        self.lm_workgroups = int(lm_workgroups)      # grid per problem of the batched launch; 0: 256 / K
+        self.per_image_plan = bool(per_image_plan)   # UNet layers planned as for one image (bit-identity with solo runs)
+        self.max_unet_batch = int(max_unet_batch)
+        self._batch_ws: Optional[torch.Tensor] = None
+        self.steps = 0
+        self.solo_frames = 0       # frames that ran through run_single_frame (cold starts, several references)
+        self.lockstep_frames = 0
+        self.timing = None         # set to {} to collect HIP-event pairs per phase (bench.py's untimed diagnostic pass)
+
+    # ------------------------------------------------------------------ helpers
+    def _lm_batch_ws(self, k: int) -> torch.Tensor:
+        need = int(_lib.lib().pxt_lm_batch_workspace_bytes(_lib.PXT_LM_MAX_BATCH))
+        if self._batch_ws is None:
+            self._batch_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        return self._batch_ws
+
+    def _mark(self, name: str):
+        if self.timing is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.timing.setdefault(name, []).append(e)
+        return e
+
+    def _unet_batch(self, jobs) -> None:
+        """jobs: [(extractor, image, scale, mask, normalize)] -> every pyramid computed in batched passes (images of
+        one size per pass, at most max_unet_batch each) and handed to its extractor through preload()."""
+        prepared = []
+        for ex, image, scale, mask, normalize in jobs:
+            img, rest_mask, scales = ex.prepared(image, scale, mask)
+            prepared.append((img, rest_mask, scales))
+        groups = {}
+        for i, (img, _m, _s) in enumerate(prepared):
+            groups.setdefault((int(img.shape[0]), int(img.shape[1])), []).append(i)
+        self.model.set_batch_plan(self.per_image_plan)
+        try:
+            for idx in groups.values():
+                for a in range(0, len(idx), self.max_unet_batch):
+                    part = idx[a:a + self.max_unet_batch]
+                    outs = self.model.forward_packed_batch([(prepared[i][0], prepared[i][1], jobs[i][4]) for i in part])
+                    for i, maps in zip(part, outs):
+                        ex, image, scale, mask, normalize = jobs[i]
+                        ex.preload(image, scale, mask, normalize, maps, prepared[i][2])
+        finally:
+            self.model.set_batch_plan(False)
+
+    # ------------------------------------------------------------------ one step = one frame of every object
+    def run_single_frames(self, frames) -> List[bool]:
+        """frames[k] = (path, image) of tracker k (None: that tracker sits this step out).  The lock-step counterpart
+        of PoseTracker.run_single_frame (reference base_pose_tracker.py:24-30) for K trackers at once."""
+        assert len(frames) == len(self.trackers)
+        out: List[Optional[bool]] = [None] * len(frames)
+        live = []
+        self._mark("step_begin")
+        # ---- phase A: per-object frame set-up (policy head, mask + reference render or the render queued last step)
+        for k, (tr, frame) in enumerate(zip(self.trackers, frames)):
+            if frame is None:
+                continue
+            scales = tr.steady_multiscale if tr.success else tr.localizer.refiner.conf.multiscale
+            if tr.cold_start or len(tr.reference_ids) != 1 or list(scales or [1]) != [1]:
+                tr.run_single_frame(frame)
+                out[k] = bool(tr.success)
+                self.solo_frames += 1
+                continue
+            tr._frame_setup(frame, lockstep=True)
+            ref_u8 = tr.get_reference_image(tr.pose)
+            tr._fused_reference = (tr.pose, ref_u8)  # get_dynamic_id asks for it again: the same tensor object
+            live.append((k, tr, frame, ref_u8))
+        self._mark("renders_enqueued")
+        if not live:
+            self.steps += 1
+            return out
+        # ---- phase B: the step's 2 K images through the UNet in batched passes
+        jobs = []
+        for k, tr, (path, image), ref_u8 in live:
+            ex = tr.localizer.refiner.feature_extractor
+            jobs.append((ex, ref_u8, 1, None, False))                               # extract_reference_features
+            jobs.append((ex, image, 1, tr.localizer.refiner.query_mask, True))      # refine_query_pose's query pass
+        self._unet_batch(jobs)
+        self._mark("unet_enqueued")
+        # ---- phase C: per object, the reference's bookkeeping + sparse sampling + the LM problem
+        pend = []
+        for k, tr, (path, image), ref_u8 in live:
+            refiner = tr.localizer.refiner
+            tr.dynamic_id = tr.get_dynamic_id(tr.pose)
+            ref_id = tr.reference_ids[0]
+            pose_init = tr._frame_pose_init()
+            dbg = DebugTracker(refiner, tr.debug)
+            status, x = refiner.begin_refine(path, tr.camera, pose_init, [ref_id], image, tr.dynamic_id)
+            refiner.feature_extractor.unstage()  # (drops a preloaded pyramid nobody asked for)
+            pend.append((k, tr, path, ref_id, dbg, status, x))
+        self._mark("sampling_enqueued")
+        # ---- phase D: ONE persistent launch for every refinement, then each object's next render behind it
+        probs = [x for (_k, _tr, _p, _r, _d, status, x) in pend if status == "lm"]
+        handles = []
+        if probs:
+            conf = probs[0]["conf"]
+            for pr in probs[1:]:
+                if bytes(pr["conf"]) != bytes(conf):
+                    raise _lib.PxtError("lock-step trackers must share the optimizer configuration")
+            conf.n_workgroups = self.lm_workgroups
+            handles = PixTrackOptimizer.refine_levels_batch(probs, conf, self._lm_batch_ws(len(probs)))
+        self._mark("lm_enqueued")
+        it = iter(handles)
+        pend = [(k, tr, path, ref_id, dbg, status, x, next(it) if status == "lm" else None)
+                for (k, tr, path, ref_id, dbg, status, x) in pend]
+        for k, tr, path, ref_id, dbg, status, x, handle in pend:
+            hook = getattr(tr.localizer.refiner, "after_lm_enqueued", None)
+            if handle is not None and hook is not None:
+                hook(handle)
+        self._mark("ahead_enqueued")
+        # ---- phase E: results, per-object policy (cost gate, pose update, history), the loop's tail
+        for k, tr, path, ref_id, dbg, status, x, handle in pend:
+            refiner = tr.localizer.refiner
+            ret = refiner.finish_refine(x, handle.result()) if handle is not None else x
+            ok = tr._frame_policy(path, {ref_id: ret}, {ref_id: tr._frame_cost()}, {ref_id: dbg})
+            if not ok:
+                tr.relocalize(frames[k])
+            tr.update_reference_ids()
+            out[k] = bool(ok)
+            self.lockstep_frames += 1
+        self._mark("step_end")
+        self.steps += 1
+        return out
+
+    def run(self, frame_iterators, max_frames=float("inf")):
+        """Advances every tracker over its own frame iterator (``get_query_frame_iterator`` objects or any iterables of
+        (path, image)), one frame of each per step, until all are exhausted."""
+        its = [iter(f) for f in frame_iterators]
+        n = 0
+        while n < max_frames:
+            frames = [next(it, None) for it in its]
+            if all(f is None for f in frames):
+                break
+            self.run_single_frames(frames)
+            n += 1
+        return n

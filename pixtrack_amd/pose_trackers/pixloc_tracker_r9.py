@@ -495,43 +495,69 @@ class PixLocPoseTrackerR9(PoseTracker):
     def refine(self, query):
         query_path, query_image = query
         refiner = self.localizer.refiner
+        self._frame_setup(query)
+        self.dynamic_id = self.get_dynamic_id(self.pose)
+        trackers, rets, costs = {}, {}, {}
+        for ref_id in self.reference_ids:
+            pose_init = self._frame_pose_init()
+            tracker = DebugTracker(refiner, self.debug)
+            ret = self.localizer.run_query(query_path, self.camera, pose_init, [ref_id], image_query=query_image,
+                                           pose=self.pose, reference_images_raw=None, dynamic_id=self.dynamic_id)
+            rets[ref_id] = ret
+            trackers[ref_id] = tracker
+            costs[ref_id] = self._frame_cost()
+        return self._frame_policy(query_path, rets, costs, trackers)
+
+    def _frame_setup(self, query, lockstep: bool = False) -> str:
+        """The head of refine() (reference :216-227): cold start -> image scales [4, 1] from the relocalised pose; a
+        tracked frame -> scale [1] with the query masked by the silhouette at the last pose; after a failed frame no
+        mask and whatever scales were last set (Appendix D.3).  Arms the extractor's two-image pass and the render that
+        rides behind the LM launch.  Returns "cold" / "steady" / "plain".  ``lockstep``: the frame's two UNet passes
+        and its LM launch are batched with other objects' by the caller (multi_object_tracker.py), which hands the
+        maps over through the extractor's preload() - nothing is staged here."""
+        query_path, query_image = query
+        refiner = self.localizer.refiner
         refiner.query_mask = None
+        kind = "plain"
         if self.cold_start:
             refiner.conf.multiscale = [4, 1]
             self.relocalize(query)
             self.cold_start = False
+            kind = "cold"
         elif self.success:
             refiner.conf.multiscale = list(self.steady_multiscale)
             refiner.query_mask = self.get_mask(self.pose)  # multiplied inside the first conv
 
         # The masked query is fully known here, before the reference render is encoded: announce
         # it so both images of the frame go through the UNet in one batched pass.
-        if self.batch_frame_images and refiner.conf.multiscale == [1]:
+        if not lockstep and self.batch_frame_images and refiner.conf.multiscale == [1]:
             refiner.feature_extractor.stage(query_image, 1, refiner.query_mask, True)
         else:
             refiner.feature_extractor.unstage()
         # one refinement, at full scale, of a tracked frame: its LM launch can carry the next frame's render(s)
         # behind it (one march when mask and reference views coincide, two renders otherwise)
-        steady = (not self.cold_start and self.success and refiner.query_mask is not None
+        steady = (kind != "cold" and self.success and refiner.query_mask is not None
                   and refiner.conf.multiscale == [1] and len(self.reference_ids) == 1)
         self._ahead = None
         refiner.after_lm_enqueued = self._render_ahead if (self.render_ahead and steady) else None
         refiner.lm_camera = self._lm_camera if (self.render_ahead and steady and self.fused_frame_outputs) else None
-        self.dynamic_id = self.get_dynamic_id(self.pose)
+        return "steady" if steady else kind
+
+    def _frame_pose_init(self) -> Pose:
         rotation, translation = self.pose.numpy()
         rotation = R.from_matrix(rotation).as_matrix()
-        trackers, rets, costs = {}, {}, {}
-        for ref_id in self.reference_ids:
-            pose_init = Pose.from_Rt(rotation, translation)
-            tracker = DebugTracker(refiner, self.debug)
-            ret = self.localizer.run_query(query_path, self.camera, pose_init, [ref_id], image_query=query_image,
-                                           pose=self.pose, reference_images_raw=None, dynamic_id=self.dynamic_id)
-            rets[ref_id] = ret
-            trackers[ref_id] = tracker
-            # mean over (scale, level) runs of the LAST logged cost; taken from the kernel log so it
-            # does not depend on --debug (the reference yields NaN with --debug 0, Appendix D.1)
-            last = [c[-1] for res in refiner.last_lm for c in res.costs if len(c)]
-            costs[ref_id] = float(np.mean(last)) if last else float("nan")
+        return Pose.from_Rt(rotation, translation)
+
+    def _frame_cost(self) -> float:
+        """mean over (scale, level) runs of the LAST logged cost; taken from the kernel log so it
+        does not depend on --debug (the reference yields NaN with --debug 0, Appendix D.1)"""
+        last = [c[-1] for res in self.localizer.refiner.last_lm for c in res.costs if len(c)]
+        return float(np.mean(last)) if last else float("nan")
+
+    def _frame_policy(self, query_path, rets, costs, trackers) -> bool:
+        """The tail of refine() (reference :251-275): best reference by cost, the cost gate frozen from the first
+        frame, pose update, history."""
+        refiner = self.localizer.refiner
         avg_cost = costs[self.reference_ids[-1]]
         if hasattr(self, "pbar") and hasattr(self.pbar, "set_description"):
             self.pbar.set_description(f"Cost: {avg_cost}, Relocalizations: {self.relocalization_count}")

@@ -313,6 +313,21 @@ class PoseTrackerRefiner:
         """pixloc BaseRefiner.refine_pose_using_features on packed buffers: coarse -> fine,
         optimizer[level] per level, all levels in one kernel launch.  ``levels`` (optional) keeps
         only those pyramid levels (conf.level_plan)."""
+        prob = self.lm_problem(features_query, scales_query, qcamera, T_init, ref, levels)
+        pending = PixTrackOptimizer.refine_levels(ref.p3d, prob["packs"], T_init, prob["conf"], self._ws, mask=ref.valid,
+                                                  camera=prob["camera"])
+        # the refinement is enqueued, its result not yet awaited: a caller may queue work behind it that reads the
+        # pose record on the device (the tracker's next render, pixloc_tracker_r9._render_ahead)
+        hook = getattr(self, "after_lm_enqueued", None)
+        if hook is not None:
+            hook(pending)
+        return self.lm_finish(prob, pending.result())
+
+    def lm_problem(self, features_query, scales_query, qcamera: Camera, T_init: Pose, ref: SparseReferenceFeatures,
+                   levels=None) -> Dict:
+        """Everything one refinement's launch needs (levels in execution order, the native configuration, the camera
+        record of a render to be queued behind the launch): what refine_pose_using_features enqueues by itself and what
+        the lock-step multi-object tracker collects from K refiners for ONE batched launch (pxt_lm_refine_batch)."""
         n_levels = len(features_query)
         order = [l for l in reversed(range(n_levels)) if levels is None or l in levels]
         packs = []
@@ -324,14 +339,13 @@ class PoseTrackerRefiner:
         # (a tracker that will queue the next frame's render behind this launch asks for the camera of that render in
         # the kernel's epilogue: pixloc_tracker_r9._lm_camera)
         cam_provider = getattr(self, "lm_camera", None)
-        pending = PixTrackOptimizer.refine_levels(ref.p3d, packs, T_init, opt0.native_conf(), self._ws, mask=ref.valid,
-                                                  camera=cam_provider() if cam_provider is not None else None)
-        # the refinement is enqueued, its result not yet awaited: a caller may queue work behind it that reads the
-        # pose record on the device (the tracker's next render, pixloc_tracker_r9._render_ahead)
-        hook = getattr(self, "after_lm_enqueued", None)
-        if hook is not None:
-            hook(pending)
-        res = pending.result()
+        return {"order": order, "packs": packs, "conf": opt0.native_conf(), "T_init": T_init, "ref": ref,
+                "camera": cam_provider() if cam_provider is not None else None, "workspace": self._ws}
+
+    def lm_finish(self, prob: Dict, res) -> Dict:
+        """The host side after a refinement's result has arrived: log replay into the tracker hooks, the
+        ``{"success", "T_refined", "diff_R", "diff_t"}`` dictionary of pixloc's refine_pose_using_features."""
+        order, packs, T_init, ref = prob["order"], prob["packs"], prob["T_init"], prob["ref"]
         self.last_lm.append(res)
         # replay the iteration log into the tracker hooks, level by level (only when someone listens:
         # DebugTracker ignores everything below debug level 1, tracker.py:33-34)
@@ -357,6 +371,36 @@ class PoseTrackerRefiner:
         d = (b[9] - a[9], b[10] - a[10], b[11] - a[11])
         dt = math.sqrt(sum((a[j] * d[0] + a[3 + j] * d[1] + a[6 + j] * d[2]) ** 2 for j in range(3)))  # |R0^T d|
         return {**ret, "success": True, "T_refined": T_opt, "diff_R": dR, "diff_t": dt}
+
+    # ---- one refinement in two halves (lock-step multi-object tracking) -------------------------------
+    def begin_refine(self, qname: str, qcamera: Camera, pose_init: Pose, dbids: List[int], image_query, dynamic_id):
+        """refine() -> refine_query_pose() of ONE image scale up to, but without, the LM launch: returns
+        ("done", ret) when the reference's early exits apply (too few points), else ("lm", problem) - the problem goes
+        into a batched launch and comes back through finish_refine.  Same calls in the same order as refine()."""
+        fail = {"success": False, "T_init": pose_init, "dbids": dbids}
+        p3dids, _ = self._points_of(dbids)
+        if len(p3dids) < self.conf.min_points_opt:
+            logger.debug("Not enough valid 3D points to optimize")
+            return "done", fail
+        multiscales = self.conf.multiscale or [1]
+        assert len(multiscales) == 1, "lock-step refinement covers one image scale (cold starts run through refine())"
+        image_scale = multiscales[0]
+        features_dict = self.features_dicts[dynamic_id]["features"]
+        self.last_lm = []
+        ref = features_dict[str(image_scale)]
+        maps_q, scales_q = self.dense_feature_extraction(image_query, qname, image_scale, mask=self.query_mask,
+                                                         normalize=True)
+        plan = self.conf.level_plan
+        levels = None if not plan else plan.get(image_scale, plan.get(str(image_scale)))
+        prob = self.lm_problem(maps_q, scales_q, qcamera, pose_init, ref, levels)
+        prob["dbids"], prob["qname"] = dbids, qname
+        return "lm", prob
+
+    def finish_refine(self, prob: Dict, res) -> Dict:
+        ret = self.lm_finish(prob, res)
+        if not ret["success"]:
+            logger.info(f"Optimization failed for query {prob['qname']}")
+        return {**ret, "dbids": prob["dbids"]}
 
 
 class Paths(dict):

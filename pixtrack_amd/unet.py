@@ -304,6 +304,9 @@ class UNet:
         if self.device.type != "cuda":
             raise _lib.PxtError("UNet needs a ROCm device; no CPU path exists")
         blob = pack_unet_weights(weights)
+        import hashlib
+
+        self.weights_signature = hashlib.sha1(blob).hexdigest()  # (lock-step trackers check that they share a checkpoint)
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().pxt_unet_create(blob, len(blob), C.byref(self._ctx)), "pxt_unet_create")
@@ -367,6 +370,12 @@ class UNet:
         ops.unet_forward_batch(int(self._ctx.value), [it[0] for it in items], [it[1] for it in items],
                                [bool(it[2]) for it in items], [o for per in outs for o in per], self._ws)
         return outs
+
+    def set_batch_plan(self, per_image_plan: bool) -> None:
+        """How batches of more than two images plan their layers (pxt_unet_set_batch_plan): False = for the batch as
+        launched (the fastest), True = every layer as a single image of the pair pass (each image's maps bit for bit
+        those of the one-object tracker)."""
+        _lib.check(_lib.lib().pxt_unet_set_batch_plan(self._ctx, int(bool(per_image_plan))), "pxt_unet_set_batch_plan")
 
     def set_defer_join(self, on: bool) -> None:
         """With True, a two-image call returns with the FIRST image's maps complete in the current stream's order and

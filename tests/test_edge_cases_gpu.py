@@ -62,7 +62,7 @@ def test_unet_rejects_images_it_cannot_encode(device):
         net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False),
                                   (torch.zeros(8, 8, 3, device=device), None, False)])
     with pytest.raises(_lib.PxtError):  # PXT_UNET_MAX_BATCH
-        net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False)] * 9)
+        net.forward_packed_batch([(torch.zeros(32, 32, 3, device=device), None, False)] * 17)
 
 
 # ------------------------------------------------------------------ LM degenerate inputs

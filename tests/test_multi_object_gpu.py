@@ -1,0 +1,118 @@
+"""Lock-step multi-object tracking (BASELINE configs[3] on fewer GPUs than objects): K PixLocPoseTrackerR9 states
+advanced together, their 2 K images per step in one batched UNet pass, their K refinements in ONE persistent launch
+(pxt_lm_refine_batch).  Per object the results must be those of the one-object tracker
+(reference: one tracker per object, pixtrack/pose_trackers/pixloc_tracker_r9.py:287-318)."""
+import numpy as np
+import pytest
+import torch
+
+from pixtrack_amd import parallel
+from pixtrack_amd.optimizer import PixTrackOptimizer
+from pixtrack_amd.pose_trackers.multi_object_tracker import MultiObjectTracker
+from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
+
+pytestmark = pytest.mark.gpu
+
+OBJECTS = parallel.load_object_configs()
+
+
+def _make(device, k, w, h, n, spp=4, lm_grid=0):
+    obj = OBJECTS[k]
+    assets = make_tracking_assets(seed=1200 + k, width=w, height=h, n_frames=n, aabb=obj["aabb"], n_points=3000)
+    tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+    tr.spp = spp
+    if lm_grid:
+        for opt in tr.localizer.optimizer:
+            opt.conf.n_workgroups = lm_grid
+    return tr, assets
+
+
+def _poses(tr, names):
+    out = []
+    for nm in names:
+        ret = tr.pose_history[nm]
+        T = ret["T_refined"] if ret.get("success") else ret["T_init"]
+        out.append(np.concatenate([T.as12().double().numpy().reshape(-1), [float(bool(ret.get("success"))), float(ret["cost"])]]))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("per_image_plan,lm_grid", [(True, 32), (False, 0)])
+def test_lockstep_equals_solo_runs(device, per_image_plan, lm_grid):
+    """Four objects (four different config/*.sh boxes), 8 frames each at 320x240.  With the per-image UNet plan and the
+    same LM grid the lock-step poses are BIT-identical to four solo runs; with the defaults (batch-planned layers, 256 / K
+    workgroups per problem) they agree to fp32 summation order."""
+    ks, w, h, n = [1, 2, 5, 7], 320, 240, 8
+    names = [f"{i:06d}.png" for i in range(n)]
+    solo, frames = [], []
+    for k in ks:
+        tr, assets = _make(device, k, w, h, n, lm_grid=lm_grid)
+        fr = render_query_frames(assets, tr.testbed)
+        for i in range(n):
+            tr.run_single_frame((names[i], fr[i]))
+        torch.cuda.synchronize()
+        solo.append(_poses(tr, names))
+        frames.append(fr)
+        assert solo[-1][:, 12].all(), (k, solo[-1][:, 12])
+    trackers = [_make(device, k, w, h, n, lm_grid=lm_grid)[0] for k in ks]
+    multi = MultiObjectTracker(trackers, lm_workgroups=lm_grid, per_image_plan=per_image_plan)
+    for i in range(n):
+        ok = multi.run_single_frames([(names[i], frames[j][i]) for j in range(len(ks))])
+        assert all(ok), (i, ok)
+    torch.cuda.synchronize()
+    assert multi.solo_frames == len(ks) and multi.lockstep_frames == len(ks) * (n - 1)  # only the cold starts ran alone
+    for j, tr in enumerate(trackers):
+        got = _poses(tr, names)
+        assert tr.renders_ahead_used >= n - 3, tr.renders_ahead_used  # the queued renders are used in lock-step too
+        if per_image_plan:
+            assert np.array_equal(got.view(np.uint64), solo[j].view(np.uint64)), (ks[j], np.abs(got - solo[j]).max())
+        else:
+            assert np.abs(got[:, :12] - solo[j][:, :12]).max() < 1e-4, (ks[j], np.abs(got - solo[j]).max())
+            assert np.array_equal(got[:, 12], solo[j][:, 12])
+
+
+def test_lm_batch_equals_single_launches(device):
+    """pxt_lm_refine_batch against K pxt_lm_refine launches with the same grid: every record bit-identical - pose,
+    iteration counts and the iteration log - for problems of different sizes, one of them failing (no valid point)."""
+    from test_lm_gpu import CONSTS, lambdas, pack_level  # the LM tests' packing of a synthetic scene
+
+    from pixtrack_amd import _lib
+    from pixtrack_amd.optimizer import LevelPack
+    from pixtrack_amd.synthetic import make_lm_scene
+
+    K, grid = 5, 24
+    lam = lambdas(CONSTS)
+    opt = PixTrackOptimizer(dict(num_iters=150, pad=1, n_workgroups=grid))
+    conf = opt.native_conf()
+    n_ws = int(_lib.lib().pxt_lm_workspace_bytes())
+    probs, singles = [], []
+    for k in range(K):
+        sc = make_lm_scene(seed=1040 + k, width=256, height=192, n_points=700 + 331 * k, sigma_px=2.0)
+        packs = []
+        for level in reversed(range(3)):
+            fmap, fref, Cc, cam = pack_level(sc, level, device, sc.camera)
+            packs.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+        p3d = torch.from_numpy(sc.p3d).float().to(device)
+        valid = torch.ones(p3d.shape[0], dtype=torch.uint8, device=device)
+        if k == 3:
+            valid.zero_()  # fewer than 10 valid points: failed = True
+        ws = torch.zeros(n_ws, dtype=torch.uint8, device=device)
+        singles.append(PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, conf, ws, mask=valid).result())
+
+        class Ref:
+            pass
+
+        ref = Ref()
+        ref.p3d, ref.valid = p3d, valid
+        probs.append({"ref": ref, "packs": packs, "T_init": sc.T_init, "workspace": torch.zeros_like(ws), "camera": None,
+                      "conf": conf})
+    bws = torch.zeros(int(_lib.lib().pxt_lm_batch_workspace_bytes(K)), dtype=torch.uint8, device=device)
+    for _ in range(2):  # (twice: the second launch continues the workspaces' tags)
+        handles = PixTrackOptimizer.refine_levels_batch(probs, conf, bws)
+        for k, (h, one) in enumerate(zip(handles, singles)):
+            res = h.result()
+            assert res.failed == one.failed and res.iters == one.iters, (k, res.iters, one.iters)
+            assert torch.equal(res.T.as12(), one.T.as12()), k
+            for l, n in enumerate(one.iters):
+                assert torch.equal(res.log[l, :n], one.log[l, :n]), (k, l)
+    assert singles[3].failed and not singles[0].failed
