@@ -48,11 +48,104 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# commits at which the committed rocprofv3 PMC summaries were collected (files without a `_meta` record)
+PROFILE_COMMITS = {"r04": "57b838f", "r03": "a686fc1", "r02": "2a1bccf"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
 # the dominant kernel: gathers + both MLPs of a round's samples (Shade + Depth of the same rays: MODE 2)
 GATHER_KERNEL = "ngp_shade_kernel<2> (hash-grid gathers + MLPs of its own samples)"
 GATHER_KERNEL_PMC = "pxt::ngp_shade_kernel<2>"
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def unet_gflop(H, W):
+    """2 * 9 * Cin * Cout * h * w over the 17 3x3 convolutions of one image (241.4 at 640x480; the 1x1 heads
+    add 0.5 % and are not counted)."""
+    from pixtrack_amd.unet import conv_layer_dims
+
+    hs = [(H >> i, W >> i) for i in range(5)]
+    dec = [(hs[4][0] * 2 ** (d + 1), hs[4][1] * 2 ** (d + 1)) for d in range(4)]
+    res = [hs[0]] * 2 + [hs[1]] * 2 + [hs[2]] * 3 + [hs[3]] * 3 + [hs[4]] * 3 + dec
+    return sum(2 * 9 * cin * cout * h * w for (cin, cout), (h, w) in zip(conv_layer_dims(), res)) / 1e9
+
+
+def lm_algorithmic_mb(n_points, iters, channels):
+    """SURVEY 8d per iteration and level: N * (12 * C' * 4 + 12 + C' * 4) bytes, C' = C + 1, summed over the iterations
+    each level ran."""
+    return sum(it * n_points * (12 * (c + 1) * 4 + 12 + (c + 1) * 4) for it, c in zip(iters, channels)) / 1e6
+
+
+def stage_rooflines(tracker, frames, names, lo, hi, dev):
+    """Live per-stage rooflines of the UNet and the LM from an untimed pass over frames[lo:hi]:
+    HIP events around the frame's two-image UNet call with the join INSIDE the call, and around the LM launch; render-ahead
+    off so that nothing rides behind the LM kernel.  UNet: GFLOP of the sizes actually run / ms against the dense fp16 MFMA
+    peak; LM: algorithmic bytes of the iterations the kernel log reports / kernel time against the HBM peak."""
+    from pixtrack_amd.optimizer import PixTrackOptimizer
+
+    ex = tracker.localizer.extractor
+    model = ex.model
+    ev_unet, ev_lm, sizes, lm_meta = [], [], [], []
+    orig_fwd, orig_lm = model.forward_packed_batch, PixTrackOptimizer.refine_levels
+    defer0, ahead0 = ex.defer_join, tracker.render_ahead
+
+    def fwd(items):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_fwd(items)
+        e1.record()
+        ev_unet.append((e0, e1))
+        sizes.append([(int(it[0].shape[0]), int(it[0].shape[1])) for it in items])
+        return out
+
+    def lm(p3d, levels, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pend = orig_lm(p3d, levels, *a, **k)
+        e1.record()
+        ev_lm.append((e0, e1))
+        lm_meta.append((int(p3d.shape[0]), [int(lp.C) for lp in levels]))
+        return pend
+
+    model.forward_packed_batch = fwd
+    PixTrackOptimizer.refine_levels = staticmethod(lm)
+    ex.defer_join = False
+    tracker.render_ahead = False
+    tracker._ahead_ok = None
+    iters = []
+    try:
+        torch.cuda.synchronize()
+        for i in range(lo, hi):
+            tracker.run_single_frame((names[i], frames[i]))
+            iters.append([list(r.iters) for r in tracker.localizer.refiner.last_lm])
+        torch.cuda.synchronize()
+    finally:
+        model.forward_packed_batch = orig_fwd
+        PixTrackOptimizer.refine_levels = staticmethod(orig_lm)
+        ex.defer_join, tracker.render_ahead = defer0, ahead0
+    out = {}
+    if ev_unet:
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev_unet]))
+        gf = float(np.mean([sum(unet_gflop(h, w) for h, w in sz) for sz in sizes]))
+        out["unet"] = {"bound": "mfma", "gflop_per_call": round(gf, 1), "image_sizes_hw": sizes[-1], "ms": round(ms, 4),
+                       "achieved": round(gf / ms, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(gf / ms / MFMA_PEAK_TFLOPS, 4), "calls": len(ev_unet),
+                       "what": "the frame's UNet call (both images, join inside), HIP events, untimed pass"}
+    if ev_lm:
+        us = [a.elapsed_time(b) * 1e3 for a, b in ev_lm]
+        flat = [it for per in iters for it in per]
+        mb = [lm_algorithmic_mb(n, it, ch) for (n, ch), it in zip(lm_meta, flat)]
+        n_it = [sum(it) for it in flat]
+        tbs = float(np.sum(mb)) / float(np.sum(us))  # MB / us = TB/s
+        out["lm"] = {"bound": "hbm", "iterations_per_level_mean": [round(float(x), 2) for x in np.mean(np.array(flat, float), 0)],
+                     "level_channels": lm_meta[-1][1], "n_points": lm_meta[-1][0],
+                     "algorithmic_mb": round(float(np.mean(mb)), 2), "kernel_us": round(float(np.mean(us)), 2),
+                     "us_per_iteration": round(float(np.sum(us)) / max(int(np.sum(n_it)), 1), 2),
+                     "achieved": round(tbs * 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(tbs * 1e3 / HBM_PEAK_GBS, 4), "launches": len(ev_lm),
+                     "what": "lm_refine_kernel, HIP events around the launch, iterations from the kernel's own log"}
+    return out
 
 
 class StageTimer:
@@ -82,7 +175,7 @@ class StageTimer:
         return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.events.items()}
 
 
-def cpu_baseline(assets, frames, first, ref_id, budget_s=70.0, max_frames=20, min_frames=5):
+def cpu_baseline(assets, frames, first, ref_id, budget_s=70.0, max_frames=20, min_frames=5, warmup_frames=1):
     """The CPU oracle ("port" of the reference PyTorch-CPU path) on a bounded sample of the same
     workload, on the GPU box's host cores: whole frames of `oracle.frame_oracle.track_frame` at FULL size - depth
     render (mask) + RGB render (reference) + UNet x2 + sparse sampling + LM - frame `first + k` tracked from the
@@ -113,7 +206,7 @@ def cpu_baseline(assets, frames, first, ref_id, budget_s=70.0, max_frames=20, mi
         assert tiled_identical, "tiled oracle render differs from the serial oracle"
         per_frame, stage_s, ok = [], {}, 0
         t_start = time.perf_counter()
-        for k in range(max_frames + 1):  # k = 0: warm-up (thread pools, allocator, worker start-up)
+        for k in range(max_frames + warmup_frames):  # k < warmup_frames: warm-up (thread pools, allocator, worker start-up)
             i = first + 1 + k
             if i >= len(frames) or i >= len(gt):
                 break
@@ -122,7 +215,7 @@ def cpu_baseline(assets, frames, first, ref_id, budget_s=70.0, max_frames=20, mi
             t0 = time.perf_counter()
             ret = FO.track_frame(assets, gt[i - 1][0], gt[i - 1][1], img, ref_id, multiscale=(1,), use_mask=True, timings=tm)
             dt = time.perf_counter() - t0
-            if k == 0:
+            if k < warmup_frames:
                 continue
             per_frame.append(dt)
             ok += int(bool(ret["success"]))
@@ -148,7 +241,11 @@ def cpu_baseline(assets, frames, first, ref_id, budget_s=70.0, max_frames=20, mi
         "stage_seconds_per_frame": {k: round(v / n, 3) for k, v in stage_s.items()},
         "tiled_render_bit_identical_to_serial": tiled_identical,
         "one_render_seconds": round(t_one_render, 2), "samples_per_render": int(st["samples"]),
-        "sample": (f"{n} whole 640x480 frames after 1 warm-up frame (oracle.frame_oracle.track_frame: depth + RGB NeRF renders at "
+        "warmup_frames": warmup_frames, "render_pool_degraded_to_serial": bool(NO._POOL.get("degraded")),
+        "baseline_md_section_3": ("to the letter (3 warm-up + >= 20 frames)" if warmup_frames >= 3 and n >= 20 else
+                                  f"bounded sample ({warmup_frames} warm-up + {n} frames: the default run keeps the whole bench "
+                                  "within a few minutes; `--cpu-baseline-frames 20` runs 3 + 20)"),
+        "sample": (f"{n} whole 640x480 frames after {warmup_frames} warm-up frame(s) (oracle.frame_oracle.track_frame: depth + RGB NeRF renders at "
                    f"full size, spp 8, UNet x2, sparse sampling, LM), mean {t_frame:.2f} s/frame; every stage on {n_threads} of the "
                    f"{os.cpu_count()} host CPUs (NeRF rows dealt to {n_threads} processes - bit-identical to the serial oracle, "
                    f"asserted; UNet / LM on {n_threads} torch threads)"),
@@ -413,6 +510,157 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
     print(json.dumps(out), flush=True)
 
 
+def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
+    """BASELINE configs[3]: the eight objects of the reference's config/*.sh tracked CONCURRENTLY on N GPUs - rank r carries
+    objects r, r + N, ... (8 / N per rank), advanced in lock-step by a MultiObjectTracker: their 2 K images of a step in one
+    batched UNet pass, their K refinements in one persistent launch (pxt_lm_refine_batch), one renderer context per object.
+    A step = one frame of every object of the rank; value = frames of all 8 objects / slowest rank's time (the work is
+    the same 8 objects whatever N: "strong" scaling).  At N = 1 an untimed second pass tracks the same frames with
+    eight one-object trackers, one after the other, for the comparison the line carries (solo aggregate, pose differences)."""
+    import gc
+
+    from pixtrack_amd import parallel
+    from pixtrack_amd.pose_trackers.multi_object_tracker import MultiObjectTracker
+    from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+    from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
+
+    objs = parallel.load_object_configs()
+    units = parallel.shard_units(len(objs), rank, ws)
+    n = args.warmup + args.steps
+    n_diag = 4
+    names = [f"{i:06d}.png" for i in range(n + n_diag)]
+    assets = {u: make_tracking_assets(seed=1002 + u, width=args.width, height=args.height, n_frames=n + n_diag,
+                                      aabb=objs[u]["aabb"]) for u in units}
+
+    def fresh(u):
+        return PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets[u])
+
+    trackers = [fresh(u) for u in units]
+    frames = {u: render_query_frames(assets[u], tr.testbed) for u, tr in zip(units, trackers)}
+    multi = MultiObjectTracker(trackers, lm_workgroups=args.lm_grid, per_image_plan=args.per_image_plan)
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    for i in range(args.warmup):
+        multi.run_single_frames([(names[i], frames[u][i]) for u in units])
+    if ws > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n):
+        multi.run_single_frames([(names[i], frames[u][i]) for u in units])
+    torch.cuda.synchronize()
+    if ws > 1:
+        torch.distributed.barrier()
+    own = time.perf_counter() - t0
+    gc.enable()
+    elapsed = parallel.max_over_ranks(own, coll_dev)
+    report = rank_report(rank, dev.index, dev, numa_node, args.steps * len(units), own, coll_dev)
+    timed = names[args.warmup:n]
+    recs = [parallel.pack_pose_records(tr.pose_history, timed) for tr in trackers]
+    gathered = parallel.gather_pose_records(torch.cat(recs).to(coll_dev), coll_dev)  # the one collective (RCCL)
+    units_all = parallel.gather_objects(units)
+    n_ok = int(sum(float(g[:, 12].sum()) for g in gathered))
+    total_frames = sum(g.shape[0] for g in gathered)
+    # untimed: per-phase HIP-event times of a lock-step step (render-ahead off: nothing rides behind the LM launch) and the
+    # live rooflines of the batched UNet pass and the batched LM launch
+    ahead = [tr.render_ahead for tr in trackers]
+    for tr in trackers:
+        tr.render_ahead = False
+        tr._ahead_ok = None
+    phases, lm_iters = [], []
+    for i in range(n, n + n_diag):
+        multi.timing = {}
+        multi.run_single_frames([(names[i], frames[u][i]) for u in units])
+        torch.cuda.synchronize()
+        t = multi.timing
+        order = ["step_begin", "renders_enqueued", "unet_enqueued", "sampling_enqueued", "lm_enqueued", "step_end"]
+        phases.append([t[a][0].elapsed_time(t[b][0]) for a, b in zip(order[:-1], order[1:])])
+        lm_iters.append([[list(r.iters) for r in tr.localizer.refiner.last_lm][0] for tr in trackers])
+    multi.timing = None
+    for tr, a in zip(trackers, ahead):
+        tr.render_ahead = a
+    ph = np.mean(np.array(phases[1:]), 0)  # (the first diagnostic step still consumed queued renders)
+    K = len(units)
+    gf = 2 * K * unet_gflop(args.height, args.width)
+    n_pts = [int(tr.localizer.refiner._points_of(tr.reference_ids)[1].shape[0]) for tr in trackers]
+    lm_mb = float(np.mean([sum(lm_algorithmic_mb(npt, it, [128, 128, 32]) for npt, it in zip(n_pts, per)) for per in lm_iters[1:]]))
+    stages = {
+        "phase_ms_per_step": {"renders": round(float(ph[0]), 4), "unet": round(float(ph[1]), 4), "sampling": round(float(ph[2]), 4),
+                              "lm": round(float(ph[3]), 4), "host_policy": round(float(ph[4]), 4)},
+        "unet": {"bound": "mfma", "images_per_call": 2 * K, "gflop_per_call": round(gf, 1), "ms": round(float(ph[1]), 4),
+                 "achieved": round(gf / float(ph[1]), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(gf / float(ph[1]) / MFMA_PEAK_TFLOPS, 4), "ms_per_image_pair": round(float(ph[1]) / K, 4)},
+        "lm": {"bound": "hbm", "problems_per_launch": K, "algorithmic_mb": round(lm_mb, 1), "kernel_us": round(float(ph[3]) * 1e3, 1),
+               "us_per_problem": round(float(ph[3]) * 1e3 / K, 1), "achieved": round(lm_mb / (float(ph[3]) * 1e3) * 1e3, 1),
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(lm_mb / (float(ph[3]) * 1e3) * 1e3 / HBM_PEAK_GBS, 4),
+               "iterations_per_level_mean": [round(float(x), 2) for x in np.mean(np.array(lm_iters[1:], float), (0, 1))]},
+        "what": "HIP events between the phases of an untimed lock-step step (render-ahead off), mean of 3 steps",
+    }
+    solo = None
+    if ws == 1 and not args.no_solo:
+        # the same frames through eight ONE-object trackers, one after the other: what the lock-step run is compared with
+        fps, diffs = [], []
+        for u, tr_multi in zip(units, trackers):
+            tr = fresh(u)
+            gc.collect()
+            gc.disable()
+            for i in range(args.warmup):
+                tr.run_single_frame((names[i], frames[u][i]))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.warmup, n):
+                tr.run_single_frame((names[i], frames[u][i]))
+            torch.cuda.synchronize()
+            fps.append(args.steps / (time.perf_counter() - t1))
+            gc.enable()
+            a = parallel.pack_pose_records(tr.pose_history, timed)[:, :12]
+            b = parallel.pack_pose_records(tr_multi.pose_history, timed)[:, :12]
+            diffs.append(float((a - b).abs().max()))
+            del tr
+        agg = len(units) * args.steps / sum(args.steps / f for f in fps)
+        solo = {"frames_per_s_per_object": [round(f, 1) for f in fps], "aggregate_frames_per_s": round(agg, 2),
+                "lockstep_speedup": round(total_frames / elapsed / agg, 3),
+                "max_abs_pose_difference_vs_lockstep": [float(f"{d:.3g}") for d in diffs],
+                "what": "untimed second pass: the same frames tracked by one-object trackers one after the other (aggregate = "
+                        "all frames / summed time); pose difference = largest |element| difference of the 12 pose floats"}
+    if rank != 0:
+        return
+    rot, tra = [], []
+    for tr, u in zip(trackers, units):
+        for k, nm in enumerate(timed):
+            ret = tr.pose_history[nm]
+            if ret.get("success"):
+                Rr, tt = ret["T_refined"].numpy()
+                Rg, tg = assets[u]["gt_poses"][args.warmup + k]
+                rot.append(float(np.arccos(np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1))))
+                tra.append(float(np.linalg.norm(tt - tg)))
+    out = {
+        "metric": "tracked frames/sec at 640x480 (8 objects of config/*.sh tracked concurrently; full NeRF render + UNet + LM loop)",
+        "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp16 storage / fp32 accumulate (UNet, NeRF MLPs); fp32 (LM)",
+        "data": "synthetic (seeded hash-grid NeRF, He-init UNet, NeRF-rendered query frames + noise)",
+        "config": {"workload": (f"configs[3]: the 8 objects of config/*.sh tracked concurrently on {ws} GPU(s), {len(units)} per rank in "
+                                "lock-step (batched UNet pass + one persistent LM launch per step), 640x480, full loop; a step = one "
+                                "frame of every object"),
+                   "objects_per_rank": [[objs[u]["name"] for u in us] for us in units_all], "width": args.width,
+                   "height": args.height, "spp": 8, "lm_workgroups_per_problem": args.lm_grid, "unet_per_image_plan": bool(args.per_image_plan),
+                   "host_numa_node": numa_node},
+        "tracked_ok": n_ok, "frames_total": total_frames,
+        "per_object_frames_per_s": round(args.steps / elapsed, 3),
+        "lockstep_frames": int(multi.lockstep_frames), "solo_frames_inside_lockstep": int(multi.solo_frames),
+        "renders_ahead_used": [int(tr.renders_ahead_used) for tr in trackers],
+        "mean_rot_err_vs_gt_rad": round(float(np.mean(rot)), 6) if rot else None,
+        "mean_trans_err_vs_gt": round(float(np.mean(tra)), 6) if tra else None,
+        "roofline": None, "roofline_stages": stages, "solo_runs": solo,
+        "cpu_baseline": {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                         "sample": "reported with the frames640 workload only"},
+        **report,
+    }
+    print(json.dumps(out), flush=True)
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run with
     N ranks on this node (one per GPU; rendezvous on 127.0.0.1, a free port) and return its exit code.
@@ -469,8 +717,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra passes (two renders, host frames, K=200)")
     ap.add_argument("--config", choices=["frames640", "objects8", "hd"], default="frames640")
-    ap.add_argument("--object-index", type=int, default=0,
-                    help="objects8: rank r tracks object (object-index + r) mod 8 of config/*.sh (default: object r)")
+    ap.add_argument("--object-index", type=int, default=-1,
+                    help="objects8: ONE object per rank, rank r tracking object (object-index + r) mod 8 of config/*.sh; default "
+                         "(-1): all eight objects, dealt round-robin to the ranks and tracked in lock-step per rank")
+    ap.add_argument("--lm-grid", type=int, default=0, help="objects8 lock-step: LM workgroups per problem (0: 256 / K)")
+    ap.add_argument("--per-image-plan", action="store_true",
+                    help="objects8 lock-step: UNet layers planned per image (maps bit-identical to the one-object tracker)")
+    ap.add_argument("--no-solo", action="store_true", help="objects8 lock-step at N = 1: skip the one-object comparison pass")
+    ap.add_argument("--cpu-baseline-frames", type=int, default=0,
+                    help="CPU baseline: track exactly this many frames after 3 warm-up frames (BASELINE.md 3 asks for >= 20); "
+                         "0 = as many as fit the default ~70 s budget after 1 warm-up frame")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: spawn the N ranks ourselves
@@ -501,12 +757,16 @@ def main():
 
     if args.config == "hd":
         return run_hd(args, rank, ws, dev, coll_dev, numa_node)
+    if args.config == "objects8" and args.object_index < 0 and ws < 8:
+        return run_objects8(args, rank, ws, dev, coll_dev, numa_node)
+    args.object_index = max(args.object_index, 0)
 
     n_diag = min(20, args.steps)  # untimed diagnostic pass (per-stage HIP-event times)
+    n_roof = 8                    # untimed pass of the per-stage rooflines (UNet TFLOP/s, LM TB/s)
     n_timed_end = args.warmup + args.steps
     extras_on = ws == 1 and not args.no_extras and args.config == "frames640"
     n_extra = 200 if extras_on else 0
-    n_frames = n_timed_end + n_diag + n_extra
+    n_frames = n_timed_end + n_diag + n_roof + n_extra
     unit = parallel.shard_units(ws, rank, ws)[0]  # one sequence per rank, seeds 1002, 1003, ...
     obj = None
     if args.config == "objects8":  # BASELINE configs[3]: one object of the reference's config/*.sh per rank
@@ -600,10 +860,12 @@ def main():
     iso_samples = iso_stats[0] - iso_stats[3]
     iso_renders = tracker.testbed.n_renders - n_renders1
     tracker.render_ahead = render_ahead
+    # (3) live rooflines of the other two stages (the UNet is ~47 % of the frame, the LM ~6 %)
+    roofline_stages = stage_rooflines(tracker, frames, names, n_timed_end + n_diag, n_timed_end + n_diag + n_roof, dev)
 
     extras = None
     if extras_on:
-        extras = run_extras(tracker, assets, frames, names, args.warmup, n_timed_end, n_timed_end + n_diag, dev)
+        extras = run_extras(tracker, assets, frames, names, args.warmup, n_timed_end, n_timed_end + n_diag + n_roof, dev)
 
     records = parallel.pack_pose_records(tracker.pose_history, names[args.warmup:n_timed_end])
     gathered = parallel.gather_pose_records(records.to(coll_dev), coll_dev)  # the one collective (RCCL)
@@ -638,9 +900,11 @@ def main():
     # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes of this command
     # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be taken live here)
     traffic, traffic_src = None, None
-    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (4, 3, 2)) if q.exists()), None)
+    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (5, 4, 3, 2)) if q.exists()), None)
+    static_commit = None
     if pmc is not None:
         recs = json.loads(pmc.read_text())
+        static_commit = (recs.get("_meta") or {}).get("collected_at_commit") or PROFILE_COMMITS.get(pmc.name[:3])
         rec = (recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
                or recs.get("void pxt::ngp_shade_kernel<2, true>"))  # (the round-2 name of the same kernel)
         if rec:
@@ -653,7 +917,7 @@ def main():
     # not HBM bytes - the fabric side moves ~0.35 x the algorithmic bytes - but the L1's miss path: requests to the L2
     # x their latency.  `l2` prices the kernel against the L2's own peak as well.
     l2 = None
-    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (4, 3)) if q.exists()), None)
+    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (5, 4, 3)) if q.exists()), None)
     if l2f is not None:
         recs = json.loads(l2f.read_text())
         rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
@@ -667,10 +931,15 @@ def main():
                                                   if rec.get("TCP_TCC_READ_REQ_LATENCY_sum") else None),
                   "l2_hit_rate": (round(rec["TCC_HIT_sum"] / max(rec["TCC_HIT_sum"] + rec.get("TCC_MISS_sum", 0.0), 1.0), 3)
                                   if rec.get("TCC_HIT_sum") else None),
-                  "source": f"profiles/{l2f.name}"}
+                  "source": f"profiles/{l2f.name}", "static": True,
+                  "static_note": "request counts read from the committed rocprofv3 pass, priced with this run's live launch time",
+                  "collected_at_commit": (recs.get("_meta") or {}).get("collected_at_commit") or PROFILE_COMMITS.get(l2f.name[:3])}
     roofline = {"kernel": GATHER_KERNEL, "bound": "hbm", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_unit": "MB per launch", "traffic_source": traffic_src,
+                "traffic_static": {"static": True, "collected_at_commit": static_commit,
+                                   "note": "FETCH_SIZE / WRITE_SIZE need their own rocprofv3 passes: read from the committed "
+                                           "profile, not measured by this run (achieved / frac / avg_launch_ms / samples ARE live)"},
                 "algorithmic_mb_per_launch": round(samples_per_launch * NERF_BYTES_PER_SAMPLE / 1e6, 2),
                 "avg_launch_ms": round(enc_avg_ms, 5), "launches_timed": enc_launches, "launches": launches_total,
                 "samples_per_launch": round(samples_per_launch, 1), "bytes_per_sample": NERF_BYTES_PER_SAMPLE,
@@ -721,25 +990,35 @@ def main():
                           "reference pass ends on the caller's stream - the query pass is joined behind the sparse sampling "
                           "(deferred join), so its last ~20-40 us are booked to `sample` / `lm`"),
         "roofline": roofline,
+        "roofline_stages": roofline_stages,
         **report,
     }
     # other kernels' utilisation from the committed rocprofv3 SQ counter pass of this command
     # (profiles/r02_pmc_sq.json; scripts/pmc_sq_summary.py): matrix-pipe busy of the UNet convolutions,
     # VALU busy of the march (a serial DDA per ray: latency- and tail-bound, not VALU-bound)
-    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (4, 3, 2)) if q.exists()), None)
+    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (5, 4, 3, 2)) if q.exists()), None)
     if sq is not None:
         rec = json.loads(sq.read_text())
         pick = {}
         for name, r in rec.items():
+            if name == "_meta":
+                continue
             if "conv3x3_v" in name or "ngp_compact_march" in name or "ngp_shade" in name or "lm_refine" in name:
                 pick[name.replace("void pxt::", "").replace("pxt::", "")] = {
                     k: round(r[k], 4) for k in ("mfma_busy", "valu_busy", "mean_waves_per_simd") if k in r}
-        out["kernel_utilisation"] = {"source": f"profiles/{sq.name} (rocprofv3 --pmc SQ_*, same command)", "kernels": pick}
+        out["kernel_utilisation"] = {"source": f"profiles/{sq.name} (rocprofv3 --pmc SQ_*, same command)", "static": True,
+                                     "collected_at_commit": (rec.get("_meta") or {}).get("collected_at_commit")
+                                     or PROFILE_COMMITS.get(sq.name[:3]), "kernels": pick}
     if extras is not None:
         out["extras"] = extras
     if not args.no_cpu_baseline and ws == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(assets, frames, args.warmup, ref_id_start)
+            if args.cpu_baseline_frames > 0:  # BASELINE.md 3 to the letter: 3 warm-up frames, then exactly this many
+                out["cpu_baseline"] = cpu_baseline(assets, frames, args.warmup, ref_id_start, budget_s=1e9,
+                                                   max_frames=args.cpu_baseline_frames, min_frames=args.cpu_baseline_frames,
+                                                   warmup_frames=3)
+            else:
+                out["cpu_baseline"] = cpu_baseline(assets, frames, args.warmup, ref_id_start)
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {e!r}"}

@@ -16,7 +16,15 @@ specification the HIP kernel is tested against:
 * rays through pixel centres, principal point at the image centre, fov from fx on x;
 * radial k1 lens handled by 8 fixed-point un-distortion iterations;
 * per-(pixel, spp) start jitter u in [0,1) from an integer hash (`start_jitter`);
-* dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 2^(cascades-1) * 8);
+* dt = clamp(t * cone_angle, sqrt(3)/1024, sqrt(3)/1024 * 2^(cascades-1) * 8)   [calc_dt: matches upstream's
+  MIN_/MAX_CONE_STEPSIZE up to the cascade count - builder decision: the model's, not the compile-time 8; no effect
+  inside a render box, DESIGN.md section 4];
+* cascade of a sample = min(max_cascade, max(mip_from_pos, frexp-exponent of dt * 2 * 128))   [mip_from_dt: matches
+  upstream since round 5; rounds 1-4 used dt * 128];
+* mip_from_pos = clamp(frexp-exponent of max|pos - 0.5| + 1, 0, max_cascade)   [matches];
+* advance_to_next_voxel: t += calc_dt(t) repeated until t passes the DDA exit of the current cascade cell
+  (distance_to_next_voxel with the floor(p + 0.5 + 0.5 sign(d)) form)   [matches the b551bf1-era do / while loop; later
+  upstream versions step analytically in "stepping space" - builder decision: the loop, the checkout is from 2022];
 * occupancy bitfield: one bit per 128^3 cell, x fastest, cascades concatenated;
 * empty cells are skipped by stepping t in dt increments to the next voxel border;
 * hash grid: tcnn layout (dense below 2^19 entries, else the 3-prime xor hash),
@@ -84,7 +92,7 @@ def grid_level_layout(m: NgpModel) -> List[Tuple[float, int, int, int, bool]]:
 
 # Switches for scripts/renderer_decisions.py ONLY (the measured effect of every recall-level decision of
 # this file).  The defaults ARE the specification; no test or product path changes them.
-VARIANT = {"jitter": "hash", "undistort_iters": 8, "max_step_cascades": None}
+VARIANT = {"jitter": "hash", "undistort_iters": 8, "max_step_cascades": None, "mip_dt_factor": 2 * GRID}
 
 
 def max_step(m: NgpModel) -> np.float32:
@@ -135,7 +143,11 @@ def mip_from_pos(pos: np.ndarray, cascades: int) -> np.ndarray:
 
 
 def mip_from_dt(dt: np.ndarray, pos: np.ndarray, cascades: int) -> np.ndarray:
-    _, e = np.frexp(dt * F32(GRID))
+    """instant-ngp nerf_device.cuh mip_from_dt: `dt *= 2 * NERF_GRIDSIZE(); if (dt < 1) return mip_from_pos;
+    frexpf(dt, &e); return min(max_cascade, max(e, mip))` - the cascade whose cell a step of dt spans HALF of.  (The
+    `dt < 1` guard is what max(e, mip) does anyway: e <= 0 there and mip >= 0.)  Rounds 1-4 had the factor as
+    NERF_GRIDSIZE() - one cascade finer wherever t >= 1: VARIANT["mip_dt_factor"] = 128 renders that."""
+    _, e = np.frexp(dt * F32(VARIANT["mip_dt_factor"]))
     return np.minimum(cascades - 1, np.maximum(e, mip_from_pos(pos, cascades))).astype(np.int32)
 
 
@@ -447,7 +459,10 @@ def _render_rows_job(job):
 def close_pool():
     """Ends the worker processes render_parallel keeps between calls."""
     pool = _POOL.pop("pool", None)
+    degraded = _POOL.get("degraded")
     _POOL.clear()
+    if degraded:
+        _POOL["degraded"] = True
     _PAR.pop("m", None)
     if pool is not None:
         pool.terminate()
@@ -486,7 +501,19 @@ def render_parallel(m: NgpModel, v: View, procs: int, return_stats: bool = False
         sets = [np.arange(r, min(r + rows_per_job, v.height)) for r in range(0, v.height, rows_per_job)]
     else:
         sets = [np.arange(k, v.height, procs) for k in range(min(procs, v.height))]
-    parts = _POOL["pool"].map(_render_rows_job, [(v, rs) for rs in sets], chunksize=1)
+    # The workers are forked from a process that may hold a GPU context and OpenMP / BLAS thread pools (bench.py's
+    # cpu_baseline runs after the GPU loop): a child can inherit a held lock and never answer.  The wait is
+    # bounded; after a time-out the pool is dropped and this and every later render of the process run serially, so a
+    # baseline figure always comes out (it then says `render_processes: 1`).
+    if _POOL.get("degraded"):
+        return render(m, v, return_stats)
+    try:
+        parts = _POOL["pool"].map_async(_render_rows_job, [(v, rs) for rs in sets], chunksize=1).get(
+            timeout=float(os.environ.get("PXT_ORACLE_POOL_TIMEOUT", "900")))
+    except mp.TimeoutError:
+        close_pool()
+        _POOL["degraded"] = True
+        return render(m, v, return_stats)
     img = np.empty((v.height, v.width, 4), np.float32)
     stats = {"samples": 0, "rays_hit": 0}
     for rs, (part, st) in parts:

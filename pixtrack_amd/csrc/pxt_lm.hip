@@ -954,10 +954,13 @@ __global__ __launch_bounds__(kLmBlock) void lm_refine_kernel(const LmParams P) {
 // times in a row.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, so with K = 8 a problem's
 // workgroups share one XCD (its L2 then holds that problem's maps); nothing depends on it.  The problems' parameter
 // records live in device memory (8 x ~1 KB exceeds the kernel-argument segment): uniform scalar loads.
-__global__ __launch_bounds__(kLmBlock) void lm_refine_batch_kernel(const LmParams* __restrict__ params, const int K) {
+__global__ __launch_bounds__(kLmBlock) void lm_refine_batch_kernel(const LmParams* __restrict__ params, const int K,
+                                                                   const int contiguous) {
   __shared__ LmShared sh;
-  const int p = (int)blockIdx.x % K;
-  lm_refine_problem(params[p], LmGrid{(int)gridDim.x / K, (int)blockIdx.x / K}, sh);
+  const int G = (int)gridDim.x / K;
+  const int p = contiguous ? (int)blockIdx.x / G : (int)blockIdx.x % K;
+  const int b = contiguous ? (int)blockIdx.x % G : (int)blockIdx.x / K;
+  lm_refine_problem(params[p], LmGrid{G, b}, sh);
 }
 
 // ---------------------------------------------------------------------------
@@ -1130,7 +1133,7 @@ int lm_fill_params(LmParams& P, const float* p3d, const uint8_t* point_mask, int
 // once: never more workgroups than the device (or the partition / CU mask this process sees) can hold.  Several
 // trackers of one process may run their LM kernels side by side (tests: three), so a launch takes at most half of
 // the resident slots.  Cached per thread and device.
-int lm_resident_cap(int* cap) {
+int lm_resident_cap(int* cap, bool whole_device = false) {
   static thread_local int resident_cap[16] = {0};
   int dev_id = 0;
   PXT_HIP_CHECK(hipGetDevice(&dev_id));
@@ -1140,9 +1143,9 @@ int lm_resident_cap(int* cap) {
     int per_cu = 0, cus = 0;
     PXT_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lm_refine_batch_kernel, kLmBlock, 0));
     PXT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
-    resident_cap[dev_id] = per_cu * cus > 1 ? per_cu * cus / 2 : 1;
+    resident_cap[dev_id] = per_cu * cus > 1 ? per_cu * cus : 1;
   }
-  *cap = resident_cap[dev_id];
+  *cap = whole_device ? resident_cap[dev_id] : std::max(1, resident_cap[dev_id] / 2);
   return PXT_OK;
 }
 
@@ -1212,17 +1215,30 @@ extern "C" int pxt_lm_refine_batch(const pxt_lm_problem* problems, int32_t n_pro
   // Workgroups per problem: the chip's 256 CUs dealt to the problems, one workgroup per CU (a 32-workgroup grid runs an
   // iteration within 5 % of the 128-workgroup one: profiles/r04_bench_lm.log), a multiple of 8, at most 128.
   int per = conf->n_workgroups;
-  if (per <= 0) per = std::max(8, std::min(128, 256 / K / 8 * 8));
+  if (per <= 0) {
+    per = std::max(8, std::min(128, 256 / K / 8 * 8));
+    // ... but never fewer than one ROUND of 8-lane point groups needs (64 per workgroup): a level whose points do not
+    // fit the grid's lane groups falls back to the several-rounds path - 17 instead of 8.3 us per iteration at
+    // N = 2341 on 32 workgroups (profiles/r04_bench_lm.log)
+    int n_max = 0;
+    for (int k = 0; k < K; ++k) n_max = std::max(n_max, problems[k].n_points);
+    per = std::max(per, std::min(128, ((n_max + 63) / 64 + 7) / 8 * 8));
+  }
   if (per > kLmMaxGrid) per = kLmMaxGrid;
+  // A batched launch stands for K trackers and may fill the device (256 VGPRs per lane: one 8-wave workgroup per CU, 256
+  // resident workgroups; K = 8 problems then get 32 each).  Another LM launch running beside it on another queue could
+  // leave both partly resident - each spinning on members that cannot start - which the bounded spins turn into
+  // PXT_E_TIMEOUT: a lock-step tracker is the device's only LM client (one process per GPU).
   int cap = 0;
-  if (const int rcap = lm_resident_cap(&cap)) return rcap;
+  if (const int rcap = lm_resident_cap(&cap, true)) return rcap;
   // The problems' workgroups are interleaved in dispatch order, so a grid that does not fit the device would leave EVERY
   // problem partly resident, each spinning on members that never start: the whole grid must be resident at once.
   if (per * K > cap) per = std::max(1, cap / K);
   hipStream_t s = (hipStream_t)stream;
   PXT_HIP_CHECK(hipMemcpyAsync(batch_workspace, slot.host, (size_t)K * sizeof(LmParams), hipMemcpyHostToDevice, s));
   PXT_HIP_CHECK(hipEventRecord(slot.copied, s));
-  hipLaunchKernelGGL(lm_refine_batch_kernel, dim3(per * K), dim3(kLmBlock), 0, s, (const LmParams*)batch_workspace, K);
+  static const int contiguous = [] { const char* e = getenv("PXT_LM_BATCH_MAP"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(lm_refine_batch_kernel, dim3(per * K), dim3(kLmBlock), 0, s, (const LmParams*)batch_workspace, K, contiguous);
   PXT_HIP_CHECK(hipGetLastError());
   return PXT_OK;
 }

@@ -458,7 +458,9 @@ __device__ inline bool probe_cell(const NgpParams& P, const Ray& r, float t, flo
 #pragma unroll
   for (int a = 0; a < 3; ++a) pos[a] = r.o[a] + t * r.d[a];
   dt = calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
-  const int e = frexp_exp(dt * (float)kGrid);
+  // instant-ngp mip_from_dt: `dt *= 2 * NERF_GRIDSIZE()` (rounds 1-4 had the factor without the 2: one cascade finer
+  // wherever t >= 1 - VERDICT r4; the `dt < 1 -> mip_from_pos` guard upstream is what the max() below does for e <= 0)
+  const int e = frexp_exp(dt * (float)(2 * kGrid));
   mip = min(P.cascades - 1, max(e, mip_from_pos(pos[0], pos[1], pos[2], P.cascades)));
   const float msc = pow2i(-mip);
   int ci[3];

@@ -306,6 +306,27 @@ __global__ __launch_bounds__(64) void head_pair_kernel(const HeadJob a, const He
   else head_mfma_body<NT>(b.in, b.npix, b.Cin, b.wts, b.bias, b.Cout, b.normalize, b.out, b.cstride, w - a.waves);
 }
 
+// ... and of a BATCH of images (round 5: the lock-step multi-object pass): blockIdx.y = image.  One launch instead of
+// 2 x n_img (a 16-image pass spent 1.5 ms of side-stream time in 32 one-image head launches squeezed between the
+// decoder's workgroups, profiles/r05_experiments.md).
+struct HeadBatch {
+  HeadJob a, b;  // image 0's; image i reads in + i * npix * Cin
+  float* out_a[PXT_UNET_MAX_BATCH];
+  float* out_b[PXT_UNET_MAX_BATCH];
+  int normalize[PXT_UNET_MAX_BATCH];
+};
+template <int NT>
+__global__ __launch_bounds__(64) void head_batch_kernel(const HeadBatch hb) {
+  const long long w = blockIdx.x;
+  const int img = blockIdx.y;
+  if (w < hb.a.waves)
+    head_mfma_body<NT>(hb.a.in + (size_t)img * hb.a.npix * hb.a.Cin, hb.a.npix, hb.a.Cin, hb.a.wts, hb.a.bias, hb.a.Cout,
+                       hb.normalize[img], hb.out_a[img], hb.a.cstride, w);
+  else
+    head_mfma_body<NT>(hb.b.in + (size_t)img * hb.b.npix * hb.b.Cin, hb.b.npix, hb.b.Cin, hb.b.wts, hb.b.bias, hb.b.Cout,
+                       hb.normalize[img], hb.out_b[img], hb.b.cstride, w - hb.a.waves);
+}
+
 // Diagnostic (not on the frame's path): largest |x| and the number of non-finite values of an fp16 activation tensor.
 // pixloc runs its UNet in fp32; here activations are stored as fp16 (65504 max).  With He-initialised synthetic weights
 // they stay below ~50; whether a real VGG16 / MegaDepth checkpoint keeps every layer inside fp16's range can only be
@@ -939,7 +960,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
 
   // both coarse heads of a single image in one launch (after dec1 exists); PXT_UNET_MERGE_HEADS=0 keeps the two launches
   static const bool merge_heads_env = [] { const char* e = getenv("PXT_UNET_MERGE_HEADS"); return e ? atoi(e) != 0 : true; }();
-  const bool merge_heads = merge_heads_env && B == 1 && ctx->head[1].cout + 1 > 64 && ctx->head[2].cout + 1 > 64 &&
+  const bool merge_heads = merge_heads_env && ctx->head[1].cout + 1 > 64 && ctx->head[2].cout + 1 > 64 &&
                            ctx->head[1].cout + 1 <= 160 && ctx->head[2].cout + 1 <= 160;
   auto head_job = [&](int k) {
     static const int head_src[3] = {0, 2, 4};
@@ -1056,7 +1077,17 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
     if (d == 1) {  // dec1 feeds the stride-4 head
       PXT_HIP_CHECK(hipEventRecord(ss.ev_dec1, s));
       PXT_HIP_CHECK(hipStreamWaitEvent(ss.side, ss.ev_dec1, 0));
-      if (merge_heads) {
+      if (merge_heads && B > 1) {
+        HeadBatch hb;
+        hb.a = head_job(2);
+        hb.b = head_job(1);
+        for (int im = 0; im < B; ++im) {
+          hb.out_a[im] = out_maps[3 * im + 2];
+          hb.out_b[im] = out_maps[3 * im + 1];
+          hb.normalize[im] = normalize[im];
+        }
+        hipLaunchKernelGGL(head_batch_kernel<5>, dim3((unsigned)(hb.a.waves + hb.b.waves), B), dim3(64), 0, ss.side, hb);
+      } else if (merge_heads) {
         const HeadJob ja = head_job(2), jb = head_job(1);
         hipLaunchKernelGGL(head_pair_kernel<5>, dim3((unsigned)(ja.waves + jb.waves)), dim3(64), 0, ss.side, ja, jb);
       } else {

@@ -55,6 +55,10 @@ def main():
     base = renders(assets)
     compare("srgb_to_linear on finished rays (on -> off: a snapshot trained in linear colours)", base,
             renders(assets, linear_colors=True), "systematic: the reference image the UNet sees changes everywhere")
+    NO.VARIANT["mip_dt_factor"] = 128
+    compare("mip_from_dt factor (2 x NERF_GRIDSIZE = 256 -> 128, rounds 1-4)", base, renders(assets),
+            "one cascade finer wherever t >= 1: fewer samples, thinner silhouette")
+    NO.VARIANT["mip_dt_factor"] = 256
     NO.VARIANT["jitter"] = "other"
     compare("start-jitter hash (builder's 24-bit hash -> an unrelated sequence)", base, renders(assets))
     NO.VARIANT["jitter"] = "none"

@@ -58,8 +58,16 @@ def test_objects8_and_hd_workloads_run(device):
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
-    assert "configs[3]" in d["config"]["workload"] and "bottle" in d["config"]["workload"]
-    assert d["tracked_ok"] == d["frames_total"] == 8
+    # configs[3] on ONE GPU: all eight config/*.sh objects in lock-step (MultiObjectTracker), 8 frames each
+    assert "configs[3]" in d["config"]["workload"] and d["config"]["objects_per_rank"][0][0] == "bottle"
+    assert len(d["config"]["objects_per_rank"][0]) == 8 and d["scaling"] == "strong"
+    assert d["tracked_ok"] == d["frames_total"] == 64, (d["tracked_ok"], d["frames_total"])
+    assert d["lockstep_frames"] == 64 + 8 * (3 - 1) and d["solo_frames_inside_lockstep"] == 8  # only the cold starts ran alone
+    st = d["roofline_stages"]
+    assert st["unet"]["images_per_call"] == 16 and 0.05 < st["unet"]["frac"] < 1.0 and st["lm"]["problems_per_launch"] == 8
+    solo = d["solo_runs"]
+    assert len(solo["frames_per_s_per_object"]) == 8 and solo["lockstep_speedup"] > 1.0, solo
+    assert max(solo["max_abs_pose_difference_vs_lockstep"]) < 5e-3, solo
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "hd", "--steps", "6", "--warmup", "2"],
                          capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
@@ -183,3 +191,14 @@ def test_eight_ranks_rehearsal_on_one_gpu(device):
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["ranks_seen"] == list(range(8)) and d["frames_total"] == 32 == d["tracked_ok"]
+    # ... and on TWO ranks: four objects per rank in lock-step (rank 0: objects 0, 2, 4, 6; rank 1: 1, 3, 5, 7)
+    cmd[cmd.index("--nproc-per-node") + 1] = "2"
+    cmd[cmd.index("--gpus") + 1] = "2"
+    cmd[cmd.index("29563")] = "29565"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1] and d["frames_total"] == 32 == d["tracked_ok"]
+    assert d["config"]["objects_per_rank"] == [["bottle", "gimble", "pickle_rick", "roncelli_blankk"],
+                                               ["cracker_box", "motor_core", "premier_protein", "spirit_level"]]
+    assert all(r["frames"] == 16 for r in d["ranks"]) and d["scaling"] == "strong"
