@@ -537,7 +537,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
 
     trackers = [fresh(u) for u in units]
     frames = {u: render_query_frames(assets[u], tr.testbed) for u, tr in zip(units, trackers)}
-    multi = MultiObjectTracker(trackers, lm_workgroups=args.lm_grid, per_image_plan=args.per_image_plan)
+    multi = MultiObjectTracker(trackers, lm_workgroups=args.lm_grid, per_image_plan=args.per_image_plan, n_groups=args.groups)
     gc.collect()
     gc.freeze()
     gc.disable()
@@ -569,6 +569,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
         tr.render_ahead = False
         tr._ahead_ok = None
     phases, lm_iters = [], []
+    multi.set_groups(1)  # (one group: the phases of a step follow each other on one stream)
     for i in range(n, n + n_diag):
         multi.timing = {}
         multi.run_single_frames([(names[i], frames[u][i]) for u in units])
@@ -645,7 +646,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
                                 "lock-step (batched UNet pass + one persistent LM launch per step), 640x480, full loop; a step = one "
                                 "frame of every object"),
                    "objects_per_rank": [[objs[u]["name"] for u in us] for us in units_all], "width": args.width,
-                   "height": args.height, "spp": 8, "lm_workgroups_per_problem": args.lm_grid, "unet_per_image_plan": bool(args.per_image_plan),
+                   "height": args.height, "spp": 8, "lm_workgroups_per_problem": args.lm_grid, "groups": args.groups, "unet_per_image_plan": bool(args.per_image_plan),
                    "host_numa_node": numa_node},
         "tracked_ok": n_ok, "frames_total": total_frames,
         "per_object_frames_per_s": round(args.steps / elapsed, 3),
@@ -723,6 +724,8 @@ def main():
     ap.add_argument("--lm-grid", type=int, default=0, help="objects8 lock-step: LM workgroups per problem (0: 256 / K)")
     ap.add_argument("--per-image-plan", action="store_true",
                     help="objects8 lock-step: UNet layers planned per image (maps bit-identical to the one-object tracker)")
+    ap.add_argument("--groups", type=int, default=2,
+                    help="objects8 lock-step: groups of objects with their own stream and batched passes (UNet passes take turns)")
     ap.add_argument("--no-solo", action="store_true", help="objects8 lock-step at N = 1: skip the one-object comparison pass")
     ap.add_argument("--cpu-baseline-frames", type=int, default=0,
                     help="CPU baseline: track exactly this many frames after 3 warm-up frames (BASELINE.md 3 asks for >= 20); "

@@ -367,7 +367,12 @@ constexpr int kK = 8;          // samples per ray per round
 // 0.62 / 0.65 / 0.72 / 0.74 / 0.75 / 0.71 / 0.64.  (Rounds 1-2 used 5 with the one-ray-per-lane straggler kernel, which took
 // 0.15-0.45 ms on the views of frames 100-250.)  PXT_NGP_ROUNDS=n (0 .. kMaxRounds) overrides the count: a ray's result
 // does not depend on it (tests/test_variants_gpu.py).
-constexpr int kRounds = 3, kMaxRounds = 12;
+// Round 5: with mip_from_dt's factor corrected (coarser occupancy cells from t = 1 on: +6 % samples per render) the rays
+// left after three rounds grew from ~1 % to 4 % of a render's samples on the benchmark object and far more on the
+// other config/*.sh boxes (the straggler kernel took 2.3 ms of a lock-step step's 14 ms of kernel time): 3 / 4 / 5 rounds =
+// 653 / 656 / 645 and 650 / 654 / 655 frames/s over 200 frames of the benchmark sequence (a tie), 817 / 904 / 905 frames/s
+// for the eight objects in lock-step (profiles/r05_experiments.md).  Four.
+constexpr int kRounds = 4, kMaxRounds = 12;
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {

@@ -289,7 +289,7 @@ class PixTrackOptimizer:
 
     @staticmethod
     def refine_levels_batch(problems: Sequence[dict], conf: _lib.LmConf, batch_workspace: torch.Tensor,
-                            want_log: bool = True) -> List["PendingLM"]:
+                            want_log: bool = True, pool_key=0) -> List["PendingLM"]:
         """K independent refinements in ONE persistent launch (pxt_lm_refine_batch): ``problems`` are
         PoseTrackerRefiner.lm_problem records (ref.p3d / ref.valid, packs, T_init, workspace, camera) of K objects
         tracked in lock-step; ``conf`` is shared (conf.n_workgroups = grid per problem, 0 = 256 / K).  Returns one
@@ -304,7 +304,7 @@ class PixTrackOptimizer:
         cam_conv, cam_slots, cam_outs, cam_on = [], [], [], []
         with_cam = any(pr.get("camera") is not None for pr in problems)
         bufs = _pinned_records([nh + (len(pr["packs"]) * conf.num_iters * _lib.PXT_LM_LOG_STRIDE if want_log else 0)
-                                for pr in problems])
+                                for pr in problems], pool_key)
         for pr, buf in zip(problems, bufs):
             ref, levels = pr["ref"], pr["packs"]
             _lib.require_gpu(ref.p3d, "p3d")
@@ -410,13 +410,14 @@ def _pinned_record(n_floats: int) -> torch.Tensor:
     return buf
 
 
-def _pinned_records(sizes: Sequence[int]) -> List[torch.Tensor]:
-    """The K records of one batched launch: distinct pinned buffers, two sets alternating per (sizes) signature."""
+def _pinned_records(sizes: Sequence[int], pool_key=0) -> List[torch.Tensor]:
+    """The K records of one batched launch: distinct pinned buffers, two sets alternating per (sizes, pool_key)
+    signature (pool_key: the caller's group - launches of different groups are in flight together)."""
     pool = _PINNED.__dict__.setdefault("batch_pool", {})
-    key = tuple(int(x) for x in sizes)
+    key = (pool_key,) + tuple(int(x) for x in sizes)
     ring = pool.get(key)
     if ring is None:
-        ring = pool[key] = [[[torch.zeros(n, dtype=torch.float32).pin_memory() for n in key] for _ in range(2)], 0]
+        ring = pool[key] = [[[torch.zeros(n, dtype=torch.float32).pin_memory() for n in key[1:]] for _ in range(2)], 0]
     bufs = ring[0][ring[1]]
     ring[1] ^= 1
     return bufs

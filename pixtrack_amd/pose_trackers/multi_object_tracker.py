@@ -36,9 +36,22 @@ from ..tracker import DebugTracker
 from .pixloc_tracker_r9 import PixLocPoseTrackerR9
 
 
+class _Group:
+    """The objects whose device work is merged: one stream, one UNet context (workspace), one LM batch workspace."""
+
+    def __init__(self, index, members, stream, model):
+        self.index, self.members, self.stream, self.model = index, members, stream, model
+        self.batch_ws: Optional[torch.Tensor] = None
+        self.unet_done: Optional[torch.cuda.Event] = None
+        self.pend = None  # what _enqueue left for _finish
+
+
 class MultiObjectTracker:
     def __init__(self, trackers: Sequence[PixLocPoseTrackerR9], lm_workgroups: int = 0, per_image_plan: bool = False,
-                 max_unet_batch: int = _lib.PXT_UNET_MAX_BATCH):
+                 max_unet_batch: int = _lib.PXT_UNET_MAX_BATCH, n_groups: int = 1):
+        """``n_groups`` > 1: the trackers are dealt to that many groups, each with its own stream, batched UNet pass and
+        batched LM launch per step; the groups' UNet passes take turns (an event token), so that one group's MFMA-bound
+        UNet pass runs beside the other group's latency-bound renders instead of beside its UNet pass."""
         if not trackers:
             raise ValueError("MultiObjectTracker needs at least one tracker")
         self.trackers: List[PixLocPoseTrackerR9] = list(trackers)
@@ -46,28 +59,43 @@ class MultiObjectTracker:
         for tr in self.trackers:
             if tr.device != self.device:
                 raise _lib.PxtError("lock-step trackers share one device")
-        # one UNet context runs every image of a step: the trackers must hold the same checkpoint
+        # one UNet context runs every image of a group's step: the trackers must hold the same checkpoint
         # (pixloc_megadepth is one network for all objects; reference pixloc_pose_refiners.py:49-60)
-        self.model = self.trackers[0].localizer.extractor.model
-        sig = getattr(self.model, "weights_signature", None)
+        sig = getattr(self.trackers[0].localizer.extractor.model, "weights_signature", None)
         for tr in self.trackers[1:]:
             if getattr(tr.localizer.extractor.model, "weights_signature", None) != sig:
                 raise _lib.PxtError("lock-step trackers must share one UNet checkpoint")
-        self.lm_workgroups = int(lm_workgroups)      # grid per problem of the batched launch; 0: 256 / K
+        self.groups: List[_Group] = []
+        self.set_groups(n_groups)
+        self.lm_workgroups = int(lm_workgroups)      # grid per problem of the batched launch; 0: the library's default
         self.per_image_plan = bool(per_image_plan)   # UNet layers planned as for one image (bit-identity with solo runs)
         self.max_unet_batch = int(max_unet_batch)
-        self._batch_ws: Optional[torch.Tensor] = None
         self.steps = 0
         self.solo_frames = 0       # frames that ran through run_single_frame (cold starts, several references)
         self.lockstep_frames = 0
         self.timing = None         # set to {} to collect HIP-event pairs per phase (bench.py's untimed diagnostic pass)
 
+    def set_groups(self, n_groups: int) -> None:
+        """(Re)deals the trackers to ``n_groups`` groups, tracker k to group k mod n_groups.  Synchronises the device: a
+        tracker's tensors of the last step were produced on its old group's stream."""
+        n_groups = max(1, min(int(n_groups), len(self.trackers)))
+        if any(g.pend for g in self.groups):
+            raise _lib.PxtError("set_groups between steps only")
+        torch.cuda.synchronize(self.device)
+        self.groups = []
+        for g in range(n_groups):
+            members = list(range(g, len(self.trackers), n_groups))
+            stream = None if n_groups == 1 else torch.cuda.Stream(self.device)
+            self.groups.append(_Group(g, members, stream, self.trackers[members[0]].localizer.extractor.model))
+        self.model = self.groups[0].model
+        self._last_unet_done = None
+
     # ------------------------------------------------------------------ helpers
-    def _lm_batch_ws(self, k: int) -> torch.Tensor:
-        need = int(_lib.lib().pxt_lm_batch_workspace_bytes(_lib.PXT_LM_MAX_BATCH))
-        if self._batch_ws is None:
-            self._batch_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
-        return self._batch_ws
+    def _lm_batch_ws(self, grp: _Group) -> torch.Tensor:
+        if grp.batch_ws is None:
+            need = int(_lib.lib().pxt_lm_batch_workspace_bytes(_lib.PXT_LM_MAX_BATCH))
+            grp.batch_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        return grp.batch_ws
 
     def _mark(self, name: str):
         if self.timing is None:
@@ -77,27 +105,34 @@ class MultiObjectTracker:
         self.timing.setdefault(name, []).append(e)
         return e
 
-    def _unet_batch(self, jobs) -> None:
+    def _unet_batch(self, grp: _Group, jobs) -> None:
         """jobs: [(extractor, image, scale, mask, normalize)] -> every pyramid computed in batched passes (images of
         one size per pass, at most max_unet_batch each) and handed to its extractor through preload()."""
         prepared = []
         for ex, image, scale, mask, normalize in jobs:
             img, rest_mask, scales = ex.prepared(image, scale, mask)
             prepared.append((img, rest_mask, scales))
-        groups = {}
+        sizes = {}
         for i, (img, _m, _s) in enumerate(prepared):
-            groups.setdefault((int(img.shape[0]), int(img.shape[1])), []).append(i)
-        self.model.set_batch_plan(self.per_image_plan)
+            sizes.setdefault((int(img.shape[0]), int(img.shape[1])), []).append(i)
+        cur = torch.cuda.current_stream(self.device)
+        if len(self.groups) > 1 and self._last_unet_done is not None:
+            cur.wait_event(self._last_unet_done)  # the groups' UNet passes take turns
+        grp.model.set_batch_plan(self.per_image_plan)
         try:
-            for idx in groups.values():
+            for idx in sizes.values():
                 for a in range(0, len(idx), self.max_unet_batch):
                     part = idx[a:a + self.max_unet_batch]
-                    outs = self.model.forward_packed_batch([(prepared[i][0], prepared[i][1], jobs[i][4]) for i in part])
+                    outs = grp.model.forward_packed_batch([(prepared[i][0], prepared[i][1], jobs[i][4]) for i in part])
                     for i, maps in zip(part, outs):
                         ex, image, scale, mask, normalize = jobs[i]
                         ex.preload(image, scale, mask, normalize, maps, prepared[i][2])
         finally:
-            self.model.set_batch_plan(False)
+            grp.model.set_batch_plan(False)
+        if len(self.groups) > 1:
+            grp.unet_done = torch.cuda.Event()
+            grp.unet_done.record(cur)
+            self._last_unet_done = grp.unet_done
 
     # ------------------------------------------------------------------ one step = one frame of every object
     def run_single_frames(self, frames) -> List[bool]:
@@ -105,10 +140,29 @@ class MultiObjectTracker:
         of PoseTracker.run_single_frame (reference base_pose_tracker.py:24-30) for K trackers at once."""
         assert len(frames) == len(self.trackers)
         out: List[Optional[bool]] = [None] * len(frames)
-        live = []
         self._mark("step_begin")
+        for grp in self.groups:
+            if grp.stream is None:
+                self._enqueue(grp, frames, out)
+            else:
+                with torch.cuda.stream(grp.stream):
+                    self._enqueue(grp, frames, out)
+        for grp in self.groups:
+            if grp.stream is None:
+                self._finish(grp, frames, out)
+            else:
+                with torch.cuda.stream(grp.stream):
+                    self._finish(grp, frames, out)
+        self._mark("step_end")
+        self.steps += 1
+        return out
+
+    def _enqueue(self, grp: _Group, frames, out) -> None:
+        live = []
+        grp.pend = []
         # ---- phase A: per-object frame set-up (policy head, mask + reference render or the render queued last step)
-        for k, (tr, frame) in enumerate(zip(self.trackers, frames)):
+        for k in grp.members:
+            tr, frame = self.trackers[k], frames[k]
             if frame is None:
                 continue
             scales = tr.steady_multiscale if tr.success else tr.localizer.refiner.conf.multiscale
@@ -123,15 +177,14 @@ class MultiObjectTracker:
             live.append((k, tr, frame, ref_u8))
         self._mark("renders_enqueued")
         if not live:
-            self.steps += 1
-            return out
+            return
         # ---- phase B: the step's 2 K images through the UNet in batched passes
         jobs = []
         for k, tr, (path, image), ref_u8 in live:
             ex = tr.localizer.refiner.feature_extractor
             jobs.append((ex, ref_u8, 1, None, False))                               # extract_reference_features
             jobs.append((ex, image, 1, tr.localizer.refiner.query_mask, True))      # refine_query_pose's query pass
-        self._unet_batch(jobs)
+        self._unet_batch(grp, jobs)
         self._mark("unet_enqueued")
         # ---- phase C: per object, the reference's bookkeeping + sparse sampling + the LM problem
         pend = []
@@ -154,18 +207,25 @@ class MultiObjectTracker:
                 if bytes(pr["conf"]) != bytes(conf):
                     raise _lib.PxtError("lock-step trackers must share the optimizer configuration")
             conf.n_workgroups = self.lm_workgroups
-            handles = PixTrackOptimizer.refine_levels_batch(probs, conf, self._lm_batch_ws(len(probs)))
+            if len(self.groups) > 1 and conf.n_workgroups <= 0:
+                # the groups' launches may run side by side: together they must fit the device's resident workgroups
+                # (one 8-wave workgroup per CU: pxt_lm.hip), or both would sit partly resident and time out
+                cus = _device_cus()
+                conf.n_workgroups = max(8, cus // (len(self.groups) * len(probs)) // 8 * 8)
+            handles = PixTrackOptimizer.refine_levels_batch(probs, conf, self._lm_batch_ws(grp), pool_key=grp.index)
         self._mark("lm_enqueued")
         it = iter(handles)
-        pend = [(k, tr, path, ref_id, dbg, status, x, next(it) if status == "lm" else None)
-                for (k, tr, path, ref_id, dbg, status, x) in pend]
-        for k, tr, path, ref_id, dbg, status, x, handle in pend:
+        grp.pend = [(k, tr, path, ref_id, dbg, status, x, next(it) if status == "lm" else None)
+                    for (k, tr, path, ref_id, dbg, status, x) in pend]
+        for k, tr, path, ref_id, dbg, status, x, handle in grp.pend:
             hook = getattr(tr.localizer.refiner, "after_lm_enqueued", None)
             if handle is not None and hook is not None:
                 hook(handle)
         self._mark("ahead_enqueued")
+
+    def _finish(self, grp: _Group, frames, out) -> None:
         # ---- phase E: results, per-object policy (cost gate, pose update, history), the loop's tail
-        for k, tr, path, ref_id, dbg, status, x, handle in pend:
+        for k, tr, path, ref_id, dbg, status, x, handle in grp.pend or []:
             refiner = tr.localizer.refiner
             ret = refiner.finish_refine(x, handle.result()) if handle is not None else x
             ok = tr._frame_policy(path, {ref_id: ret}, {ref_id: tr._frame_cost()}, {ref_id: dbg})
@@ -174,9 +234,7 @@ class MultiObjectTracker:
             tr.update_reference_ids()
             out[k] = bool(ok)
             self.lockstep_frames += 1
-        self._mark("step_end")
-        self.steps += 1
-        return out
+        grp.pend = None
 
     def run(self, frame_iterators, max_frames=float("inf")):
         """Advances every tracker over its own frame iterator (``get_query_frame_iterator`` objects or any iterables of
@@ -190,3 +248,11 @@ class MultiObjectTracker:
             self.run_single_frames(frames)
             n += 1
         return n
+
+
+def _device_cus() -> int:
+    import ctypes as C
+
+    n = C.c_int(0)
+    _lib.check(_lib.lib().pxt_device_cus(C.byref(n)), "pxt_device_cus")
+    return int(n.value)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--max-unet-batch", type=int, default=16)
     ap.add_argument("--no-solo", action="store_true")
     ap.add_argument("--phases", action="store_true")
+    ap.add_argument("--groups", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     objs = parallel.load_object_configs()
@@ -57,7 +58,7 @@ def main():
     trackers = [fresh(k) for k in range(K)]
     frames = [render_query_frames(assets[k], trackers[k].testbed) for k in range(K)]
     out = {"objects": K, "steps": args.steps, "lm_grid": args.lm_grid, "per_image_plan": args.per_image_plan,
-           "max_unet_batch": args.max_unet_batch}
+           "max_unet_batch": args.max_unet_batch, "groups": args.groups}
     solo_poses = None
     if not args.no_solo:
         fps, solo_poses = [], []
@@ -78,7 +79,7 @@ def main():
         out["solo_fps"] = [round(f, 1) for f in fps]
         out["solo_aggregate_fps"] = round(K * args.steps / sum(args.steps / f for f in fps), 1)  # one after the other
     multi = MultiObjectTracker(trackers, lm_workgroups=args.lm_grid, per_image_plan=args.per_image_plan,
-                               max_unet_batch=args.max_unet_batch)
+                               max_unet_batch=args.max_unet_batch, n_groups=args.groups)
     gc.collect()
     gc.disable()
     for i in range(args.warmup):
@@ -100,6 +101,7 @@ def main():
         out["speedup_vs_solo_aggregate"] = round(out["lockstep_aggregate_fps"] / out["solo_aggregate_fps"], 3)
     if args.phases:  # a separate untimed pass: one synchronised step with event marks between the phases
         extra = []
+        multi.set_groups(1)
         for tr in trackers:
             tr.render_ahead = False
         for rep in range(4):

@@ -62,7 +62,7 @@ def test_objects8_and_hd_workloads_run(device):
     assert "configs[3]" in d["config"]["workload"] and d["config"]["objects_per_rank"][0][0] == "bottle"
     assert len(d["config"]["objects_per_rank"][0]) == 8 and d["scaling"] == "strong"
     assert d["tracked_ok"] == d["frames_total"] == 64, (d["tracked_ok"], d["frames_total"])
-    assert d["lockstep_frames"] == 64 + 8 * (3 - 1) and d["solo_frames_inside_lockstep"] == 8  # only the cold starts ran alone
+    assert d["lockstep_frames"] == 8 * (3 + 8 + 4 - 1) and d["solo_frames_inside_lockstep"] == 8  # only the cold starts ran alone
     st = d["roofline_stages"]
     assert st["unet"]["images_per_call"] == 16 and 0.05 < st["unet"]["frac"] < 1.0 and st["lm"]["problems_per_launch"] == 8
     solo = d["solo_runs"]
