@@ -721,6 +721,8 @@ def main():
     ap.add_argument("--object-index", type=int, default=-1,
                     help="objects8: ONE object per rank, rank r tracking object (object-index + r) mod 8 of config/*.sh; default "
                          "(-1): all eight objects, dealt round-robin to the ranks and tracked in lock-step per rank")
+    ap.add_argument("--extra", choices=["ycb_policy", "ycb_refshape", "r9_phone", "r9_12mp"], default=None,
+                    help="run only this extra pass (the reference's own reference-image shapes) and print its record")
     ap.add_argument("--lm-grid", type=int, default=0, help="objects8 lock-step: LM workgroups per problem (0: 256 / K)")
     ap.add_argument("--per-image-plan", action="store_true",
                     help="objects8 lock-step: UNet layers planned per image (maps bit-identical to the one-object tracker)")
@@ -758,6 +760,14 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     numa_node = parallel.bind_to_device_numa(local_rank)  # before any pinned allocation
 
+    if args.extra:  # one of the extra passes on its own (profiling: scripts/collect_profiles.sh's refshape leg)
+        from pixtrack_amd.synthetic import REF_CAMERA_12MP, REF_CAMERA_PHONE
+
+        fn = {"ycb_policy": lambda: ycb_policy_extra(dev), "ycb_refshape": lambda: ycb_policy_extra(dev, refshape=True),
+              "r9_phone": lambda: r9_refshape_extra(dev, REF_CAMERA_PHONE, "1920x1440 (4:3 phone frames)"),
+              "r9_12mp": lambda: r9_refshape_extra(dev, REF_CAMERA_12MP, "4032x3024 (12-MP stills)", n=34)}[args.extra]
+        print(json.dumps({args.extra: fn()}), flush=True)
+        return
     if args.config == "hd":
         return run_hd(args, rank, ws, dev, coll_dev, numa_node)
     if args.config == "objects8" and args.object_index < 0 and ws < 8:

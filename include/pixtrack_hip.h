@@ -177,6 +177,13 @@ typedef struct {
   int32_t h, w, C, cstride;
   float cam[10];      /* reference camera scaled by reference_scale and level scale */
   int32_t ndist;
+  /* The map may be a WINDOW of the level's full map (round 5: the reference pass runs on a crop of the reference render
+   * that holds every input pixel the sampled points depend on - the pyramid's dependency radius around the points'
+   * bounding box - instead of on the whole render; pixloc_pose_refiners.py:282-290 computes the dense maps only to sample
+   * them at the points, :236,316 `del`).  full_w > 0: the map holds columns [x0, x0 + w) and rows [y0, y0 + h) of a
+   * full_w x full_h level; projection, visibility and the padded in-image test use the full level, texels are read at
+   * (u - x0, v - y0) - bit for bit the samples of the full map wherever both hold the same texels.  full_w = 0: no window. */
+  int32_t x0, y0, full_w, full_h;
 } pxt_sample_level;
 
 int pxt_sample_sparse(const float* p3d, int32_t n_points, const float* T_host /* 12 floats */,

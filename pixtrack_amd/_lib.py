@@ -70,6 +70,10 @@ class SampleLevel(C.Structure):
         ("cstride", C.c_int32),
         ("cam", C.c_float * 10),
         ("ndist", C.c_int32),
+        ("x0", C.c_int32),
+        ("y0", C.c_int32),
+        ("full_w", C.c_int32),
+        ("full_h", C.c_int32),
     ]
 
 

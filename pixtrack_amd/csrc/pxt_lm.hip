@@ -972,6 +972,7 @@ struct SampleLevelDev {
   int h, w, C, cs;
   float cam[10];
   int ndist;
+  int x0, y0, fw, fh;  // the map is the window [x0, x0 + w) x [y0, y0 + h) of an fw x fh level (fw = w, fh = h, x0 = y0 = 0: the whole)
 };
 
 struct SampleParams {
@@ -987,11 +988,12 @@ __device__ inline bool sample_level(const SampleParams& P, const SampleLevelDev&
                                     bool active, float px, float py, float pz, int sub) {
   const Cam cam = make_cam(L.cam, L.ndist);
   const int W = L.w, H = L.h, C = L.C, cs = L.cs;
+  const int FW = L.fw, FH = L.fh;  // the full level (projection, visibility, padded in-image test)
   const float pad = (float)P.pad;
   float u = 0.f, v = 0.f;
   bool valid = project_point(cam, px, py, pz, u, v, nullptr) && active;
-  valid = valid && (u >= pad) && (v >= pad) && (u <= (float)(W - 1) - pad) &&
-          (v <= (float)(H - 1) - pad);
+  valid = valid && (u >= pad) && (v >= pad) && (u <= (float)(FW - 1) - pad) &&
+          (v <= (float)(FH - 1) - pad);
   if (!active) return false;
   float* o = L.out + (size_t)n * cs;
   if (!valid) {
@@ -999,12 +1001,16 @@ __device__ inline bool sample_level(const SampleParams& P, const SampleLevelDev&
     return false;
   }
   const float fu = floorf(u), fv = floorf(v);
-  const int ix0 = (int)fu, iy0 = (int)fv;
+  const int ix0f = (int)fu, iy0f = (int)fv;
   const float ax = u - fu, ay = v - fv;
-  const int x1 = min(ix0 + 1, W - 1), y1 = min(iy0 + 1, H - 1);
-  const float mx = (ix0 + 1 < W) ? 1.f : 0.f, my = (iy0 + 1 < H) ? 1.f : 0.f;
+  const int x1f = min(ix0f + 1, FW - 1), y1f = min(iy0f + 1, FH - 1);
+  const float mx = (ix0f + 1 < FW) ? 1.f : 0.f, my = (iy0f + 1 < FH) ? 1.f : 0.f;
   const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay) * mx, w01 = (1.f - ax) * ay * my,
               w11 = ax * ay * mx * my;
+  // window coordinates (the caller's window holds every texel a valid point reads; the clamps only keep a caller's
+  // mistake from reading outside the buffer)
+  const int ix0 = min(max(ix0f - L.x0, 0), W - 1), iy0 = min(max(iy0f - L.y0, 0), H - 1);
+  const int x1 = min(max(x1f - L.x0, 0), W - 1), y1 = min(max(y1f - L.y0, 0), H - 1);
   const float* p00 = L.fmap + ((size_t)iy0 * W + ix0) * cs;
   const float* p10 = L.fmap + ((size_t)iy0 * W + x1) * cs;
   const float* p01 = L.fmap + ((size_t)y1 * W + ix0) * cs;
@@ -1268,6 +1274,12 @@ extern "C" int pxt_sample_sparse(const float* p3d, int32_t n_points, const float
     d.h = s.h; d.w = s.w; d.C = s.C; d.cs = s.cstride;
     for (int i = 0; i < 10; ++i) d.cam[i] = s.cam[i];
     d.ndist = s.ndist;
+    if (s.full_w > 0) {  // a window of the level
+      if (s.full_h < 1 || s.x0 < 0 || s.y0 < 0 || s.x0 + s.w > s.full_w || s.y0 + s.h > s.full_h) return PXT_E_ARG;
+      d.x0 = s.x0; d.y0 = s.y0; d.fw = s.full_w; d.fh = s.full_h;
+    } else {
+      d.x0 = 0; d.y0 = 0; d.fw = s.w; d.fh = s.h;
+    }
   }
   const int groups_per_block = 256 / 32;
   const int grid = (n_points + groups_per_block - 1) / groups_per_block;

@@ -1206,6 +1206,8 @@ extern "C" int pxt_unet_activation_stats(pxt_unet* ctx, int32_t H, int32_t W, co
   Plan P;
   if (!make_plan(ctx, 1, H, W, P)) return PXT_E_ARG;
   hipStream_t s = (hipStream_t)stream;
+  // a pass left running by a deferred-join pair call may still be writing a workspace: wait for it first
+  if (ctx->join_pending) { PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0)); ctx->join_pending = false; }
   PXT_HIP_CHECK(hipMemsetAsync(stats, 0, kNumConv * 2 * sizeof(float), s));
   static const int block_first[5] = {0, 2, 4, 7, 10};
   static const int block_n[5] = {2, 2, 3, 3, 3};
@@ -1229,9 +1231,9 @@ extern "C" int pxt_unet_activation_stats(pxt_unet* ctx, int32_t H, int32_t W, co
       n = (long long)P.dh[d] * P.dw[d] * ctx->conv[li].cout;
       if (d == 3 && ctx->dev_head0 != nullptr) x = nullptr;  // consumed by the fused fine head in registers
     }
-    if (!x) {  // not in memory in this configuration: reported as -1
-      const float minus1[2] = {-1.f, 0.f};
-      PXT_HIP_CHECK(hipMemcpyAsync(stats + 2 * li, minus1, sizeof(minus1), hipMemcpyHostToDevice, s));
+    if (!x) {  // not in memory in this configuration: reported as -1 (0xBF800000: byte-wise memsets, no host source buffer
+               // whose lifetime an asynchronous copy would depend on)
+      PXT_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(stats + 2 * li), 0xBF800000u, 1, s));
       continue;
     }
     hipLaunchKernelGGL(activation_stats_kernel, dim3(512), dim3(256), 0, s, x, n / 8, stats + 2 * li);

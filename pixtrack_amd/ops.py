@@ -49,7 +49,7 @@ SCHEMAS = {
         "int[]? cam_enabled=None) -> ()"),
     "sample_sparse": (
         "(Tensor p3d, float[] T, Tensor[] fmaps, int[] channels, float[] cameras, int[] ndist, int pad, "
-        "bool normalize, Tensor(a!)[] outs, Tensor(b!) valid) -> ()"),
+        "bool normalize, Tensor(a!)[] outs, Tensor(b!) valid, int[]? windows=None) -> ()"),
     "unet_forward_batch": (
         "(int ctx, Tensor[] images, Tensor?[] masks, bool[] normalize, Tensor(a!)[] outs, Tensor(b!) workspace) -> ()"),
     "ngp_render": (
@@ -231,7 +231,7 @@ def _lm_refine_batch(p3d, point_masks, n_levels, fmaps, frefs, channels, cameras
 
 
 # ------------------------------------------------------------------------------------ sampling
-def _sample_sparse(p3d, T, fmaps, channels, cameras, ndist, pad, normalize, outs, valid):
+def _sample_sparse(p3d, T, fmaps, channels, cameras, ndist, pad, normalize, outs, valid, windows=None):
     L = _lib.lib()
     n_levels = len(fmaps)
     if len(outs) != n_levels or len(cameras) != 10 * n_levels or len(T) != 12:
@@ -248,6 +248,10 @@ def _sample_sparse(p3d, T, fmaps, channels, cameras, ndist, pad, normalize, outs
         arr[i].h, arr[i].w, arr[i].C, arr[i].cstride = h, w, int(channels[i]), cs
         arr[i].cam[:] = cameras[10 * i:10 * i + 10]
         arr[i].ndist = int(ndist[i])
+        if windows is not None:  # (x0, y0, full_w, full_h) per level: the map is a window of the full level
+            arr[i].x0, arr[i].y0, arr[i].full_w, arr[i].full_h = (int(x) for x in windows[4 * i:4 * i + 4])
+    if windows is not None and len(windows) != 4 * n_levels:
+        raise _lib.PxtError("sample_sparse: windows holds (x0, y0, full_w, full_h) per level")
     if valid.dtype != torch.uint8 or valid.numel() != n:
         raise _lib.PxtError("sample_sparse: valid must be uint8 [n_points]")
     T12 = (C.c_float * 12)(*[float(x) for x in T])

@@ -182,7 +182,9 @@ class MultiObjectTracker:
         jobs = []
         for k, tr, (path, image), ref_u8 in live:
             ex = tr.localizer.refiner.feature_extractor
-            jobs.append((ex, ref_u8, 1, None, False))                               # extract_reference_features
+            # (extract_reference_features encodes the window of the render its points depend on: refiner.reference_window)
+            ref_in, _win = tr.localizer.refiner.reference_window(tr.reference_ids, tr.pose, ref_u8)
+            jobs.append((ex, ref_in, 1, None, False))                               # extract_reference_features
             jobs.append((ex, image, 1, tr.localizer.refiner.query_mask, True))      # refine_query_pose's query pass
         self._unet_batch(grp, jobs)
         self._mark("unet_enqueued")

@@ -79,6 +79,7 @@ class PoseTrackerRefiner:
         # Not a reference feature: it exists for BASELINE configs[4]'s "4-level pyramid" stress
         # workload ({4: [2], 1: [2, 1, 0]}: the 1/64 map of the downscaled image + the three native ones)
         level_plan=None,
+        reference_window=True,  # encode only the window of the reference render the sampled points depend on (see reference_window)
         filter_covisibility=False,
         do_pose_approximation=False,
         do_inlier_ranking=False,
@@ -100,6 +101,7 @@ class PoseTrackerRefiner:
         assert self.conf.normalize_descriptors and self.conf.compute_uncertainty
         self.query_mask: Optional[torch.Tensor] = None  # device uint8 [H,W], set by the tracker
         self._p3d_cache: Dict[int, Tuple[List[int], torch.Tensor]] = {}
+        self._p3d_host: Dict[int, np.ndarray] = {}
         self._ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=self.device)
         self.last_lm = []  # LMResult per image scale of the last refine (costs for the tracker gate)
 
@@ -123,7 +125,66 @@ class PoseTrackerRefiner:
             p3dids = dbid_to_p3dids.get(dbids[0], [])
             xyz = np.array([self.model3d.points3D[p].xyz for p in p3dids], dtype=np.float32).reshape(-1, 3)
             self._p3d_cache[key] = (p3dids, torch.from_numpy(xyz).to(self.device))
+            self._p3d_host[key] = xyz.astype(np.float64)
         return self._p3d_cache[key]
+
+    # ---- the reference pass on a window of the reference render ---------------------------------------------
+    # The reference computes the reference image's dense maps only to sample them at the projected 3-D points
+    # (pixloc_pose_refiners.py:282-290, then `del features_ref_dense` :236,316).  A sample depends on the input
+    # pixels within the pyramid's dependency radius of its 2 x 2 texels: 130 px for the stride-1 level (through the
+    # 1/16 bottleneck and back up), 122 / 90 px for the other two (interval propagation through the 17 convolutions,
+    # four pools and four bilinear up-samplings; scripts/unet_dependency_radius.py).  With real assets the reference
+    # render is large and mostly background (921 x 921 for the YCB objects: SfM camera 3072 x 3072 x 0.3,
+    # scripts/create_sfm_from_obj.py:154-159): the pass then runs on the window [bounding box of the projected points
+    # +- WINDOW_MARGIN], aligned to the coarsest stride so that pooling and up-sampling pair the same pixels, and the
+    # sampler reads it as a window of the full maps (pxt_sample_level.x0 ..).  Every sampled texel's whole dependency
+    # cone lies inside the window, so it sees exactly the inputs it sees in the full pass; what differs is only which
+    # tile configuration / split-K factor a layer of that size takes, i.e. fp32 summation order.
+    WINDOW_MARGIN = 160   # >= 130 + 1 (bilinear) + 16 (alignment) + a lens-distortion allowance, a multiple of 16
+    WINDOW_MIN_SAVING = 0.35  # a window is used when it drops at least this share of the image's pixels
+
+    def reference_window(self, dbids, pose: Optional[Pose], reference_image):
+        """-> (image to encode, window or None): window = (x0, y0, full_w, full_h) in image pixels."""
+        memo = self.__dict__.get("_window_memo")
+        if memo is not None and memo[0] is reference_image and memo[1] is pose:
+            return memo[2], memo[3]
+        out = (reference_image, None)
+        if self.conf.get("reference_window", True) and torch.is_tensor(reference_image) and pose is not None \
+                and (self.conf.multiscale or [1]) == [1]:
+            H, W = int(reference_image.shape[0]), int(reference_image.shape[1])
+            ex = self.feature_extractor
+            if ex.target_size(H, W, 1)[:2] == (H, W):  # (no resize on the way into the network)
+                self._points_of(dbids)
+                xyz = self._p3d_host[int(dbids[0])]
+                image = self.model3d.dbs[dbids[0]]
+                cam = self._reference_camera_of(image.camera_id)
+                R, t = pose.numpy()
+                p = xyz @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
+                front = p[:, 2] > 1e-3
+                if front.any():
+                    fx, fy = (float(v) for v in cam.f)
+                    cx, cy = (float(v) for v in cam.c)
+                    u = fx * p[front, 0] / p[front, 2] + cx
+                    v = fy * p[front, 1] / p[front, 2] + cy
+                    inside = (u >= 0) & (v >= 0) & (u <= W - 1) & (v <= H - 1)
+                    if inside.any():
+                        m = self.WINDOW_MARGIN
+                        x0 = max(0, int(np.floor(u[inside].min()) - m) // 16 * 16)
+                        y0 = max(0, int(np.floor(v[inside].min()) - m) // 16 * 16)
+                        x1 = min(W, -(-(int(np.ceil(u[inside].max())) + 1 + m) // 16) * 16)
+                        y1 = min(H, -(-(int(np.ceil(v[inside].max())) + 1 + m) // 16) * 16)
+                        if (x1 - x0) * (y1 - y0) <= (1.0 - self.WINDOW_MIN_SAVING) * W * H and x1 - x0 >= 64 and y1 - y0 >= 64:
+                            out = (reference_image[y0:y1, x0:x1].contiguous(), (x0, y0, W, H))
+        self._window_memo = (reference_image, pose, out[0], out[1])
+        return out
+
+    def _reference_camera_of(self, camera_id) -> Camera:
+        ck = (camera_id, float(self.reference_scale))
+        cams_memo = self.__dict__.setdefault("_ref_cameras", {})  # model cameras are static: build each once
+        camera = cams_memo.get(ck)
+        if camera is None:
+            camera = cams_memo[ck] = Camera.from_colmap(self.model3d.cameras[camera_id]).scale(self.reference_scale)
+        return camera
 
     def warm_reference_points(self, dbids: Optional[Sequence[int]] = None) -> None:
         """Builds the per-reference point tables (static data) up front, so that a switch of the
@@ -145,13 +206,11 @@ class PoseTrackerRefiner:
     # ---- sparse reference observations --------------------------------------------
     def interp_sparse_observations(self, feature_maps: List[torch.Tensor], feature_scales, image_id: int,
                                    p3dids: List[int], pose: Optional[Pose] = None,
-                                   p3d: Optional[torch.Tensor] = None) -> SparseReferenceFeatures:
+                                   p3d: Optional[torch.Tensor] = None, window=None) -> SparseReferenceFeatures:
+        """``window`` = (x0, y0, full_w, full_h) in image pixels: the maps are those of that window of the reference
+        image (reference_window); sampling addresses them as windows of the full levels."""
         image = self.model3d.dbs[image_id]
-        ck = (image.camera_id, float(self.reference_scale))
-        cams_memo = self.__dict__.setdefault("_ref_cameras", {})  # model cameras are static: build each once
-        camera = cams_memo.get(ck)
-        if camera is None:
-            camera = cams_memo[ck] = Camera.from_colmap(self.model3d.cameras[image.camera_id]).scale(self.reference_scale)
+        camera = self._reference_camera_of(image.camera_id)
         T_w2cam = Pose.from_colmap(image) if pose is None else pose
         if p3d is None:
             p3d = torch.from_numpy(np.array([self.model3d.points3D[p].xyz for p in p3dids], np.float32)).to(self.device)
@@ -165,8 +224,16 @@ class PoseTrackerRefiner:
         valid = torch.empty(n, dtype=torch.uint8, device=self.device)
         pad = self.optimizer[0].interpolator.pad
         T12 = T_w2cam.as12().detach().cpu().reshape(-1).tolist()
+        windows = None
+        if window is not None:
+            x0, y0, fw, fh = window
+            windows = []
+            for fm, stride in zip(feature_maps, self.feature_extractor.model.scales):
+                # level l of the full image: the sizes UNet.level_shapes gives it; the window starts at x0 / stride
+                lh, lw = self.feature_extractor.model.level_shapes(fh, fw)[len(windows) // 4]
+                windows += [x0 // stride, y0 // stride, lw, lh]
         ops.sample_sparse(p3d, T12, list(feature_maps), list(OUTPUT_DIMS[:len(feature_maps)]), cams, ndist, int(pad),
-                          True, outs, valid)
+                          True, outs, valid, windows)
         return SparseReferenceFeatures(outs, valid, list(p3dids), p3d, OUTPUT_DIMS)
 
     def extract_reference_features(self, dbids, pose: Optional[Pose] = None, reference_image=None):
@@ -180,8 +247,9 @@ class PoseTrackerRefiner:
             pose = Pose.from_Rt(ref_img.qvec2rotmat(), ref_img.tvec)
         features = {}
         for image_scale in multiscales:
-            maps, scales = self.dense_feature_extraction(reference_image, ref_img.name, image_scale)
-            features[str(image_scale)] = self.interp_sparse_observations(maps, scales, dbids[0], p3dids, pose, p3d)
+            image, window = self.reference_window(dbids, pose, reference_image)
+            maps, scales = self.dense_feature_extraction(image, ref_img.name, image_scale)
+            features[str(image_scale)] = self.interp_sparse_observations(maps, scales, dbids[0], p3dids, pose, p3d, window)
         return features
 
     # ---- pre-extracted reference features (reference :175-198) ---------------------------

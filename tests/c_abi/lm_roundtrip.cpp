@@ -100,7 +100,7 @@ int main() {
   hipStream_t stream;
   CK(hipStreamCreate(&stream));
 
-  pxt_sample_level sl;
+  pxt_sample_level sl = {};  // (zero: no window of a larger level)
   sl.fmap = d_map; sl.out = d_ref; sl.h = H; sl.w = W; sl.C = C; sl.cstride = CS; sl.ndist = 0;
   for (int i = 0; i < 10; ++i) sl.cam[i] = cam[i];
   int rc = pxt_sample_sparse(d_p3d, N, T_gt, &sl, 1, 1, 1, d_valid, stream);

@@ -136,7 +136,9 @@ def test_ycb_refshape_frame_matches_oracle_fixture(device):
     R, t = ret["T_refined"].numpy()
     assert geodesic_distance_for_rotations(R, g["R"]) < 1e-3 and np.linalg.norm(t - g["t"]) < 1e-3
     assert ret["cost"] == pytest.approx(float(g["cost"]), rel=0.03)
-    assert tr.localizer.refiner.feature_extractor.last_input_wh in ((921, 921), (640, 480))
+    # (the reference pass runs on the window of the 921 x 921 render its points depend on: test_reference_window_gpu.py)
+    w_in, h_in = tr.localizer.refiner.feature_extractor.last_input_wh
+    assert (w_in, h_in) == (640, 480) or (w_in <= 921 and h_in <= 921 and w_in % 16 in (0, 921 % 16))
     mask = tr.localizer.refiner.query_mask.cpu().numpy()
     want = np.unpackbits(g["mask_bits"])[: 640 * 480].reshape(480, 640)
     assert int(mask.sum()) == int(g["mask_sum"]) and int((mask != want).sum()) == 0
