@@ -34,6 +34,9 @@ from .unet import OUTPUT_DIMS, UNet
 from .utils.conf import Conf, merge
 
 logger = logging.getLogger(__name__)
+import os as _os
+
+_WINDOW_ENV = _os.environ.get("PXT_REF_WINDOW", "1") != "0"  # A/B knob: 0 = the reference pass always on the whole render
 
 
 class SparseReferenceFeatures(dict):
@@ -149,7 +152,7 @@ class PoseTrackerRefiner:
         if memo is not None and memo[0] is reference_image and memo[1] is pose:
             return memo[2], memo[3]
         out = (reference_image, None)
-        if self.conf.get("reference_window", True) and torch.is_tensor(reference_image) and pose is not None \
+        if self.conf.get("reference_window", True) and _WINDOW_ENV and torch.is_tensor(reference_image) and pose is not None \
                 and (self.conf.multiscale or [1]) == [1]:
             H, W = int(reference_image.shape[0]), int(reference_image.shape[1])
             ex = self.feature_extractor

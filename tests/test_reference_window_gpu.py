@@ -95,13 +95,14 @@ def test_windowed_reference_features_equal_the_full_pass(device):
     ref_u8 = tr.get_reference_image(pose)
     assert tuple(ref_u8.shape[:2]) == (921, 921)
     refiner.conf.multiscale = [1]
-    image, window = refiner.reference_window(tr.reference_ids, pose, ref_u8)
+    dbids = [sorted(refiner.model3d.dbs)[0]]  # (the YCB policy picks its reference inside refine(); any image's points do)
+    image, window = refiner.reference_window(dbids, pose, ref_u8)
     assert window is not None and image.shape[0] * image.shape[1] <= 0.65 * 921 * 921, (window, image.shape)
     assert window[0] % 16 == 0 and window[1] % 16 == 0 and window[2:] == (921, 921)
-    got = refiner.extract_reference_features(tr.reference_ids, pose, ref_u8)["1"]
+    got = refiner.extract_reference_features(dbids, pose, ref_u8)["1"]
     refiner.conf.reference_window = False
     refiner._window_memo = None
-    want = refiner.extract_reference_features(tr.reference_ids, pose, ref_u8)["1"]
+    want = refiner.extract_reference_features(dbids, pose, ref_u8)["1"]
     assert torch.equal(got.valid, want.valid) and int(want.valid.sum()) > 1000
     keep = want.valid.bool()
     for a, b, c in zip(got.packed, want.packed, OUTPUT_DIMS):
