@@ -77,7 +77,7 @@ def lm_algorithmic_mb(n_points, iters, channels):
     return sum(it * n_points * (12 * (c + 1) * 4 + 12 + (c + 1) * 4) for it, c in zip(iters, channels)) / 1e6
 
 
-def stage_rooflines(tracker, frames, names, lo, hi, dev):
+def stage_rooflines(tracker, frames, names, lo, hi, dev, run_frame=None):
     """Live per-stage rooflines of the UNet and the LM from an untimed pass over frames[lo:hi]:
     HIP events around the frame's two-image UNet call with the join INSIDE the call, and around the LM launch; render-ahead
     off so that nothing rides behind the LM kernel.  UNet: GFLOP of the sizes actually run / ms against the dense fp16 MFMA
@@ -117,7 +117,10 @@ def stage_rooflines(tracker, frames, names, lo, hi, dev):
     try:
         torch.cuda.synchronize()
         for i in range(lo, hi):
-            tracker.run_single_frame((names[i], frames[i]))
+            if run_frame is not None:
+                run_frame(i)
+            else:
+                tracker.run_single_frame((names[i], frames[i]))
             iters.append([list(r.iters) for r in tracker.localizer.refiner.last_lm])
         torch.cuda.synchronize()
     finally:
@@ -356,6 +359,34 @@ def other_config_extra(argv, timeout_s=240):
         return {"frames_per_s": None, "what": "python bench.py " + " ".join(argv), "error": repr(e)[:200]}
 
 
+def refshape_stage_block(tr, run_frame, lo, hi, dev):
+    """`roofline_refshape` of an extra pass: per-stage HIP-event ms over frames [lo, mid) with the
+    render-ahead off, then the live UNet / LM rooflines over [mid, hi) - where a real-asset frame's time goes."""
+    mid = (lo + hi) // 2
+    timer = StageTimer()
+    for attr in ("render_device", "render_both_device", "render_frame_device"):
+        timer.wrap(tr.testbed, attr, "nerf_render")
+    timer.wrap(tr.localizer.extractor.model, "forward_packed_batch", "unet")
+    timer.wrap(tr.localizer.refiner, "refine_pose_using_features", "lm")
+    timer.wrap(tr.localizer.refiner, "interp_sparse_observations", "sample")
+    ahead = tr.render_ahead
+    tr.render_ahead = False
+    tr._ahead_ok = None
+    torch.cuda.synchronize()
+    timer.enabled = True
+    for i in range(lo, mid):
+        run_frame(i)
+    torch.cuda.synchronize()
+    timer.enabled = False
+    tr.render_ahead = ahead
+    stage = {k: round(v[0] / max(mid - lo, 1), 4) for k, v in timer.totals_ms().items()}
+    roof = stage_rooflines(tr, None, None, mid, hi, dev, run_frame=run_frame)
+    dom = max(stage, key=stage.get) if stage else None
+    return {"stage_ms_per_frame": stage, "dominant_stage": dom, **roof,
+            "what": f"untimed: HIP-event stage times over {mid - lo} frames (render-ahead off; the two renders of a frame run side by "
+                    "side, so `nerf_render` counts their overlapped launches twice), then the UNet call / LM launch with events"}
+
+
 def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
     """BASELINE configs[2]'s policy (pixloc_tracker_ycb.py:241-295: mask every frame, GT-gated pose update, reference
     camera x 0.3, render box from the SfM points) on the synthetic unit-cube object at 640x480: per frame two renders of
@@ -370,8 +401,9 @@ def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
                                         render_query_frames)
 
     kw = dict(ref_camera=REF_CAMERA_YCB, query_f=YCB_QUERY_FXY[0]) if refshape else {}
-    assets = make_tracking_assets(seed=1005, width=640, height=480, n_frames=n, aabb=CRACKER_BOX_AABB, reference_scale=0.3,
-                                  n_points=5600, **kw)
+    n_diag = 12 if refshape else 0
+    assets = make_tracking_assets(seed=1005, width=640, height=480, n_frames=n + n_diag, aabb=CRACKER_BOX_AABB,
+                                  reference_scale=0.3, n_points=5600, **kw)
     tr = ycb.PixLocPoseTrackerYCB("", "", "/tmp", "003_cracker_box", device=dev, assets=assets)
     f = float(assets["query_camera"]["params"][0])
     fxy = YCB_QUERY_FXY if refshape else (f, f)
@@ -387,6 +419,9 @@ def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
         ok += int(good and i >= lead)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    block = None
+    if refshape:
+        block = refshape_stage_block(tr, lambda i: tr.refine((f"{i + 1:06d}-color.png", frames[i], gts[i], cam)), n, n + n_diag, dev)
     what = ("the YCB policy (configs[2]) on the synthetic unit-cube object, 640x480, 5600 points, reference at 0.3 x: "
             "two renders of different cameras + two UNet passes of different sizes per frame, each pair side by side")
     if refshape:
@@ -394,7 +429,9 @@ def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
                 "reference render + UNet pass, query 640x480 with fx 1066.778 / fy 1067.487, c (319.5, 239.5)")
     return {"frames_per_s": round((n - lead) / dt, 2), "frames": n - lead, "tracked_ok": ok,
             "renders_ahead_used": int(tr.renders_ahead_used),
-            "reference_render_wh": [int(x) for x in tr._reference_camera().size], "what": what}
+            "reference_render_wh": [int(x) for x in tr._reference_camera().size],
+            "reference_unet_input_wh": [int(x) for x in (getattr(tr.localizer.refiner, "last_reference_wh", None) or (0, 0))],
+            **({"roofline_refshape": block} if block else {}), "what": what}
 
 
 def r9_refshape_extra(dev, ref_camera, label, n=44, lead=10):
@@ -405,17 +442,19 @@ def r9_refshape_extra(dev, ref_camera, label, n=44, lead=10):
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
     from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
 
-    assets = make_tracking_assets(seed=1002, width=640, height=480, n_frames=n, ref_camera=ref_camera)
+    n_diag = 12
+    assets = make_tracking_assets(seed=1002, width=640, height=480, n_frames=n + n_diag, ref_camera=ref_camera)
     tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=dev, assets=assets)
     frames = render_query_frames(assets, tr.testbed)
-    names = [f"{i:06d}.png" for i in range(n)]
+    names = [f"{i:06d}.png" for i in range(n + n_diag)]
     for i in range(lead):
         tr.run_single_frame((names[i], frames[i]))
     fps, ok = _timed_frames(tr, frames, names, lead, n)
     rw, rh = (int(x) for x in tr._reference_camera().size)
-    ex = tr.localizer.extractor
+    block = refshape_stage_block(tr, lambda i: tr.run_single_frame((names[i], frames[i])), n, n + n_diag, dev)
     return {"frames_per_s": round(fps, 2), "frames": n - lead, "tracked_ok": ok, "reference_render_wh": [rw, rh],
-            "reference_unet_input_wh": [int(x) for x in getattr(ex, "last_input_wh", (rw, rh))],
+            "reference_unet_input_wh": [int(x) for x in (getattr(tr.localizer.refiner, "last_reference_wh", None) or (rw, rh))],
+            "roofline_refshape": block,
             "renders_ahead_used": int(tr.renders_ahead_used),
             "what": f"r9 policy, query 640x480, SfM camera 1 = {label} x 0.5 -> {rw}x{rh} reference render"}
 

@@ -252,6 +252,7 @@ class PoseTrackerRefiner:
         for image_scale in multiscales:
             image, window = self.reference_window(dbids, pose, reference_image)
             maps, scales = self.dense_feature_extraction(image, ref_img.name, image_scale)
+            self.last_reference_wh = self.feature_extractor.last_input_wh  # (w, h) the reference pass ran at
             features[str(image_scale)] = self.interp_sparse_observations(maps, scales, dbids[0], p3dids, pose, p3d, window)
         return features
 

@@ -47,6 +47,19 @@ def test_single_gpu_line_has_the_contract_fields(device):
         assert ex[k]["reference_render_wh"] == wh and ex[k]["frames_per_s"] > 30.0, (k, ex[k])
         assert ex[k]["tracked_ok"] == ex[k]["frames"], (k, ex[k])
     assert ex["value_r9_12mp"]["reference_unet_input_wh"] in ([1024, 768], [640, 480])
+    # the real-asset frame as a measured object: stage times + live UNet / LM rooflines of those passes
+    for k in ("value_ycb_refshape", "value_r9_phone"):
+        rb = ex[k]["roofline_refshape"]
+        assert set(rb["stage_ms_per_frame"]) >= {"nerf_render", "unet", "lm"} and 0.05 < rb["unet"]["frac"] < 1.0, (k, rb)
+        assert rb["lm"]["kernel_us"] > 10.0 and rb["unet"]["image_sizes_hw"][1] == [480, 640], (k, rb)
+        # the reference pass ran on a window of the render (refiner.reference_window), not on all of it
+        w, h = ex[k]["reference_unet_input_wh"]
+        assert w * h < 0.7 * ex[k]["reference_render_wh"][0] * ex[k]["reference_render_wh"][1], (k, ex[k])
+    # live per-stage rooflines of the headline run; what is read from committed profiles says so
+    rs = d["roofline_stages"]
+    assert 0.05 < rs["unet"]["frac"] < 1.0 and rs["unet"]["gflop_per_call"] == pytest.approx(2 * 241.4, rel=0.02), rs["unet"]
+    assert 0.01 < rs["lm"]["frac"] < 1.0 and sum(rs["lm"]["iterations_per_level_mean"]) >= 3, rs["lm"]
+    assert d["roofline"]["traffic_static"]["static"] is True and d["kernel_utilisation"]["static"] is True
     assert ex["value_two_renders"]["frames_per_s"] < d["value"] * 1.05
     assert ex["value_ycb_policy"]["renders_ahead_used"] >= ex["value_ycb_policy"]["frames"] - 2
 
