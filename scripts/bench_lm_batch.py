@@ -1,5 +1,6 @@
 """Micro-benchmark of pxt_lm_refine_batch: K copies of one problem (own buffers), time per call vs K and grid per problem.
-    python scripts/bench_lm_batch.py [N]        (PXT_LM_BATCH_MAP=1: contiguous workgroups per problem)"""
+    python scripts/bench_lm_batch.py [N] [K list, e.g. 1,8] [grid list, e.g. 0,32]
+    (PXT_LM_BATCH_MAP=1: contiguous workgroups per problem; PXT_LM_XCD_LOCAL=1: the K = 8 exchange through one XCD's L2)"""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -46,8 +47,8 @@ def main():
                       "camera": None})
     bws = torch.zeros(int(_lib.lib().pxt_lm_batch_workspace_bytes(8)), dtype=torch.uint8, device=dev)
     for stops in ("default", "never"):
-        for K in (1, 2, 4, 8):
-            for grid in (0, 16, 24, 32, 40, 48, 64):
+        for K in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8)):
+            for grid in ([int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (0, 16, 24, 32, 40, 48, 64)):
                 conf = dict(num_iters=150 if stops == "default" else 40, pad=1, n_workgroups=grid)
                 if stops == "never":
                     conf.update(grad_stop_criteria=0.0, dt_stop_criteria=0.0, dR_stop_criteria=0.0)

@@ -50,5 +50,5 @@ python scripts/bench_unet_batch.py --sizes 2,4,8,16 > $out/${r}_bench_unet_batch
 python scripts/bench_conv.py --all-cfgs > $out/${r}_conv_cfgs.log 2>&1
 python bench.py > $out/${r}_bench.json 2> $out/${r}_bench.err
 python bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras > $out/${r}_bench_k200.json 2>/dev/null
-rm -rf $out/kt $out/pf $out/pw $out/psq $out/pl1 $out/pl2 $out/ut $out/rs_* $out/rsq_* $out/o8 $out/o8sq  # (databases: too large to carry back)
+rm -rf $out/pf $out/pw $out/psq $out/pl1 $out/pl2 $out/ut $out/rs_* $out/rsq_* $out/o8 $out/o8sq  # (databases: too large to carry back)
 ls -la $out | head -60
