@@ -124,3 +124,48 @@ def test_object_configs_match_the_reference_shell_files():
     assert pp["OBJ_AABB"] == [[0.359, -0.248, 0.047], [0.627, 0.223, 0.574]] and pp["UPRIGHT_REF_IMG"] == "mapping/IMG_2520.png"
     for o in objs:  # boxes come out ordered even where the shell file has them swapped (motor_core)
         assert all(a < b for a, b in zip(*o["aabb"]))
+
+
+def _objects_worker(rank, ws, port, q):
+    """bench.py --config objects8 on N < 8 ranks: rank r carries objects r, r + N, ... of config/*.sh; the per-object pose
+    records of a rank travel as one block (objects in the rank's order, frames within an object) through the one gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    objs = parallel.load_object_configs()
+    units = parallel.shard_units(len(objs), rank, ws)
+    steps = 3
+    recs = []
+    for u in units:
+        hist = {f"{i:06d}.png": {"success": True, "T_init": Pose(torch.zeros(12, dtype=torch.float64)),
+                                  "T_refined": Pose(torch.full((12,), float(10 * u + i), dtype=torch.float64)), "cost": float(u)}
+                for i in range(steps)}
+        recs.append(parallel.pack_pose_records(hist, sorted(hist)))
+    gathered = parallel.gather_pose_records(torch.cat(recs))
+    units_all = parallel.gather_objects(units)
+    q.put((rank, units, [objs[u]["name"] for u in units], units_all, [g.shape[0] for g in gathered],
+           [g[:, 13].tolist() for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("ws", [2, 4])
+def test_eight_objects_dealt_to_fewer_ranks(ws):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_objects_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=100) for _ in range(ws))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert sorted(u for o in out for u in o[1]) == list(range(8))       # every object on exactly one rank
+    assert all(len(o[1]) == 8 // ws for o in out)                          # 8 / N per rank
+    assert out[0][2][0] == "bottle" and out[1][2][0] == "cracker_box"      # rank r starts with object r
+    for o in out:
+        assert o[3] == [list(range(r, 8, ws)) for r in range(ws)]          # every rank knows every rank's objects
+        assert o[4] == [3 * (8 // ws)] * ws                                # 3 frames of each of its objects per rank
+        # the cost column carries the object index: rank r's block is its objects in order, 3 frames each
+        assert o[5] == [[float(u) for u in range(r, 8, ws) for _ in range(3)] for r in range(ws)]
