@@ -278,7 +278,8 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
     (c) `value_k200`: the headline configuration over the 200 frames that follow (the per-frame cost drifts
         along the synthetic orbit as the object turns its broad side to the camera);
     (d) `value_ycb_policy`: the YCB tracker's policy on its own synthetic object (ycb_policy_extra);
-    (e) `value_objects8_rank0`, `value_hd`: the other two workloads at N = 1, each its own run of this file."""
+    (e) `value_objects8_one_gpu` (configs[3] at N = 1: all eight config/*.sh objects in lock-step, with the comparison
+        against eight one-object runs), `value_hd`: the other two workloads at N = 1, each its own run of this file."""
     import gc
 
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
@@ -340,21 +341,29 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
         except Exception as e:  # (reported, never fatal: the headline line must come out)
             out[key] = {"frames_per_s": None, "error": repr(e)[:300]}
     # BASELINE configs[3] / [4] at N = 1, each as its own `--config` run of this file: one driver record for all three workloads
-    for key, argv in (("value_objects8_rank0", ["--config", "objects8", "--steps", "20", "--warmup", "5"]),
+    for key, argv in (("value_objects8_one_gpu", ["--config", "objects8", "--steps", "20", "--warmup", "5"]),
                       ("value_hd", ["--config", "hd", "--steps", "12", "--warmup", "3"])):
         out[key] = other_config_extra(argv)
     return out
 
 
-def other_config_extra(argv, timeout_s=240):
+def other_config_extra(argv, timeout_s=420):
     import subprocess
 
     try:
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], capture_output=True, text=True, timeout=timeout_s,
                            env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
         line = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"frames_per_s": line["value"], "frames": line["steps"], "tracked_ok": line.get("tracked_ok"),
-                "ms_per_step": line["ms_per_step"], "what": "python bench.py " + " ".join(argv) + ": " + line["config"]["workload"][:160]}
+        rec = {"frames_per_s": line["value"], "frames": line.get("frames_total", line["steps"]), "tracked_ok": line.get("tracked_ok"),
+               "ms_per_step": line["ms_per_step"], "what": "python bench.py " + " ".join(argv) + ": " + line["config"]["workload"][:200]}
+        if line.get("solo_runs"):  # objects8 in lock-step: the comparison against one-object runs and the batched stages
+            rec["solo_aggregate_frames_per_s"] = line["solo_runs"]["aggregate_frames_per_s"]
+            rec["lockstep_speedup"] = line["solo_runs"]["lockstep_speedup"]
+            rec["max_abs_pose_difference_vs_solo"] = max(line["solo_runs"]["max_abs_pose_difference_vs_lockstep"])
+            st = line.get("roofline_stages") or {}
+            rec["unet_batched"] = {k: st["unet"][k] for k in ("images_per_call", "ms_per_image_pair", "achieved", "frac")} if "unet" in st else None
+            rec["lm_batched"] = {k: st["lm"][k] for k in ("problems_per_launch", "kernel_us", "us_per_problem")} if "lm" in st else None
+        return rec
     except Exception as e:  # (reported, never fatal: the headline line must come out)
         return {"frames_per_s": None, "what": "python bench.py " + " ".join(argv), "error": repr(e)[:200]}
 
@@ -666,15 +675,23 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
                         "all frames / summed time); pose difference = largest |element| difference of the 12 pose floats"}
     if rank != 0:
         return
-    rot, tra = [], []
+    rot, tra, per_obj = [], [], {}
     for tr, u in zip(trackers, units):
+        r_u, t_u = [], []
         for k, nm in enumerate(timed):
             ret = tr.pose_history[nm]
             if ret.get("success"):
                 Rr, tt = ret["T_refined"].numpy()
                 Rg, tg = assets[u]["gt_poses"][args.warmup + k]
-                rot.append(float(np.arccos(np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1))))
-                tra.append(float(np.linalg.norm(tt - tg)))
+                r_u.append(float(np.arccos(np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1))))
+                t_u.append(float(np.linalg.norm(tt - tg)))
+        rot += r_u
+        tra += t_u
+        # (per object, against the SYNTHETIC ground truth - ADVICE r4: the record of what each object's track looks like)
+        per_obj[objs[u]["name"]] = {"mean_rot_err_rad": round(float(np.mean(r_u)), 6) if r_u else None,
+                                    "max_rot_err_rad": round(float(np.max(r_u)), 6) if r_u else None,
+                                    "mean_trans_err": round(float(np.mean(t_u)), 6) if t_u else None,
+                                    "camera_distance": round(float(np.linalg.norm(assets[u]["gt_poses"][args.warmup][1])), 3)}
     out = {
         "metric": "tracked frames/sec at 640x480 (8 objects of config/*.sh tracked concurrently; full NeRF render + UNet + LM loop)",
         "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
@@ -693,6 +710,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
         "renders_ahead_used": [int(tr.renders_ahead_used) for tr in trackers],
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot)), 6) if rot else None,
         "mean_trans_err_vs_gt": round(float(np.mean(tra)), 6) if tra else None,
+        "per_object_error_vs_synthetic_gt": per_obj,
         "roofline": None, "roofline_stages": stages, "solo_runs": solo,
         "cpu_baseline": {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                          "sample": "reported with the frames640 workload only"},
