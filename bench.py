@@ -649,7 +649,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
     solo = None
     if ws == 1 and not args.no_solo:
         # the same frames through eight ONE-object trackers, one after the other: what the lock-step run is compared with
-        fps, diffs = [], []
+        fps, diffs, solo_err, lock_err, solo_ok = [], [], [], [], 0
         for u, tr_multi in zip(units, trackers):
             tr = fresh(u)
             gc.collect()
@@ -663,14 +663,23 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
             torch.cuda.synchronize()
             fps.append(args.steps / (time.perf_counter() - t1))
             gc.enable()
+            solo_ok += sum(1 for nm in timed if tr.pose_history[nm].get("success"))
             a = parallel.pack_pose_records(tr.pose_history, timed)[:, :12]
             b = parallel.pack_pose_records(tr_multi.pose_history, timed)[:, :12]
             diffs.append(float((a - b).abs().max()))
+            # (and each run against the synthetic ground truth: a difference between the two runs is read against these)
+            for rec, store in ((a, solo_err), (b, lock_err)):
+                e = []
+                for k in range(len(timed)):
+                    Rr, Rg = rec[k, :9].reshape(3, 3).numpy(), assets[u]["gt_poses"][args.warmup + k][0]
+                    e.append(float(np.arccos(np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1))))
+                store.append(round(float(np.max(e)), 5))
             del tr
         agg = len(units) * args.steps / sum(args.steps / f for f in fps)
         solo = {"frames_per_s_per_object": [round(f, 1) for f in fps], "aggregate_frames_per_s": round(agg, 2),
-                "lockstep_speedup": round(total_frames / elapsed / agg, 3),
+                "lockstep_speedup": round(total_frames / elapsed / agg, 3), "tracked_ok": solo_ok,
                 "max_abs_pose_difference_vs_lockstep": [float(f"{d:.3g}") for d in diffs],
+                "max_rot_err_vs_gt_rad_solo": solo_err, "max_rot_err_vs_gt_rad_lockstep": lock_err,
                 "what": "untimed second pass: the same frames tracked by one-object trackers one after the other (aggregate = "
                         "all frames / summed time); pose difference = largest |element| difference of the 12 pose floats"}
     if rank != 0:

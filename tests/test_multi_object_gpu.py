@@ -37,8 +37,8 @@ def _poses(tr, names):
     return np.stack(out)
 
 
-@pytest.mark.parametrize("per_image_plan,lm_grid", [(True, 32), (False, 0)])
-def test_lockstep_equals_solo_runs(device, per_image_plan, lm_grid):
+@pytest.mark.parametrize("per_image_plan,lm_grid,n_groups", [(True, 32, 1), (True, 32, 2), (False, 0, 1), (False, 0, 2)])
+def test_lockstep_equals_solo_runs(device, per_image_plan, lm_grid, n_groups):
     """Four objects (four different config/*.sh boxes), 8 frames each at 320x240.  With the per-image UNet plan and the
     same LM grid the lock-step poses are BIT-identical to four solo runs; with the defaults (batch-planned layers, 256 / K
     workgroups per problem) they agree to fp32 summation order."""
@@ -55,7 +55,7 @@ def test_lockstep_equals_solo_runs(device, per_image_plan, lm_grid):
         frames.append(fr)
         assert solo[-1][:, 12].all(), (k, solo[-1][:, 12])
     trackers = [_make(device, k, w, h, n, lm_grid=lm_grid)[0] for k in ks]
-    multi = MultiObjectTracker(trackers, lm_workgroups=lm_grid, per_image_plan=per_image_plan)
+    multi = MultiObjectTracker(trackers, lm_workgroups=lm_grid, per_image_plan=per_image_plan, n_groups=n_groups)
     for i in range(n):
         ok = multi.run_single_frames([(names[i], frames[j][i]) for j in range(len(ks))])
         assert all(ok), (i, ok)
