@@ -41,6 +41,7 @@ class _Group:
 
     def __init__(self, index, members, stream, model):
         self.index, self.members, self.stream, self.model = index, members, stream, model
+        self.render_streams: List[torch.cuda.Stream] = []  # optional sub-streams of the group's queued renders
         self.batch_ws: Optional[torch.Tensor] = None
         self.unet_done: Optional[torch.cuda.Event] = None
         self.pend = None  # what _enqueue left for _finish
@@ -48,7 +49,8 @@ class _Group:
 
 class MultiObjectTracker:
     def __init__(self, trackers: Sequence[PixLocPoseTrackerR9], lm_workgroups: int = 0, per_image_plan: bool = False,
-                 max_unet_batch: int = _lib.PXT_UNET_MAX_BATCH, n_groups: int = 1):
+                 max_unet_batch: int = _lib.PXT_UNET_MAX_BATCH, n_groups: int = 1, render_pipelines: int = -1,
+                 render_streams: int = 1):
         """``n_groups`` > 1: the trackers are dealt to that many groups, each with its own stream, batched UNet pass and
         batched LM launch per step; the groups' UNet passes take turns (an event token), so that one group's MFMA-bound
         UNet pass runs beside the other group's latency-bound renders instead of beside its UNet pass."""
@@ -66,6 +68,8 @@ class MultiObjectTracker:
             if getattr(tr.localizer.extractor.model, "weights_signature", None) != sig:
                 raise _lib.PxtError("lock-step trackers must share one UNet checkpoint")
         self.groups: List[_Group] = []
+        self.render_pipelines = int(render_pipelines)  # -1: one pipeline per render with several groups, else the default
+        self.render_streams = int(render_streams)      # sub-streams per group for the queued renders (experiment: 1 = none)
         self.set_groups(n_groups)
         self.lm_workgroups = int(lm_workgroups)      # grid per problem of the batched launch; 0: the library's default
         self.per_image_plan = bool(per_image_plan)   # UNet layers planned as for one image (bit-identity with solo runs)
@@ -87,8 +91,16 @@ class MultiObjectTracker:
             members = list(range(g, len(self.trackers), n_groups))
             stream = None if n_groups == 1 else torch.cuda.Stream(self.device)
             self.groups.append(_Group(g, members, stream, self.trackers[members[0]].localizer.extractor.model))
+            if n_groups > 1 and self.render_streams > 1:
+                self.groups[-1].render_streams = [torch.cuda.Stream(self.device) for _ in range(self.render_streams)]
         self.model = self.groups[0].model
         self._last_unet_done = None
+        # With several groups the concurrency a render needs comes from the OTHER group's UNet pass: one pipeline per
+        # render (no fork / join between two half-renders) is faster there (898 -> 931 frames/s for eight objects); one
+        # group keeps the renderer's default of two pipelines over the two halves of the rays.  Bit-identical either way.
+        pipes = self.render_pipelines if self.render_pipelines >= 0 else (1 if n_groups > 1 else 0)
+        for tr in self.trackers:
+            tr.testbed.set_pipelines(pipes)
 
     # ------------------------------------------------------------------ helpers
     def _lm_batch_ws(self, grp: _Group) -> torch.Tensor:
@@ -224,10 +236,32 @@ class MultiObjectTracker:
         it = iter(handles)
         grp.pend = [(k, tr, path, ref_id, dbg, status, x, next(it) if status == "lm" else None)
                     for (k, tr, path, ref_id, dbg, status, x) in pend]
+        subs = grp.render_streams
+        if subs:  # the group's queued renders dealt to sub-streams behind the LM launch, joined before the next UNet pass
+            cur = torch.cuda.current_stream(self.device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            for st in subs:
+                st.wait_event(fork)
+        j = 0
         for k, tr, path, ref_id, dbg, status, x, handle in grp.pend:
             hook = getattr(tr.localizer.refiner, "after_lm_enqueued", None)
             if handle is not None and hook is not None:
-                hook(handle)
+                if subs:
+                    with torch.cuda.stream(subs[j % len(subs)]):
+                        hook(handle)
+                    if tr._ahead is not None:  # (mask, 8-bit reference image: read on the group's stream next step)
+                        for t in tr._ahead[1:3]:
+                            if torch.is_tensor(t):
+                                t.record_stream(cur)
+                    j += 1
+                else:
+                    hook(handle)
+        if subs:
+            for st in subs:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
         self._mark("ahead_enqueued")
 
     def _finish(self, grp: _Group, frames, out) -> None:

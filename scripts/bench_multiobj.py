@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-solo", action="store_true")
     ap.add_argument("--phases", action="store_true")
     ap.add_argument("--groups", type=int, default=1)
+    ap.add_argument("--render-pipelines", type=int, default=-1)
+    ap.add_argument("--render-streams", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     objs = parallel.load_object_configs()
@@ -79,7 +81,8 @@ def main():
         out["solo_fps"] = [round(f, 1) for f in fps]
         out["solo_aggregate_fps"] = round(K * args.steps / sum(args.steps / f for f in fps), 1)  # one after the other
     multi = MultiObjectTracker(trackers, lm_workgroups=args.lm_grid, per_image_plan=args.per_image_plan,
-                               max_unet_batch=args.max_unet_batch, n_groups=args.groups)
+                               max_unet_batch=args.max_unet_batch, n_groups=args.groups,
+                               render_pipelines=args.render_pipelines, render_streams=args.render_streams)
     gc.collect()
     gc.disable()
     for i in range(args.warmup):
