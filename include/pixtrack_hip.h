@@ -126,7 +126,7 @@ int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_poi
                       void* workspace, const pxt_lm_camera* cam_host, void* stream);
 
 /* K independent refinements in ONE persistent launch - K objects tracked in lock-step on one GPU (BASELINE configs[3]:
- * the eight objects of /root/reference/config/*.sh, one tracker per object as
+ * the eight objects of /root/reference/config/<object>.sh, one tracker per object as
  * pixtrack/pose_trackers/pixloc_tracker_r9.py:287-318 builds it; on fewer than 8 GPUs a rank carries 8 / N of them).
  * Each problem is exactly one pxt_lm_refine_cam call - own points, levels, initial pose, output record, log, workspace
  * (pxt_lm_workspace_bytes() each, all different) and optional camera record - and is solved by its own share of the

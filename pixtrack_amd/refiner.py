@@ -143,7 +143,7 @@ class PoseTrackerRefiner:
     # sampler reads it as a window of the full maps (pxt_sample_level.x0 ..).  Every sampled texel's whole dependency
     # cone lies inside the window, so it sees exactly the inputs it sees in the full pass; what differs is only which
     # tile configuration / split-K factor a layer of that size takes, i.e. fp32 summation order.
-    WINDOW_MARGIN = 160   # >= 130 + 1 (bilinear) + 16 (alignment) + a lens-distortion allowance, a multiple of 16
+    WINDOW_MARGIN = 160   # >= 135 (dependency radius) + 1 (the bilinear sample's second texel) + 16 (alignment), a multiple of 16
     WINDOW_MIN_SAVING = 0.35  # a window is used when it drops at least this share of the image's pixels
 
     def reference_window(self, dbids, pose: Optional[Pose], reference_image):
@@ -165,10 +165,14 @@ class PoseTrackerRefiner:
                 p = xyz @ np.asarray(R, np.float64).T + np.asarray(t, np.float64)
                 front = p[:, 2] > 1e-3
                 if front.any():
-                    fx, fy = (float(v) for v in cam.f)
-                    cx, cy = (float(v) for v in cam.c)
-                    u = fx * p[front, 0] / p[front, 2] + cx
-                    v = fy * p[front, 1] / p[front, 2] + cy
+                    c10 = [float(x) for x in cam.as10().tolist()]  # w, h, fx, fy, cx, cy, k1, k2, p1, p2
+                    fx, fy, cx, cy, k1, k2, p1, p2 = c10[2:10]
+                    xn, yn = p[front, 0] / p[front, 2], p[front, 1] / p[front, 2]
+                    r2 = xn * xn + yn * yn  # the camera model of the sampler (pxt_common.h project_point), in float64
+                    rad = k1 * r2 + k2 * r2 * r2
+                    xd = xn + xn * rad + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn)
+                    yd = yn + yn * rad + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn)
+                    u, v = fx * xd + cx, fy * yd + cy
                     inside = (u >= 0) & (v >= 0) & (u <= W - 1) & (v <= H - 1)
                     if inside.any():
                         m = self.WINDOW_MARGIN

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -142,6 +143,43 @@ int main() {
   ok = ok && pxt_lm_refine(nullptr, nullptr, N, &lv, 1, T0, &conf, d_out, nullptr, d_ws, stream) == PXT_E_ARG;
   ok = ok && pxt_lm_refine(d_p3d, nullptr, N, &lv, PXT_MAX_LEVELS + 1, T0, &conf, d_out, nullptr, d_ws, stream) == PXT_E_ARG;
   ok = ok && pxt_sample_sparse(d_p3d, 0, T_gt, &sl, 1, 1, 1, d_valid, stream) == PXT_E_ARG;
+  // K problems in one persistent launch (pxt_lm_refine_batch): three copies of the problem, own records and workspaces;
+  // every record must equal, bit for bit, a single launch with the same grid
+  {
+    const int K = 3;
+    conf.n_workgroups = 32;
+    float one[16 + PXT_MAX_LEVELS];
+    CK(hipMemset(d_ws, 0, (size_t)pxt_lm_workspace_bytes()));
+    rc = pxt_lm_refine(d_p3d, d_valid, N, &lv, 1, T0, &conf, d_out, nullptr, d_ws, stream);
+    CK(hipStreamSynchronize(stream));
+    CK(hipMemcpy(one, d_out, sizeof(one), hipMemcpyDeviceToHost));
+    ok = ok && rc == PXT_OK && one[15] == 1.f && one[12] == 0.f;
+    float* d_outs[K];
+    void* d_wss[K];
+    void* d_bws = nullptr;
+    pxt_lm_problem probs[K];
+    for (int k = 0; k < K; ++k) {
+      CK(hipMalloc((void**)&d_outs[k], (16 + PXT_MAX_LEVELS) * 4));
+      CK(hipMemset(d_outs[k], 0, (16 + PXT_MAX_LEVELS) * 4));
+      CK(hipMalloc(&d_wss[k], (size_t)pxt_lm_workspace_bytes()));
+      CK(hipMemset(d_wss[k], 0, (size_t)pxt_lm_workspace_bytes()));
+      probs[k] = pxt_lm_problem{d_p3d, d_valid, N, &lv, 1, T0, d_outs[k], nullptr, d_wss[k], nullptr};
+    }
+    CK(hipMalloc(&d_bws, (size_t)pxt_lm_batch_workspace_bytes(K)));
+    rc = pxt_lm_refine_batch(probs, K, &conf, d_bws, stream);
+    if (rc != PXT_OK) { std::printf("pxt_lm_refine_batch -> %d (%s)\n", rc, pxt_last_error()); return 5; }
+    CK(hipStreamSynchronize(stream));
+    for (int k = 0; k < K; ++k) {
+      float got[16 + PXT_MAX_LEVELS];
+      CK(hipMemcpy(got, d_outs[k], sizeof(got), hipMemcpyDeviceToHost));
+      ok = ok && std::memcmp(got, one, 17 * sizeof(float)) == 0;
+    }
+    // two problems on one workspace would read each other's granules: refused
+    probs[1].workspace = probs[0].workspace;
+    ok = ok && pxt_lm_refine_batch(probs, K, &conf, d_bws, stream) == PXT_E_ARG;
+    ok = ok && pxt_lm_refine_batch(probs, PXT_LM_MAX_BATCH + 1, &conf, d_bws, stream) == PXT_E_ARG;
+    std::printf("batched launch of %d problems: %s\n", K, ok ? "records equal the single launch" : "MISMATCH");
+  }
   std::printf(ok ? "C-ABI ROUNDTRIP OK\n" : "C-ABI ROUNDTRIP FAILED\n");
   return ok ? 0 : 1;
 }
