@@ -151,6 +151,13 @@ def stage_rooflines(tracker, frames, names, lo, hi, dev, run_frame=None):
     return out
 
 
+def _tracked(ret) -> bool:
+    """A frame counts as tracked when the TRACKER accepted it (refiner success and the cost gate), parallel.frame_tracked."""
+    from pixtrack_amd.parallel import frame_tracked
+
+    return frame_tracked(ret)
+
+
 class StageTimer:
     """HIP-event timing of a wrapped callable on torch's current stream (the stream every
     pxt_* launch of this process uses)."""
@@ -274,7 +281,7 @@ def _timed_frames(tracker, frames, names, lo, hi):
     finally:
         if was:
             gc.enable()
-    ok = sum(1 for i in range(lo, hi) if tracker.pose_history[names[i]].get("success"))
+    ok = sum(1 for i in range(lo, hi) if _tracked(tracker.pose_history[names[i]]))
     return (hi - lo) / dt, ok
 
 
@@ -315,7 +322,7 @@ def run_extras(tracker, assets, frames, names, warmup, n_timed_end, first_free, 
         finally:
             gc.enable()
         n = n_timed_end - warmup
-        ok = sum(1 for i in range(warmup, n_timed_end) if tr.pose_history[names[i]].get("success"))
+        ok = sum(1 for i in range(warmup, n_timed_end) if _tracked(tr.pose_history[names[i]]))
         return round(n / dt, 2), n, ok
 
     def two_renders(tr):
@@ -683,7 +690,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
             torch.cuda.synchronize()
             fps.append(args.steps / (time.perf_counter() - t1))
             gc.enable()
-            solo_ok += sum(1 for nm in timed if tr.pose_history[nm].get("success"))
+            solo_ok += sum(1 for nm in timed if _tracked(tr.pose_history[nm]))
             a = parallel.pack_pose_records(tr.pose_history, timed)[:, :12]
             b = parallel.pack_pose_records(tr_multi.pose_history, timed)[:, :12]
             diffs.append(float((a - b).abs().max()))
@@ -709,7 +716,7 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
         r_u, t_u = [], []
         for k, nm in enumerate(timed):
             ret = tr.pose_history[nm]
-            if ret.get("success"):
+            if _tracked(ret):
                 Rr, tt = ret["T_refined"].numpy()
                 Rg, tg = assets[u]["gt_poses"][args.warmup + k]
                 r_u.append(float(np.arccos(np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1))))
@@ -990,7 +997,7 @@ def main():
     rot_err, tr_err = [], []
     for i in range(args.warmup, n_timed_end):
         ret = tracker.pose_history[names[i]]
-        if ret.get("success"):
+        if _tracked(ret):
             Rr, tt = ret["T_refined"].numpy()
             Rg, tg = assets["gt_poses"][i]
             c = np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1)

@@ -70,14 +70,22 @@ def load_object_configs() -> List[dict]:
     return objs
 
 
+def frame_tracked(ret: dict) -> bool:
+    """The tracker's decision for a frame: refiner success AND the policy's gate (r9: cost <= 1.1 x the first frame's,
+    pixloc_tracker_r9.py:258-263; `tracked` in the record) - not the refiner's `success` alone, which the reference's
+    poses.pkl carries (a frame the gate rejected keeps `success: True` and a `T_refined` the tracker did NOT adopt)."""
+    return bool(ret.get("tracked", ret.get("success")))
+
+
 def pack_pose_records(history: dict, names: Sequence[str]) -> torch.Tensor:
     """[n_frames, 14] float64 from a tracker's pose_history."""
     out = torch.zeros(len(names), RECORD, dtype=torch.float64)
     for i, n in enumerate(names):
         ret = history[n]
-        T = ret.get("T_refined", ret["T_init"]) if ret.get("success") else ret["T_init"]
+        ok = frame_tracked(ret)
+        T = ret.get("T_refined", ret["T_init"]) if ok else ret["T_init"]
         out[i, :12] = T.as12().detach().cpu().double()
-        out[i, 12] = 1.0 if ret.get("success") else 0.0
+        out[i, 12] = 1.0 if ok else 0.0
         out[i, 13] = float(ret.get("cost", float("nan")))
     return out
 

@@ -575,6 +575,9 @@ class PixLocPoseTrackerR9(PoseTracker):
         refiner.after_lm_enqueued = None
         refiner.lm_camera = None
         self._verify_render_ahead(success)
+        # (`success` stays what the refiner said, as in the reference's poses.pkl; `tracked` - an added key - is the tracker's
+        # decision: refiner success AND the cost gate.  bench.py and the pose gather count THIS one.)
+        ret["tracked"] = success
         ret["camera"] = self.camera
         ret["reference_ids"] = self.reference_ids
         ret["query_path"] = query_path

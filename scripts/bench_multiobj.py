@@ -26,8 +26,9 @@ def poses(tr, names):
     out = []
     for nm in names:
         ret = tr.pose_history[nm]
-        T = ret["T_refined"] if ret.get("success") else ret["T_init"]
-        out.append(np.concatenate([T.as12().double().numpy().reshape(-1), [float(bool(ret.get("success")))]]))
+        ok = parallel.frame_tracked(ret)
+        T = ret["T_refined"] if ok else ret["T_init"]
+        out.append(np.concatenate([T.as12().double().numpy().reshape(-1), [float(ok)]]))
     return np.stack(out)
 
 

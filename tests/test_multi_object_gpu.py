@@ -73,6 +73,54 @@ def test_lockstep_equals_solo_runs(device, per_image_plan, lm_grid, n_groups):
             assert np.array_equal(got[:, 12], solo[j][:, 12])
 
 
+def test_lockstep_with_a_rejected_frame_equals_solo_runs(device):
+    """One object's fourth frame is uniform noise: its refinement runs to the end and the cost gate rejects it (pose kept,
+    success False), the next frame runs unmasked from the old pose, without a queued render (reference
+    pixloc_tracker_r9.py:218-225,258-268; Appendix D.3) - inside the lock-step step, beside objects that carry on.  The
+    batched LM launch then holds problems with and without a camera record.  Decisions, costs and poses equal the solo
+    runs bit for bit (per-image UNet plan, same LM grid, two groups)."""
+    ks, w, h, n, bad_obj, bad_frame = [2, 5, 7], 320, 240, 7, 1, 3
+    names = [f"{i:06d}.png" for i in range(n)]
+    solo, frames, decisions, final = [], [], [], []
+    for j, k in enumerate(ks):
+        tr, assets = _make(device, k, w, h, n, lm_grid=32)
+        fr = render_query_frames(assets, tr.testbed)
+        decisions.append([])
+        if j == bad_obj:
+            g = torch.Generator().manual_seed(3)
+            fr[bad_frame] = (torch.rand(h, w, 3, generator=g) * 255).to(device)
+        for i in range(n):
+            gate = tr.cost_threshold
+            if j == bad_obj and i == bad_frame:
+                tr.cost_threshold = 1e-9  # (at this size the noise frame's cost can stay under the cold start's: force the gate)
+            tr.run_single_frame((names[i], fr[i]))
+            decisions[j].append(bool(tr.success))  # (the tracker's decision: LM success AND the cost gate)
+            if j == bad_obj and i == bad_frame:
+                tr.cost_threshold = gate
+        torch.cuda.synchronize()
+        solo.append(_poses(tr, names))
+        final.append(tr.pose.as12().double().numpy().copy())
+        frames.append(fr)
+    assert decisions[bad_obj] == [i != bad_frame for i in range(n)]  # rejected once, then tracked again
+    assert all(decisions[0]) and all(decisions[2])
+    trackers = [_make(device, k, w, h, n, lm_grid=32)[0] for k in ks]
+    multi = MultiObjectTracker(trackers, lm_workgroups=32, per_image_plan=True, n_groups=2)
+    for i in range(n):
+        gate = trackers[bad_obj].cost_threshold
+        if i == bad_frame:
+            trackers[bad_obj].cost_threshold = 1e-9
+        ok = multi.run_single_frames([(names[i], frames[j][i]) for j in range(len(ks))])
+        if i == bad_frame:
+            trackers[bad_obj].cost_threshold = gate
+        assert ok == [decisions[j][i] for j in range(len(ks))], (i, ok)
+    torch.cuda.synchronize()
+    for j, tr in enumerate(trackers):
+        got = _poses(tr, names)
+        assert np.array_equal(got.view(np.uint64), solo[j].view(np.uint64)), (ks[j], np.abs(got - solo[j]).max())
+        assert np.array_equal(tr.pose.as12().double().numpy(), final[j])
+    assert trackers[bad_obj].relocalization_count >= 2  # the cold start's and the rejected frame's
+
+
 def test_lm_batch_equals_single_launches(device):
     """pxt_lm_refine_batch against K pxt_lm_refine launches with the same grid: every record bit-identical - pose,
     iteration counts and the iteration log - for problems of different sizes, one of them failing (no valid point)."""
