@@ -239,6 +239,16 @@ int pxt_unet_forward_batch(pxt_unet* ctx, int32_t n_images, const void* const* i
                            float* const* out_maps, const int32_t out_cstride[3], const int32_t* normalize,
                            void* workspace, void* stream);
 
+/* Constant-tile skipping in encoder blocks 1-3 (on by default; $PXT_UNET_SKIP=0 turns it off for the process).  The
+ * tracker's images are mostly constant - the masked query is exactly 0 outside the dilated silhouette
+ * (pixloc_tracker_r9.py:224-225), the NeRF reference render exactly 0 outside the object - and a convolution tile whose
+ * whole dependency cone (through every layer up to it) lies in such a region and inside the image equals ONE vector per
+ * layer.  Such tiles (found conservatively from `mask` / a uint8 image on an 8 x 8 block grid) are filled with that
+ * vector - obtained once per layer plan by running the layer's own kernel configuration on a constant map, hence the
+ * very bits the tile would have computed: the maps are unchanged, bit for bit.  An image with neither a mask nor a
+ * uint8 type is computed in full. */
+int pxt_unet_set_tile_skip(pxt_unet* ctx, int32_t on);
+
 /* How a batch of MORE than two images plans its layers.  0 (default): tile configuration and split-K factor chosen for
  * the batch as launched (large batches need no split-K: the fastest).  1: every layer takes the plan a SINGLE image of
  * the tracker's two-stream pair pass takes, whatever the batch size, so each image's maps are bit for bit the maps the

@@ -151,6 +151,7 @@ PROTOTYPES = {
     ),
     "pxt_unet_set_defer_join": (C.c_int, [_VP, _I32]),
     "pxt_unet_set_batch_plan": (C.c_int, [_VP, _I32]),
+    "pxt_unet_set_tile_skip": (C.c_int, [_VP, _I32]),
     "pxt_unet_pair_join": (C.c_int, [_VP, _VP]),
     "pxt_unet_activation_stats": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP]),
     "pxt_unet_workspace_bytes_batch": (_I64, [_VP, _I32, _I32, _I32]),

@@ -54,6 +54,38 @@ struct FusedFirst {
   int enabled;
 };
 
+// Optional per-tile skip (round 5): a tile whose whole dependency cone - through every layer up to this one - lies in a
+// region where the network's INPUT is constant (the masked-out part of the query: pixloc_tracker_r9.py:224-225; the
+// background of the NeRF reference render) and inside the image (no zero padding seen) has the same output vector at
+// every pixel.  `flags[blockIdx.x]` == 0 marks such a tile (computed conservatively from the mask / the image,
+// pxt_unet.hip); the workgroup then stores `value` (the layer's output for that constant input, obtained once by
+// running THIS kernel configuration on a constant map: bit for bit what the tile would have computed) and leaves.
+struct TileSkip {
+  const uint8_t* flags;  // [gridDim.x] or nullptr
+  const half_t* value;   // [Cout]
+};
+
+template <int TH, int BNC, int NT>
+__device__ __forceinline__ void conv_fill_constant_tile(const half_t* __restrict__ value, half_t* __restrict__ out_img,
+                                                        half_t* __restrict__ pool_img, int H, int W, int Cout, int ty0, int tx0,
+                                                        int co0) {
+  constexpr int CH = BNC / 8;  // 16-B pieces per pixel of this workgroup's channel block
+  const half8* cv = (const half8*)(value + co0);
+  for (int i = threadIdx.x; i < TH * 16 * CH; i += NT) {
+    const int c = i % CH, p = i / CH;
+    const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
+    if (y < H && x < W) *(half8*)(out_img + ((size_t)y * W + x) * Cout + co0 + 8 * c) = cv[c];
+  }
+  if (pool_img) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    for (int i = threadIdx.x; i < (TH / 2) * 8 * CH; i += NT) {
+      const int c = i % CH, p = i / CH;
+      const int y = (ty0 >> 1) + (p >> 3), x = (tx0 >> 1) + (p & 7);
+      if (y < Hp && x < Wp) *(half8*)(pool_img + ((size_t)y * Wp + x) * Cout + co0 + 8 * c) = cv[c];
+    }
+  }
+}
+
 struct ConvArgs {
   const half_t* in;      // [n_img][H][W][Cin]  (UPCAT: the skip tensor [n_img][Hs][Ws][Cin - Cp])
   int H, W, Cin;
@@ -66,6 +98,7 @@ struct ConvArgs {
   half_t* pool;          // optional [n_img][H/2][W/2][Cout]: 2x2 max-pool of `out` (gridDim.z == 1 only)
   FusedHead head;        // head.enabled: Cout == 32, gridDim.z == 1
   FusedFirst first;      // first.enabled: Cin == 64, gridDim.z == 1, the FIRST kernel variant
+  TileSkip skip;         // skip.flags: gridDim.z == 1, no fused head
 };
 
 // Host-side mirror of the packed layout: element (cout, tap, cin) lives at
@@ -174,6 +207,12 @@ __global__ __launch_bounds__(256, AR > 3 ? 1 : 2) void conv3x3_v2_kernel(const C
   const int in_w = UPCAT ? a.up.Ws : W;
   const half_t* in = a.in + (size_t)img * (UPCAT ? a.up.Hs : H) * in_w * Cs;
   const half_t* prev = UPCAT ? a.up.prev + (size_t)img * a.up.Hp * a.up.Wp * a.up.Cp : nullptr;
+  if (a.skip.flags != nullptr && a.skip.flags[blockIdx.x] == 0) {  // (workgroup-uniform) a constant tile: fill and leave
+    conv_fill_constant_tile<TH, BNC, 256>(a.skip.value, a.out + (size_t)img * H * W * Cout,
+                                          a.pool ? a.pool + (size_t)img * (H >> 1) * (W >> 1) * Cout : nullptr, H, W, Cout, ty0,
+                                          tx0, co0);
+    return;
+  }
 
   // the workgroup's biases wait in LDS for the epilogue (fetched there from global memory they cost the
   // epilogue ~2.5k cycles of exposed latency; stamps)

@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3x3_v3_kernel(const ConvArgs 
   const int cp0 = UPCAT ? a.up.Cp : 0;         // channels [0, cp0) of the conv input come from `prev`
   const half_t* in = a.in + (size_t)img * (UPCAT ? a.up.Hs : H) * in_w * Cs;
   const half_t* prev = UPCAT ? a.up.prev + (size_t)img * a.up.Hp * a.up.Wp * a.up.Cp : nullptr;
+  if (a.skip.flags != nullptr && a.skip.flags[blockIdx.x] == 0) {  // (workgroup-uniform) a constant tile: pxt_conv_v2.h TileSkip
+    conv_fill_constant_tile<TH, BNC, 256 * KS>(a.skip.value, a.out + (size_t)img * H * W * Cout,
+                                               a.pool ? a.pool + (size_t)img * (H >> 1) * (W >> 1) * Cout : nullptr, H, W, Cout,
+                                               ty0, tx0, co0);
+    return;
+  }
 
   if ((int)threadIdx.x < BNC) s_bias[threadIdx.x] = a.bias[co0 + threadIdx.x];
 

@@ -382,6 +382,73 @@ __global__ void maxpool2_kernel(const half_t* __restrict__ in, int H, int W, int
 }
 
 // ---------------------------------------------------------------------------
+// Constant-tile skipping in encoder blocks 1-3 (round 5; pxt_conv_v2.h TileSkip).
+//  * skip_block_or_kernel: per image an 8 x 8-pixel block grid of "the network's input is NOT the constant here":
+//    a masked query is exactly 0 wherever its mask is 0 (the mask is multiplied into the image ahead of the first
+//    convolution, pixloc_tracker_r9.py:224-225), a NeRF reference render is exactly 0 outside the object.  An image
+//    with neither a mask nor a uint8 type counts as active everywhere.
+//  * skip_tile_flags_kernel: flag per (layer, image, tile) = 1 unless the tile's dependency cone - its pixels' footprint
+//    at full resolution grown by the layer's cumulative radius R - holds no active block and lies inside the image (no
+//    zero padding reached through any layer).  Conservative on both counts: an extra 1 only costs the skip.
+// ---------------------------------------------------------------------------
+struct SkipImages {
+  const void* image[PXT_UNET_MAX_BATCH];
+  const uint8_t* mask[PXT_UNET_MAX_BATCH];
+  int is_u8[PXT_UNET_MAX_BATCH];
+};
+__global__ void skip_block_or_kernel(const SkipImages im, int H, int W, int bh, int bw, uint8_t* __restrict__ grid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y;
+  if (b >= bh * bw) return;
+  const int by = b / bw, bx = b % bw;
+  const uint8_t* mask = im.mask[img];
+  const uint8_t* u8 = im.is_u8[img] ? (const uint8_t*)im.image[img] : nullptr;
+  unsigned any = (mask == nullptr && u8 == nullptr) ? 1u : 0u;
+  if (!any)
+    for (int y = 8 * by; y < min(8 * by + 8, H); ++y)
+      for (int x = 8 * bx; x < min(8 * bx + 8, W); ++x) {
+        if (mask) any |= mask[(size_t)y * W + x];  // (a set mask bit counts whatever the pixel holds)
+        else any |= u8[((size_t)y * W + x) * 3] | u8[((size_t)y * W + x) * 3 + 1] | u8[((size_t)y * W + x) * 3 + 2];
+      }
+  grid[(size_t)img * bh * bw + b] = any ? 1 : 0;
+}
+
+struct SkipLayerGeo {
+  int th, shift, radius, h, w, offset;  // tile rows (x 16 columns), log2 stride, cone radius R in input pixels, layer size, flag offset
+};
+struct SkipGeo {
+  SkipLayerGeo l[6];
+  int n_layers;
+};
+__global__ void skip_tile_flags_kernel(const SkipGeo geo, const uint8_t* __restrict__ grid, int H, int W, int bh, int bw,
+                                       int n_img, uint8_t* __restrict__ flags) {
+  const SkipLayerGeo g = geo.l[blockIdx.y];
+  const int tiles_x = (g.w + 15) >> 4, tiles_y = (g.h + g.th - 1) / g.th;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_img * tiles_x * tiles_y) return;
+  const int img = t / (tiles_x * tiles_y), tile = t % (tiles_x * tiles_y);
+  const int ty0 = (tile / tiles_x) * g.th, tx0 = (tile % tiles_x) * 16;
+  // the tile's pixels at full resolution, grown by R
+  const int y0 = (ty0 << g.shift) - g.radius, y1 = (min(ty0 + g.th, g.h) << g.shift) + g.radius;  // [y0, y1)
+  const int x0 = (tx0 << g.shift) - g.radius, x1 = (min(tx0 + 16, g.w) << g.shift) + g.radius;
+  unsigned any = (y0 < 0 || x0 < 0 || y1 > H || x1 > W) ? 1u : 0u;  // zero padding inside the cone
+  if (!any) {
+    const uint8_t* gi = grid + (size_t)img * bh * bw;
+    for (int by = y0 >> 3; by <= (y1 - 1) >> 3 && !any; ++by)
+      for (int bx = x0 >> 3; bx <= (x1 - 1) >> 3; ++bx) any |= gi[by * bw + bx];
+  }
+  flags[g.offset + t] = any ? 1 : 0;
+}
+
+__global__ void skip_fill_kernel(half_t* __restrict__ dst, int n_pix, int C, const half_t* __restrict__ value) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pix * C) dst[i] = value[i % C];
+}
+__global__ void skip_copy_kernel(half_t* __restrict__ dst, const half_t* __restrict__ src, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
 // Context
 // ---------------------------------------------------------------------------
 struct UnetLayer {
@@ -411,6 +478,15 @@ struct pxt_unet {
   } sides[2];
   hipStream_t pass2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // constant-tile skipping: the output vectors of conv layers 1..6 for the constant input, per plan signature
+  struct SkipEntry {
+    int cfg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stamp = 0;  // 0: empty
+    pxt::half_t* values = nullptr;  // device [6][256]
+  } skip_cache[4];
+  unsigned long long skip_clock = 0;
+  bool tile_skip = true;         // pxt_unet_set_tile_skip
+  void* skip_scratch = nullptr;  // device: raw zero image 48 x 48 x 3 f32 | in map 48 x 48 x 256 f16 | out map | pooled map
   bool plan_as_single = false;  // pxt_unet_set_batch_plan
   bool defer_join = false;    // pxt_unet_set_defer_join: the pair entry leaves the second pass un-joined ...
   bool join_pending = false;  // ... until pxt_unet_pair_join (or the next forward call) makes the caller's stream wait for it
@@ -565,6 +641,8 @@ struct Plan {
   int dh[4], dw[4];        // decoder block output resolutions
   // byte offsets into the workspace
   size_t enc_tmp[5][2], enc_pool[5], enc_out[5], dec_out[4], splitk, splitk_bytes, total;
+  size_t skip_grid, skip_flags;  // constant-tile skipping: the 8 x 8 block grid, then the tile flags of layers 1..6
+  int skip_bh, skip_bw;
 };
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -602,6 +680,11 @@ bool make_plan(const pxt_unet* ctx, int n_img, int H, int W, Plan& P) {
     sk = std::max(sk, splitk_bytes(n_img, P.dh[d], P.dw[d], ctx->conv[13 + d].cin, ctx->conv[13 + d].cout, true));
   P.splitk = take(sk + 256);
   P.splitk_bytes = sk;
+  P.skip_bh = (H + 7) / 8;
+  P.skip_bw = (W + 7) / 8;
+  P.skip_grid = take((size_t)n_img * P.skip_bh * P.skip_bw);
+  // tiles of a layer: at most (h / 8 + 1) x (w / 16 + 1) (the smallest tile is 8 rows), six layers at strides 1, 2, 2, 4, 4, 4
+  P.skip_flags = take((size_t)n_img * 6 * ((size_t)(H / 8 + 2) * (W / 16 + 2)));
   P.total = off;
   return true;
 }
@@ -687,7 +770,8 @@ void launch_v2_cfg(int cfg, bool upcat, const ConvArgs& a, dim3 grid, hipStream_
 int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const half_t* in, int H, int W, half_t* out,
                 hipStream_t s, int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr,
                 half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0,
-                const FusedHead* head = nullptr, const FusedFirst* first = nullptr, size_t partial_cap = ~(size_t)0) {
+                const FusedHead* head = nullptr, const FusedFirst* first = nullptr, size_t partial_cap = ~(size_t)0,
+                const TileSkip* skip = nullptr, int skip_th = 0) {
   if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
@@ -738,6 +822,10 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
     a.first = *first;
     a.first.enabled = 1;
   }
+  // constant-tile skipping: only with the tile geometry the flags were made for, one K pass, no fused head
+  a.skip.flags = nullptr;
+  a.skip.value = nullptr;
+  if (skip && skip->flags && cp.splits == 1 && !head && !up && cfg_th(cp.cfg) == skip_th) a.skip = *skip;
   if (pooled) *pooled = a.pool != nullptr;
   const dim3 grid(cp.tiles, cp.nb, cp.splits);
   static const bool debug_plan = getenv("PXT_CONV_DEBUG") != nullptr;
@@ -750,6 +838,74 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, cp.splits,
                        n4, cout, bias, relu, out);
   }
+  return PXT_OK;
+}
+
+// ---- constant-tile skipping: the layers' output vectors for the constant input -------------------------------
+// For a plan signature (the tile configuration of conv layers 1..6) the chain c1 = conv1_2(conv1_1(0-pixel)), c2 =
+// conv2_1(c1), ... is computed ONCE on the device by running each layer's own kernel configuration on a 48 x 48
+// constant map and taking the centre pixel: the same K walk, the same bits as a constant tile of the real pass.
+constexpr int kSkipS = 48, kSkipLayers = 6, kSkipMaxC = 256;
+bool conv_plan_env_set() {
+  static const bool set = getenv("PXT_CONV_PLAN") != nullptr;
+  return set;
+}
+int ensure_skip_values(pxt_unet* ctx, const int cfg[kSkipLayers], hipStream_t s, const half_t** values) {
+  ++ctx->skip_clock;
+  pxt_unet::SkipEntry* victim = &ctx->skip_cache[0];
+  for (auto& e : ctx->skip_cache) {
+    if (e.stamp && std::memcmp(e.cfg, cfg, sizeof(e.cfg)) == 0) {
+      e.stamp = ctx->skip_clock;
+      *values = e.values;
+      return PXT_OK;
+    }
+    if (e.stamp < victim->stamp) victim = &e;
+  }
+  // A miss happens once per plan signature (the first pass of an image size; four signatures are kept).  The context's
+  // passes may be running on two streams (the pair pass), and the entry being replaced may still be read there: drain
+  // the device before the entry is rewritten and again before anyone uses it - a one-off bubble, no per-frame cost.
+  PXT_HIP_CHECK(hipDeviceSynchronize());
+  const size_t raw_b = (size_t)kSkipS * kSkipS * 3 * sizeof(float), map_b = (size_t)kSkipS * kSkipS * kSkipMaxC * sizeof(half_t);
+  if (!ctx->skip_scratch) {
+    PXT_HIP_CHECK(hipMalloc(&ctx->skip_scratch, raw_b + 2 * map_b));
+    PXT_HIP_CHECK(hipMemset(ctx->skip_scratch, 0, raw_b + 2 * map_b));
+  }
+  if (!victim->values) PXT_HIP_CHECK(hipMalloc((void**)&victim->values, (size_t)kSkipLayers * kSkipMaxC * sizeof(half_t)));
+  char* sc = (char*)ctx->skip_scratch;
+  half_t* in_map = (half_t*)(sc + raw_b);
+  half_t* out_map = (half_t*)(sc + raw_b + map_b);
+  for (int k = 0; k < kSkipLayers; ++k) {
+    const int li = k + 1;
+    const int cin = ctx->conv[li].cin, cout = ctx->conv[li].cout;
+    if (cout > kSkipMaxC || cin > kSkipMaxC || !cfg_valid(cfg[k]) || cout % cfg_bnc(cfg[k]) != 0) return PXT_E_ARG;
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.H = kSkipS; a.W = kSkipS; a.Cin = cin; a.Cout = cout; a.relu = 1;
+    a.wpk = cfg_v3(cfg[k]) ? ctx->conv_packed[li] + (size_t)cout * 9 * cin : ctx->conv_packed[li];
+    a.bias = ctx->conv[li].b;
+    a.out = out_map;
+    if (li == 1) {  // the first layer computed inside the second one's staging, from a raw zero image
+      a.first.image[0] = sc;
+      a.first.w = (const float*)ctx->conv[0].w;
+      a.first.b = ctx->conv[0].b;
+      a.first.enabled = 1;
+    } else {
+      const int n = kSkipS * kSkipS * cin;
+      hipLaunchKernelGGL(skip_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in_map, kSkipS * kSkipS, cin,
+                         (const half_t*)(victim->values + (size_t)(k - 1) * kSkipMaxC));
+      a.in = in_map;
+    }
+    const int th = cfg_th(cfg[k]);
+    const dim3 grid(((kSkipS + th - 1) / th) * (kSkipS / 16), cout / cfg_bnc(cfg[k]), 1);
+    launch_v2_cfg(cfg[k], false, a, grid, s);
+    hipLaunchKernelGGL(skip_copy_kernel, dim3((cout + 255) / 256), dim3(256), 0, s, victim->values + (size_t)k * kSkipMaxC,
+                       (const half_t*)(out_map + ((size_t)(kSkipS / 2) * kSkipS + kSkipS / 2) * cout), cout);
+  }
+  PXT_HIP_CHECK(hipGetLastError());
+  PXT_HIP_CHECK(hipStreamSynchronize(s));
+  std::memcpy(victim->cfg, cfg, sizeof(victim->cfg));
+  victim->stamp = ctx->skip_clock;
+  *values = victim->values;
   return PXT_OK;
 }
 
@@ -883,6 +1039,9 @@ extern "C" int pxt_unet_destroy(pxt_unet* ctx) {
   if (ctx->dev_head) (void)hipFree(ctx->dev_head);
   if (ctx->dev_packed) (void)hipFree(ctx->dev_packed);
   if (ctx->dev_head0) (void)hipFree(ctx->dev_head0);
+  if (ctx->skip_scratch) (void)hipFree(ctx->skip_scratch);
+  for (auto& e : ctx->skip_cache)
+    if (e.values) (void)hipFree(e.values);
   for (auto& ss : ctx->sides) {
     if (ss.ev_enc4) (void)hipEventDestroy(ss.ev_enc4);
     if (ss.ev_dec1) (void)hipEventDestroy(ss.ev_dec1);
@@ -974,6 +1133,63 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
     return j;
   };
 
+  // ---- constant-tile skipping in encoder blocks 1-3 (conv layers 1..6): PXT_UNET_SKIP=0 computes every tile -------
+  // Exact: a skipped tile receives the very bits it would have computed (TileSkip, pxt_conv_v2.h), so the maps do not
+  // change (tests/test_unet_gpu.py compares skip on / off bit for bit).  Worth it because the tracker's images are mostly
+  // constant: the masked query is 0 outside the dilated silhouette, the reference render 0 outside the object (15 % /
+  // 12 % of the benchmark's 640 x 480 frame is not: 71-75 % of the first block's tiles, 66 % of the second's and 30-40 %
+  // of the third's are skipped).
+  TileSkip tile_skip[kSkipLayers];
+  int tile_skip_th[kSkipLayers];
+  for (int k = 0; k < kSkipLayers; ++k) { tile_skip[k].flags = nullptr; tile_skip[k].value = nullptr; tile_skip_th[k] = 0; }
+  {
+    static const bool skip_env = [] { const char* e = getenv("PXT_UNET_SKIP"); return e ? atoi(e) != 0 : true; }();
+    static const bool fuse_first_env0 = [] { const char* e = getenv("PXT_UNET_FUSE_FIRST"); return e ? atoi(e) != 0 : true; }();
+    bool any_source = false;
+    for (int i = 0; i < B; ++i) any_source = any_source || (masks && masks[i]) || image_is_u8[i];
+    const bool can = skip_env && ctx->tile_skip && !conv_plan_env_set() && fuse_first_env0 && any_source && H >= 64 && W >= 64 &&
+                     ctx->conv[0].cout == 64 && ctx->conv[1].cin == 64 && ctx->conv[1].cout == 64;
+    if (can) {
+      static const int blk_of6[kSkipLayers] = {0, 1, 1, 2, 2, 2}, radius6[kSkipLayers] = {2, 4, 6, 10, 14, 18};
+      static const bool last6[kSkipLayers] = {true, false, true, false, false, true};  // the block's last conv (fused pool)
+      int cfgs[kSkipLayers];
+      SkipGeo geo;
+      geo.n_layers = kSkipLayers;
+      int off = 0, max_tiles = 0;
+      bool ok = true;
+      for (int k = 0; k < kSkipLayers; ++k) {
+        const int li = k + 1, b = blk_of6[k];
+        // the plan launch_conv will take for this layer (same arguments: the fused first layer forces configuration 2)
+        const ConvPlan cp = plan_conv(B, P.h[b], P.w[b], ctx->conv[li].cin, ctx->conv[li].cout, li != 1, li == 1 ? 2 : 0, 0, false,
+                                      last6[k]);
+        cfgs[k] = cp.cfg;
+        ok = ok && cfg_valid(cp.cfg) && ctx->conv[li].cout <= kSkipMaxC && ctx->conv[li].cin <= kSkipMaxC;
+        SkipLayerGeo& g = geo.l[k];
+        g.th = cfg_th(cp.cfg); g.shift = b; g.radius = radius6[k]; g.h = P.h[b]; g.w = P.w[b]; g.offset = off;
+        const int tiles = B * ((P.h[b] + g.th - 1) / g.th) * ((P.w[b] + 15) / 16);
+        tile_skip_th[k] = cp.splits == 1 ? g.th : 0;  // (a split-K layer computes every tile)
+        off += tiles;
+        max_tiles = std::max(max_tiles, tiles);
+      }
+      const half_t* values = nullptr;
+      if (ok && (size_t)off <= (size_t)B * 6 * ((size_t)(H / 8 + 2) * (W / 16 + 2)) &&
+          ensure_skip_values(ctx, cfgs, s, &values) == PXT_OK) {
+        SkipImages si;
+        for (int i = 0; i < B; ++i) { si.image[i] = images[i]; si.mask[i] = masks ? masks[i] : nullptr; si.is_u8[i] = image_is_u8[i]; }
+        uint8_t* grid_b = (uint8_t*)(ws + P.skip_grid);
+        uint8_t* flags_b = (uint8_t*)(ws + P.skip_flags);
+        const int nb = P.skip_bh * P.skip_bw;
+        hipLaunchKernelGGL(skip_block_or_kernel, dim3((nb + 127) / 128, B), dim3(128), 0, s, si, H, W, P.skip_bh, P.skip_bw, grid_b);
+        hipLaunchKernelGGL(skip_tile_flags_kernel, dim3((max_tiles + 127) / 128, kSkipLayers), dim3(128), 0, s, geo,
+                           (const uint8_t*)grid_b, H, W, P.skip_bh, P.skip_bw, B, flags_b);
+        for (int k = 0; k < kSkipLayers; ++k) {
+          tile_skip[k].flags = flags_b + geo.l[k].offset;
+          tile_skip[k].value = values + (size_t)k * kSkipMaxC;
+        }
+      }
+    }
+  }
+
   const half_t* skip[5];
   const half_t* cur = nullptr;
   bool pooled_by_conv = false;
@@ -1027,10 +1243,11 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       half_t* pool_to = (last && b < 4) ? buf(P.enc_pool[b + 1]) : nullptr;
       g_conv_layer = li;
       const bool with_first = li == 1 && fuse_first;
+      const bool can_skip = li >= 1 && li <= kSkipLayers && (li != 1 || with_first);
       int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
                            1, with_first ? nullptr : (float*)(ws + P.splitk), B, nullptr, pool_to,
                            pool_to ? &pooled_by_conv : nullptr, with_first ? 2 : 0, 0, nullptr, with_first ? &ff : nullptr,
-                           P.splitk_bytes);
+                           P.splitk_bytes, can_skip ? &tile_skip[li - 1] : nullptr, can_skip ? tile_skip_th[li - 1] : 0);
       if (rc != PXT_OK) return rc;
       x = o;
     }
@@ -1164,6 +1381,12 @@ extern "C" int pxt_unet_forward_pair(pxt_unet* ctx, const void* const* images, c
     return PXT_OK;
   }
   PXT_HIP_CHECK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  return PXT_OK;
+}
+
+extern "C" int pxt_unet_set_tile_skip(pxt_unet* ctx, int32_t on) {
+  if (!ctx) return PXT_E_ARG;
+  ctx->tile_skip = on != 0;
   return PXT_OK;
 }
 

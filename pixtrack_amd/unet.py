@@ -377,6 +377,12 @@ class UNet:
         those of the one-object tracker)."""
         _lib.check(_lib.lib().pxt_unet_set_batch_plan(self._ctx, int(bool(per_image_plan))), "pxt_unet_set_batch_plan")
 
+    def set_tile_skip(self, on: bool) -> None:
+        """Constant-tile skipping in encoder blocks 1-3 (pxt_unet_set_tile_skip; on by default): tiles whose dependency
+        cone lies where the input is constant (masked-out query, background of the reference render) are filled with
+        the layer's constant output instead of being computed - the same bits."""
+        _lib.check(_lib.lib().pxt_unet_set_tile_skip(self._ctx, int(bool(on))), "pxt_unet_set_tile_skip")
+
     def set_defer_join(self, on: bool) -> None:
         """With True, a two-image call returns with the FIRST image's maps complete in the current stream's order and
         the second image's pass still running on the library's side stream: the caller may enqueue work on the first

@@ -316,3 +316,60 @@ def test_deferred_join_of_the_pair_pass(device):
     torch.cuda.synchronize()
     for x, y in zip(list(ref_maps) + list(q_maps), want[0] + want[1]):
         assert torch.equal(x, y)
+
+
+def _tracker_like_images(H, W, seed, device):
+    """A 'reference render' (uint8, exactly 0 outside a blob) and a 'masked query' (float noise + a dilated silhouette
+    mask), as the tracker hands them to the extractor (pixloc_tracker_r9.py:224-227)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    cy, cx, ry, rx = 0.52 * H, 0.47 * W, 0.17 * H, 0.2 * W
+    blob = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1.0
+    ref = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8) * blob[..., None].to(torch.uint8)
+    mask = (((yy - cy) / (ry + 12)) ** 2 + ((xx - cx) / (rx + 12)) ** 2) < 1.0
+    query = torch.rand(H, W, 3, generator=g) * 255
+    return ref.to(device).contiguous(), query.to(device).contiguous(), mask.to(torch.uint8).to(device).contiguous()
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (240, 320), (333, 421)])
+def test_constant_tile_skipping_leaves_every_map_bit_identical(device, H, W):
+    """Encoder blocks 1-3 skip tiles whose dependency cone lies where the input is constant (pxt_unet_set_tile_skip):
+    single passes, the frame's two-stream pair pass and a batched pass, skip on against skip off - torch.equal."""
+    net = UNet(make_synthetic_unet_weights(7), device)
+    ref, query, mask = _tracker_like_images(H, W, 3, device)
+    calls = {
+        "single u8": lambda: [net.forward_packed(ref, None, False)],
+        "single masked": lambda: [net.forward_packed(query, mask, True)],
+        "pair": lambda: net.forward_packed_batch([(ref, None, False), (query, mask, True)]),
+        "batch of 4": lambda: net.forward_packed_batch([(ref, None, False), (query, mask, True), (query, None, True),
+                                                       (ref, None, True)]),
+    }
+    for name, call in calls.items():
+        net.set_tile_skip(True)
+        on = [[m.clone() for m in maps] for maps in call()]
+        net.set_tile_skip(False)
+        off = call()
+        torch.cuda.synchronize()
+        for a, b in zip(on, off):
+            for l, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), (name, l, float((x - y).abs().max()))
+    net.set_tile_skip(True)
+
+
+def test_constant_tile_skipping_two_sizes_and_a_fully_masked_image(device):
+    """The pair entry with two image sizes (real assets), and the degenerate inputs: a mask that is 0 everywhere (every
+    interior tile constant) and one that is 1 everywhere (nothing to skip)."""
+    net = UNet(make_synthetic_unet_weights(7), device)
+    ref, _q, _m = _tracker_like_images(496, 512, 5, device)
+    _r, query, mask = _tracker_like_images(480, 640, 6, device)
+    cases = [[(ref, None, False), (query, mask, True)],
+             [(query, torch.zeros_like(mask), True), (query, torch.ones_like(mask), True)]]
+    for items in cases:
+        net.set_tile_skip(True)
+        on = [[m.clone() for m in maps] for maps in net.forward_packed_batch(items)]
+        net.set_tile_skip(False)
+        off = net.forward_packed_batch(items)
+        for a, b in zip(on, off):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    net.set_tile_skip(True)
