@@ -483,7 +483,7 @@ struct pxt_unet {
     int cfg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long stamp = 0;  // 0: empty
     pxt::half_t* values = nullptr;  // device [6][256]
-  } skip_cache[4];
+  } skip_cache[8];
   unsigned long long skip_clock = 0;
   bool tile_skip = true;         // pxt_unet_set_tile_skip
   void* skip_scratch = nullptr;  // device: raw zero image 48 x 48 x 3 f32 | in map 48 x 48 x 256 f16 | out map | pooled map
@@ -861,7 +861,7 @@ int ensure_skip_values(pxt_unet* ctx, const int cfg[kSkipLayers], hipStream_t s,
     }
     if (e.stamp < victim->stamp) victim = &e;
   }
-  // A miss happens once per plan signature (the first pass of an image size; four signatures are kept).  The context's
+  // A miss happens once per plan signature (the first pass with a new set of tile configurations; eight signatures are kept).  The context's
   // passes may be running on two streams (the pair pass), and the entry being replaced may still be read there: drain
   // the device before the entry is rewritten and again before anyone uses it - a one-off bubble, no per-frame cost.
   PXT_HIP_CHECK(hipDeviceSynchronize());
