@@ -396,20 +396,35 @@ struct SkipImages {
   const uint8_t* mask[PXT_UNET_MAX_BATCH];
   int is_u8[PXT_UNET_MAX_BATCH];
 };
+// one thread per (block, row): 8 consecutive lanes hold a block's 8 rows and OR their results with three shuffles
 __global__ void skip_block_or_kernel(const SkipImages im, int H, int W, int bh, int bw, uint8_t* __restrict__ grid) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y;
-  if (b >= bh * bw) return;
-  const int by = b / bw, bx = b % bw;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, img = blockIdx.y;
+  const int b = t >> 3, r = t & 7;
+  const bool live = b < bh * bw;
+  const int by = live ? b / bw : 0, bx = live ? b % bw : 0;
   const uint8_t* mask = im.mask[img];
   const uint8_t* u8 = im.is_u8[img] ? (const uint8_t*)im.image[img] : nullptr;
   unsigned any = (mask == nullptr && u8 == nullptr) ? 1u : 0u;
-  if (!any)
-    for (int y = 8 * by; y < min(8 * by + 8, H); ++y)
-      for (int x = 8 * bx; x < min(8 * bx + 8, W); ++x) {
-        if (mask) any |= mask[(size_t)y * W + x];  // (a set mask bit counts whatever the pixel holds)
-        else any |= u8[((size_t)y * W + x) * 3] | u8[((size_t)y * W + x) * 3 + 1] | u8[((size_t)y * W + x) * 3 + 2];
+  const int y = 8 * by + r, x0 = 8 * bx, n = min(8, W - x0);
+  if (live && !any && y < H) {
+    if (mask) {  // (a set mask bit counts whatever the pixel holds)
+      const uint8_t* p = mask + (size_t)y * W + x0;
+      if (n == 8 && (((uintptr_t)p) & 7) == 0) any = *(const unsigned long long*)p != 0ull;
+      else for (int x = 0; x < n; ++x) any |= p[x];
+    } else {
+      const uint8_t* p = u8 + ((size_t)y * W + x0) * 3;
+      if (n == 8 && (((uintptr_t)p) & 7) == 0) {
+        const unsigned long long* q = (const unsigned long long*)p;
+        any = (q[0] | q[1] | q[2]) != 0ull;
+      } else {
+        for (int x = 0; x < 3 * n; ++x) any |= p[x];
       }
-  grid[(size_t)img * bh * bw + b] = any ? 1 : 0;
+    }
+  }
+  any |= __shfl_xor(any, 1, 64);
+  any |= __shfl_xor(any, 2, 64);
+  any |= __shfl_xor(any, 4, 64);
+  if (live && r == 0) grid[(size_t)img * bh * bw + b] = any ? 1 : 0;
 }
 
 struct SkipLayerGeo {
@@ -419,12 +434,13 @@ struct SkipGeo {
   SkipLayerGeo l[6];
   int n_layers;
 };
+// one wave per (layer, image, tile): the lanes share the block cells of the tile's cone
 __global__ void skip_tile_flags_kernel(const SkipGeo geo, const uint8_t* __restrict__ grid, int H, int W, int bh, int bw,
                                        int n_img, uint8_t* __restrict__ flags) {
   const SkipLayerGeo g = geo.l[blockIdx.y];
   const int tiles_x = (g.w + 15) >> 4, tiles_y = (g.h + g.th - 1) / g.th;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_img * tiles_x * tiles_y) return;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (t >= n_img * tiles_x * tiles_y) return;  // (wave-uniform)
   const int img = t / (tiles_x * tiles_y), tile = t % (tiles_x * tiles_y);
   const int ty0 = (tile / tiles_x) * g.th, tx0 = (tile % tiles_x) * 16;
   // the tile's pixels at full resolution, grown by R
@@ -433,10 +449,11 @@ __global__ void skip_tile_flags_kernel(const SkipGeo geo, const uint8_t* __restr
   unsigned any = (y0 < 0 || x0 < 0 || y1 > H || x1 > W) ? 1u : 0u;  // zero padding inside the cone
   if (!any) {
     const uint8_t* gi = grid + (size_t)img * bh * bw;
-    for (int by = y0 >> 3; by <= (y1 - 1) >> 3 && !any; ++by)
-      for (int bx = x0 >> 3; bx <= (x1 - 1) >> 3; ++bx) any |= gi[by * bw + bx];
+    const int by0 = y0 >> 3, bx0 = x0 >> 3, nby = ((y1 - 1) >> 3) - by0 + 1, nbx = ((x1 - 1) >> 3) - bx0 + 1;
+    for (int c = lane; c < nby * nbx; c += 64) any |= gi[(by0 + c / nbx) * bw + bx0 + c % nbx];
   }
-  flags[g.offset + t] = any ? 1 : 0;
+  any = __ballot(any != 0) != 0ull;
+  if (lane == 0) flags[g.offset + t] = any ? 1 : 0;
 }
 
 __global__ void skip_fill_kernel(half_t* __restrict__ dst, int n_pix, int C, const half_t* __restrict__ value) {
@@ -1179,8 +1196,8 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
         uint8_t* grid_b = (uint8_t*)(ws + P.skip_grid);
         uint8_t* flags_b = (uint8_t*)(ws + P.skip_flags);
         const int nb = P.skip_bh * P.skip_bw;
-        hipLaunchKernelGGL(skip_block_or_kernel, dim3((nb + 127) / 128, B), dim3(128), 0, s, si, H, W, P.skip_bh, P.skip_bw, grid_b);
-        hipLaunchKernelGGL(skip_tile_flags_kernel, dim3((max_tiles + 127) / 128, kSkipLayers), dim3(128), 0, s, geo,
+        hipLaunchKernelGGL(skip_block_or_kernel, dim3((8 * nb + 255) / 256, B), dim3(256), 0, s, si, H, W, P.skip_bh, P.skip_bw, grid_b);
+        hipLaunchKernelGGL(skip_tile_flags_kernel, dim3((max_tiles + 3) / 4, kSkipLayers), dim3(256), 0, s, geo,
                            (const uint8_t*)grid_b, H, W, P.skip_bh, P.skip_bw, B, flags_b);
         for (int k = 0; k < kSkipLayers; ++k) {
           tile_skip[k].flags = flags_b + geo.l[k].offset;
