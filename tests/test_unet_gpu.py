@@ -373,3 +373,33 @@ def test_constant_tile_skipping_two_sizes_and_a_fully_masked_image(device):
             for x, y in zip(a, b):
                 assert torch.equal(x, y)
     net.set_tile_skip(True)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_constant_tile_skipping_isolated_pixels_probe_the_cone_radii(device, seed):
+    """Adversarial activity: a handful of isolated non-zero pixels / tiny mask rectangles at random places (next to tile
+    corners as often as not).  A dependency radius one pixel short anywhere in the six layers would skip a tile a lit
+    pixel reaches, and the maps would differ."""
+    H, W = 368, 496
+    g = torch.Generator().manual_seed(100 + seed)
+    net = UNet(make_synthetic_unet_weights(7), device)
+    ref = torch.zeros(H, W, 3, dtype=torch.uint8)
+    for _ in range(10):
+        y, x = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+        ref[y, x, int(torch.randint(0, 3, (1,), generator=g))] = int(torch.randint(1, 256, (1,), generator=g))
+    mask = torch.zeros(H, W, dtype=torch.uint8)
+    for _ in range(6):
+        y, x = int(torch.randint(0, H - 3, (1,), generator=g)), int(torch.randint(0, W - 3, (1,), generator=g))
+        mask[y:y + int(torch.randint(1, 4, (1,), generator=g)), x:x + int(torch.randint(1, 4, (1,), generator=g))] = 1
+    query = torch.rand(H, W, 3, generator=g) * 255
+    items = [(ref.to(device), None, False), (query.to(device), mask.to(device), True)]
+    net.set_tile_skip(True)
+    on = [[m.clone() for m in maps] for maps in net.forward_packed_batch(items)]
+    single_on = [m.clone() for m in net.forward_packed(items[0][0], None, False)]
+    net.set_tile_skip(False)
+    off = net.forward_packed_batch(items)
+    single_off = net.forward_packed(items[0][0], None, False)
+    for a, b in zip(on + [single_on], off + [single_off]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), float((x - y).abs().max())
+    net.set_tile_skip(True)
