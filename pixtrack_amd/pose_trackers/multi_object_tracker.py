@@ -89,10 +89,10 @@ class MultiObjectTracker:
         self.groups = []
         for g in range(n_groups):
             members = list(range(g, len(self.trackers), n_groups))
-            stream = None if n_groups == 1 else torch.cuda.Stream(self.device)
+            stream = None if n_groups == 1 else _group_stream(self.device, g)
             self.groups.append(_Group(g, members, stream, self.trackers[members[0]].localizer.extractor.model))
             if n_groups > 1 and self.render_streams > 1:
-                self.groups[-1].render_streams = [torch.cuda.Stream(self.device) for _ in range(self.render_streams)]
+                self.groups[-1].render_streams = [_group_stream(self.device, 100 + 10 * g + j) for j in range(self.render_streams)]
         self.model = self.groups[0].model
         self._last_unet_done = None
         # With several groups the concurrency a render needs comes from the OTHER group's UNet pass: one pipeline per
@@ -289,6 +289,18 @@ class MultiObjectTracker:
             self.run_single_frames(frames)
             n += 1
         return n
+
+
+_GROUP_STREAMS = {}
+
+
+def _group_stream(device, g: int) -> "torch.cuda.Stream":
+    """Group g's stream on ``device``: made once per process (HIP deals streams to its hardware queues in creation order:
+    fresh streams per tracker would make the groups' overlap depend on how many trackers the process has seen)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), g)
+    if key not in _GROUP_STREAMS:
+        _GROUP_STREAMS[key] = torch.cuda.Stream(device)
+    return _GROUP_STREAMS[key]
 
 
 def _device_cus() -> int:

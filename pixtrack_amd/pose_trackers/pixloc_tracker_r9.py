@@ -41,6 +41,9 @@ from ..visualization.run_vis_on_poses import get_nerf_image_device, rgba_to_u8
 from .base_pose_tracker import PoseTracker
 
 
+_AHEAD_STREAMS = {}  # device index -> the process's second render stream (see PixLocPoseTrackerR9._two_streams)
+
+
 def infer_camera_from_image(width: int, height: int) -> ColmapCamera:
     """pycolmap.infer_camera_from_image without EXIF: SIMPLE_RADIAL, f = 1.2 max(w, h),
     principal point at the image centre, k = 0."""
@@ -377,7 +380,13 @@ class PixLocPoseTrackerR9(PoseTracker):
     def _two_streams(self):
         """(current stream, the stream the second of a frame's two renders runs on) + the fork / join events."""
         if self.__dict__.get("_ahead_stream") is None:
-            self._ahead_stream = torch.cuda.Stream(self.device)
+            # ONE such stream per device and process, shared by every tracker: HIP deals streams to its four hardware
+            # queues in creation order, so a stream made by the fourth tracker of a process may share a queue with the
+            # stream it is meant to run beside (bench.py: value_r9_phone 457 inside the full run, 530-550 on its own)
+            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if key not in _AHEAD_STREAMS:
+                _AHEAD_STREAMS[key] = torch.cuda.Stream(self.device)
+            self._ahead_stream = _AHEAD_STREAMS[key]
             self._ahead_fork, self._ahead_join = torch.cuda.Event(), torch.cuda.Event()
         return torch.cuda.current_stream(self.device), self._ahead_stream
 
