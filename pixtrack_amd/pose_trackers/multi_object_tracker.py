@@ -61,6 +61,10 @@ class MultiObjectTracker:
         for tr in self.trackers:
             if tr.device != self.device:
                 raise _lib.PxtError("lock-step trackers share one device")
+            # the step below is PixLocPoseTrackerR9.refine() in pieces: a tracker with its own refine() (the YCB policy:
+            # ground-truth-gated updates, pixloc_tracker_ycb.py:241-295) would silently run r9's policy here
+            if type(tr).refine is not PixLocPoseTrackerR9.refine or type(tr)._frame_policy is not PixLocPoseTrackerR9._frame_policy:
+                raise _lib.PxtError(f"{type(tr).__name__} overrides refine(): lock-step tracking implements PixLocPoseTrackerR9's policy only")
         # one UNet context runs every image of a group's step: the trackers must hold the same checkpoint
         # (pixloc_megadepth is one network for all objects; reference pixloc_pose_refiners.py:49-60)
         sig = getattr(self.trackers[0].localizer.extractor.model, "weights_signature", None)
