@@ -788,7 +788,7 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
                 hipStream_t s, int relu = 1, float* partial = nullptr, int n_img = 1, const UpSrc* up = nullptr,
                 half_t* pool_out = nullptr, bool* pooled = nullptr, int force_cfg = 0, int force_splits = 0,
                 const FusedHead* head = nullptr, const FusedFirst* first = nullptr, size_t partial_cap = ~(size_t)0,
-                const TileSkip* skip = nullptr, int skip_th = 0) {
+                const TileSkip* skip = nullptr, int skip_cfg = 0) {
   if (cin % 32 != 0 || cout % 32 != 0) return PXT_E_ARG;
   if (up && (up->Cp % 32 != 0 || up->Cp >= cin || H != 2 * up->Hp || W != 2 * up->Wp || up->Hs < H || up->Ws < W))
     return PXT_E_ARG;
@@ -839,10 +839,11 @@ int launch_conv(int cin, int cout, const half_t* wpk, const float* bias, const h
     a.first = *first;
     a.first.enabled = 1;
   }
-  // constant-tile skipping: only with the tile geometry the flags were made for, one K pass, no fused head
+  // constant-tile skipping: only with the very tile configuration the flags (tile geometry) and the constant vector (K
+  // walk) were made for, one K pass, no fused head
   a.skip.flags = nullptr;
   a.skip.value = nullptr;
-  if (skip && skip->flags && cp.splits == 1 && !head && !up && cfg_th(cp.cfg) == skip_th) a.skip = *skip;
+  if (skip && skip->flags && cp.splits == 1 && !head && !up && cp.cfg == skip_cfg) a.skip = *skip;
   if (pooled) *pooled = a.pool != nullptr;
   const dim3 grid(cp.tiles, cp.nb, cp.splits);
   static const bool debug_plan = getenv("PXT_CONV_DEBUG") != nullptr;
@@ -1157,8 +1158,8 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
   // 12 % of the benchmark's 640 x 480 frame is not: 71-75 % of the first block's tiles, 66 % of the second's and 30-40 %
   // of the third's are skipped).
   TileSkip tile_skip[kSkipLayers];
-  int tile_skip_th[kSkipLayers];
-  for (int k = 0; k < kSkipLayers; ++k) { tile_skip[k].flags = nullptr; tile_skip[k].value = nullptr; tile_skip_th[k] = 0; }
+  int tile_skip_cfg[kSkipLayers];
+  for (int k = 0; k < kSkipLayers; ++k) { tile_skip[k].flags = nullptr; tile_skip[k].value = nullptr; tile_skip_cfg[k] = 0; }
   {
     static const bool skip_env = [] { const char* e = getenv("PXT_UNET_SKIP"); return e ? atoi(e) != 0 : true; }();
     static const bool fuse_first_env0 = [] { const char* e = getenv("PXT_UNET_FUSE_FIRST"); return e ? atoi(e) != 0 : true; }();
@@ -1184,7 +1185,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
         SkipLayerGeo& g = geo.l[k];
         g.th = cfg_th(cp.cfg); g.shift = b; g.radius = radius6[k]; g.h = P.h[b]; g.w = P.w[b]; g.offset = off;
         const int tiles = B * ((P.h[b] + g.th - 1) / g.th) * ((P.w[b] + 15) / 16);
-        tile_skip_th[k] = cp.splits == 1 ? g.th : 0;  // (a split-K layer computes every tile)
+        tile_skip_cfg[k] = cp.splits == 1 ? cp.cfg : 0;  // (a split-K layer computes every tile)
         off += tiles;
         max_tiles = std::max(max_tiles, tiles);
       }
@@ -1264,7 +1265,7 @@ static int forward_pass(pxt_unet* ctx, int32_t n_images, const void* const* imag
       int rc = launch_conv(ctx->conv[li].cin, ctx->conv[li].cout, ctx->conv_packed[li], ctx->conv[li].b, x, h, w, o, s,
                            1, with_first ? nullptr : (float*)(ws + P.splitk), B, nullptr, pool_to,
                            pool_to ? &pooled_by_conv : nullptr, with_first ? 2 : 0, 0, nullptr, with_first ? &ff : nullptr,
-                           P.splitk_bytes, can_skip ? &tile_skip[li - 1] : nullptr, can_skip ? tile_skip_th[li - 1] : 0);
+                           P.splitk_bytes, can_skip ? &tile_skip[li - 1] : nullptr, can_skip ? tile_skip_cfg[li - 1] : 0);
       if (rc != PXT_OK) return rc;
       x = o;
     }

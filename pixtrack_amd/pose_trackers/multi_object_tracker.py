@@ -313,3 +313,85 @@ def _device_cus() -> int:
     n = C.c_int(0)
     _lib.check(_lib.lib().pxt_device_cus(C.byref(n)), "pxt_device_cus")
     return int(n.value)
+
+
+def parse_config_sh(path) -> dict:
+    """The two settings a reference `config/<object>.sh` exports for the tracker: OBJ_AABB and UPRIGHT_REF_IMG
+    (e.g. /root/reference/config/premier_protein.sh:14; read as text, the file is not executed)."""
+    import re
+
+    out = {}
+    for line in open(path):
+        m = re.match(r"\s*(?:export\s+)?(OBJ_AABB|UPRIGHT_REF_IMG)\s*=\s*(.*?)\s*$", line)
+        if m:
+            out[m.group(1)] = m.group(2).strip().strip("'\"")
+    return out
+
+
+def main(argv=None):
+    """Several objects, one GPU: the reference's tracker command line (pixloc_tracker_r9.py:288-318) once per object, in
+    lock-step.  Every list takes one entry per object; an object's OBJ_AABB / UPRIGHT_REF_IMG come from --config (a
+    reference config/<object>.sh) or from --obj_aabb / --upright_ref_img.  Outputs per object as r9's CLI writes them:
+    <out_dir>/poses.pkl, <out_dir>/trackers.pkl, and the `Cache hits / Done` lines per object."""
+    import argparse
+    import gc
+    import os
+    from pathlib import Path
+
+    import numpy as np
+
+    from .pixloc_tracker_r9 import _dump
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--object_path", type=Path, nargs="+", required=True)
+    ap.add_argument("--query", type=Path, nargs="+", required=True)
+    ap.add_argument("--out_dir", type=Path, nargs="+", required=True)
+    ap.add_argument("--config", type=Path, nargs="*", default=None, help="config/<object>.sh per object")
+    ap.add_argument("--obj_aabb", nargs="*", default=None)
+    ap.add_argument("--upright_ref_img", nargs="*", default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--debug", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=2)
+    ap.add_argument("--pixloc_pickles", action="store_true")
+    args = ap.parse_args(argv)
+    K = len(args.object_path)
+    if len(args.query) != K or len(args.out_dir) != K:
+        ap.error("--object_path, --query and --out_dir take one entry per object")
+    if torch.cuda.is_available():
+        from ..parallel import bind_to_device_numa
+
+        bind_to_device_numa(0)
+    trackers = []
+    for k in range(K):
+        conf = parse_config_sh(args.config[k]) if args.config else {}
+        if args.obj_aabb:
+            conf["OBJ_AABB"] = args.obj_aabb[k]
+        if args.upright_ref_img:
+            conf["UPRIGHT_REF_IMG"] = args.upright_ref_img[k]
+        if "OBJ_AABB" not in conf or "UPRIGHT_REF_IMG" not in conf:
+            ap.error(f"object {k}: OBJ_AABB and UPRIGHT_REF_IMG are needed (--config, or --obj_aabb / --upright_ref_img)")
+        os.environ.update(OBJ_AABB=conf["OBJ_AABB"], UPRIGHT_REF_IMG=conf["UPRIGHT_REF_IMG"])  # read in the constructor (:77, :85)
+        obj = args.object_path[k]
+        os.makedirs(args.out_dir[k], exist_ok=True)
+        trackers.append(PixLocPoseTrackerR9(object_path=str(obj), data_path=str(obj / "pixtrack/pixsfm/dataset"),
+                                            eval_path=str(args.out_dir[k]), loc_path=str(obj / "pixtrack/aug_nerf_sfm"),
+                                            debug=args.debug))
+    multi = MultiObjectTracker(trackers, n_groups=args.groups)
+    its = [tr.get_query_frame_iterator(q, args.frames if args.frames is not None else np.inf)
+           for tr, q in zip(trackers, args.query)]
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    try:
+        multi.run(its)
+    finally:
+        gc.enable()
+    for tr in trackers:
+        tr.save_poses(args.pixloc_pickles)
+        print("Cache hits: %d, misses: %d" % (tr.hits, tr.misses))
+        _dump(tr.pose_tracker_history, os.path.join(tr.eval_path, "trackers.pkl"), args.pixloc_pickles)
+    print("Done")
+
+
+if __name__ == "__main__":
+    main()

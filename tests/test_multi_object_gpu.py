@@ -167,3 +167,58 @@ def test_lm_batch_equals_single_launches(device):
                 # (bit patterns: the failed problem's mean cost is 0 / 0 = NaN in both)
                 assert torch.equal(res.log[l, :n].contiguous().view(torch.int32), one.log[l, :n].contiguous().view(torch.int32)), (k, l)
     assert singles[3].failed and not singles[0].failed
+
+
+def test_multi_object_cli_on_disk_assets(device, tmp_path, monkeypatch, capsys):
+    """Two objects written in the reference's on-disk layout, their OBJ_AABB / UPRIGHT_REF_IMG in reference-style
+    config/<object>.sh files: the lock-step command line writes per object what pixloc_tracker_r9's writes
+    (poses.pkl, trackers.pkl; reference :281-284,313-318), with the poses of two one-object command lines."""
+    import pickle
+
+    from pixtrack_amd.pose_trackers import multi_object_tracker as mcli
+    from pixtrack_amd.pose_trackers import pixloc_tracker_r9 as cli
+    from pixtrack_amd.synthetic import write_object_dir
+
+    init = cli.PixLocPoseTrackerR9.__init__
+
+    def small_spp(self, *a, **k):
+        init(self, *a, **k)
+        self.spp = 2
+
+    monkeypatch.setattr(cli.PixLocPoseTrackerR9, "__init__", small_spp)
+    monkeypatch.delenv("PIXTRACK_WEIGHTS", raising=False)
+    n, objs, queries, confs = 5, [], [], []
+    for j, k in enumerate((5, 2)):
+        assets = make_tracking_assets(seed=1300 + k, width=192, height=144, n_frames=n, aabb=OBJECTS[k]["aabb"], n_points=3000)
+        tr = PixLocPoseTrackerR9("", "", "", "/tmp", device=device, assets=assets)
+        frames = render_query_frames(assets, tr.testbed)
+        obj, query = tmp_path / f"obj{j}", tmp_path / f"query{j}"
+        write_object_dir(assets, obj, query, frames)
+        conf = tmp_path / f"object{j}.sh"
+        aabb = [list(map(float, assets["aabb"][0])), list(map(float, assets["aabb"][1]))]
+        conf.write_text(f"#!/bin/bash\\nexport OBJECT={OBJECTS[k]['name']}\\nexport OBJ_AABB=\\"{aabb}\\"\\n"
+                        f"export UPRIGHT_REF_IMG={assets['upright_ref_img']}\\n")
+        objs.append(obj); queries.append(query); confs.append(conf)
+    solo = []
+    for j in range(2):
+        c = mcli.parse_config_sh(confs[j])
+        monkeypatch.setenv("OBJ_AABB", c["OBJ_AABB"])
+        monkeypatch.setenv("UPRIGHT_REF_IMG", c["UPRIGHT_REF_IMG"])
+        out = tmp_path / f"solo{j}"
+        cli.main(["--object_path", str(objs[j]), "--query", str(queries[j]), "--out_dir", str(out), "--debug", "1"])
+        solo.append(pickle.load(open(out / "poses.pkl", "rb")))
+    capsys.readouterr()
+    outs = [tmp_path / "multi0", tmp_path / "multi1"]
+    mcli.main(["--object_path", *map(str, objs), "--query", *map(str, queries), "--out_dir", *map(str, outs), "--config",
+               *map(str, confs), "--debug", "1"])
+    text = capsys.readouterr().out
+    assert text.count("Cache hits: 0, misses: %d" % (n - 1)) == 2 and text.rstrip().endswith("Done")
+    for j in range(2):
+        poses = pickle.load(open(outs[j] / "poses.pkl", "rb"))
+        assert list(poses) == list(solo[j]) and len(poses) == n
+        assert (outs[j] / "trackers.pkl").is_file()
+        for key in poses:
+            a, b = poses[key], solo[j][key]
+            assert a["success"] == b["success"] and a.get("tracked") == b.get("tracked")
+            if a["success"]:
+                assert float((a["T_refined"].as12() - b["T_refined"].as12()).abs().max()) < 2e-3
