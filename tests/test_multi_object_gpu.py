@@ -196,8 +196,8 @@ def test_multi_object_cli_on_disk_assets(device, tmp_path, monkeypatch, capsys):
         write_object_dir(assets, obj, query, frames)
         conf = tmp_path / f"object{j}.sh"
         aabb = [list(map(float, assets["aabb"][0])), list(map(float, assets["aabb"][1]))]
-        conf.write_text(f"#!/bin/bash\\nexport OBJECT={OBJECTS[k]['name']}\\nexport OBJ_AABB=\\"{aabb}\\"\\n"
-                        f"export UPRIGHT_REF_IMG={assets['upright_ref_img']}\\n")
+        conf.write_text("#!/bin/bash\nexport OBJECT=%s\nexport OBJ_AABB=\"%s\"\nexport UPRIGHT_REF_IMG=%s\n"
+                        % (OBJECTS[k]["name"], aabb, assets["upright_ref_img"]))
         objs.append(obj); queries.append(query); confs.append(conf)
     solo = []
     for j in range(2):
