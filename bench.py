@@ -563,6 +563,27 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
             rot.append(float(np.arccos(np.clip((np.trace(Rr @ Rg.T) - 1) / 2, -1, 1))))
             tra.append(float(np.linalg.norm(tt - tg)))
     lm = tracker.localizer.refiner.last_lm
+    # untimed: where a frame of this workload goes (HIP events per stage, the last frames of this rank's last segment again)
+    stage_hd = None
+    if mine:
+        timer = StageTimer()
+        for attr in ("render_device", "render_both_device", "render_frame_device"):
+            timer.wrap(tracker.testbed, attr, "nerf_render")
+        timer.wrap(tracker.localizer.extractor.model, "forward_packed_batch", "unet")
+        timer.wrap(tracker.localizer.extractor.model, "forward_packed", "unet")
+        timer.wrap(tracker.localizer.refiner, "refine_pose_using_features", "lm")
+        timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")
+        tail = mine[-min(4, len(mine)):]
+        torch.cuda.synchronize()
+        timer.enabled = True
+        t1 = time.perf_counter()
+        for i in tail:
+            tracker.run_single_frame((names[i], frames[i]))
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t1) / len(tail) * 1e3
+        timer.enabled = False
+        stage_hd = {k: round(v[0] / len(tail), 4) for k, v in timer.totals_ms().items()}
+        stage_hd["wall_ms_per_frame"] = round(wall, 4)
     out = {
         "metric": "tracked frames/sec at 1920x1080 (configs[4] stress workload)", "value": round(n_total / elapsed, 3),
         "unit": "frames/s", "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
@@ -578,6 +599,7 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
         "tracked_ok": int(video[:, 12].sum()), "frames_total": n_total,
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot)), 6) if rot else None,
         "mean_trans_err_vs_gt": round(float(np.mean(tra)), 6) if tra else None,
+        "stage_ms_per_frame": stage_hd,
         "roofline": None, "cpu_baseline": {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                            "sample": "reported with the frames640 workload only"},
         **report,

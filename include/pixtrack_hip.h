@@ -422,6 +422,14 @@ int pxt_rgba_to_u8(const float* rgba, int32_t H, int32_t W, float alpha_thresh, 
 int pxt_resize_linear(const float* src, int32_t H, int32_t W, int32_t C, float* dst, int32_t Ho,
                       int32_t Wo, void* stream);
 
+/* Which pixels of an image that pxt_resize_linear produces can be non-zero (uint8 [Ho][Wo], 1 = may be non-zero): 0 only
+ * where every source pixel under the 2 x 2 bilinear taps, grown by one pixel, is inactive - `mask` 0 where the source was
+ * multiplied by a mask (a masked query, feature_extractor.py:41-45 resizes after masking), else a uint8 source that is 0
+ * in all three channels (a NeRF render's background).  Passed on as the `mask` of pxt_unet_forward (a multiplication by
+ * exactly 0 or 1 there), it gives the constant-tile skipping its source for images above the extractor's size limit. */
+int pxt_resize_activity(const uint8_t* mask, const uint8_t* image_u8, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                        uint8_t* active_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,7 @@ PROTOTYPES = {
     "pxt_depth_mask_plane": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "pxt_rgba_to_u8": (C.c_int, [_VP, _I32, _I32, C.c_float, _VP, _VP]),
     "pxt_resize_linear": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I32, _I32, _VP]),
+    "pxt_resize_activity": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP]),
 }
 
 

@@ -270,9 +270,38 @@ __global__ void resize_linear_kernel(const float* __restrict__ src, int H, int W
   }
 }
 
+// Which pixels of a resized image can be non-zero: dst pixel (y, x) of resize_linear_kernel reads the 2 x 2 source taps
+// around ((y + 0.5) H / Ho - 0.5, ...); it is exactly 0 when those taps are 0 (0 * w + 0 * w).  `active` = 1 unless every
+// source pixel in the taps' neighbourhood grown by one pixel (so that no rounding of the tap position matters) is
+// inactive; a source pixel is inactive where `mask` is 0 (the image was multiplied by it) or, without a mask, where the
+// uint8 image is 0 in all three channels.  Feeds the UNet's constant-tile skipping for images the extractor resizes.
+__global__ void resize_activity_kernel(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ u8, int H, int W, int Ho,
+                                       int Wo, uint8_t* __restrict__ active) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= Wo || y >= Ho) return;
+  const float sx = (float)W / (float)Wo, sy = (float)H / (float)Ho;
+  const int x0 = (int)floorf(((float)x + 0.5f) * sx - 0.5f), y0 = (int)floorf(((float)y + 0.5f) * sy - 0.5f);
+  unsigned any = 0;
+  for (int yy = max(y0 - 1, 0); yy <= min(y0 + 2, H - 1); ++yy)
+    for (int xx = max(x0 - 1, 0); xx <= min(x0 + 2, W - 1); ++xx) {
+      const size_t i = (size_t)yy * W + xx;
+      any |= mask ? mask[i] : (unsigned)(u8[3 * i] | u8[3 * i + 1] | u8[3 * i + 2]);
+    }
+  active[(size_t)y * Wo + x] = any ? 1 : 0;
+}
+
 }  // namespace pxt
 
 using namespace pxt;
+
+extern "C" int pxt_resize_activity(const uint8_t* mask, const uint8_t* image_u8, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                   uint8_t* active_out, void* stream) {
+  if ((!mask && !image_u8) || !active_out || H < 1 || W < 1 || Ho < 1 || Wo < 1) return PXT_E_ARG;
+  dim3 blk(64, 4), grd((Wo + 63) / 64, (Ho + 3) / 4);
+  hipLaunchKernelGGL(resize_activity_kernel, grd, blk, 0, (hipStream_t)stream, mask, image_u8, H, W, Ho, Wo, active_out);
+  PXT_HIP_CHECK(hipGetLastError());
+  return PXT_OK;
+}
 
 extern "C" int pxt_depth_mask(const float* depth_rgba, int32_t H, int32_t W, int32_t n_erode,
                               int32_t n_dilate, uint8_t* mask_out, uint8_t* tmp, void* stream) {

@@ -106,9 +106,19 @@ class PixTrackFeatureExtractor:
         H, W = int(img.shape[0]), int(img.shape[1])
         h_new, w_new, scale_resize = self.target_size(H, W, scale_image)
         if (h_new, w_new) != (H, W):
+            # where the resized image can be non-zero (the UNet's constant-tile skipping needs to know: a resized image is
+            # float and carries no mask any more): from the mask it is multiplied by, or from a uint8 render's zeros.
+            # Handed on as the UNet call's mask - a multiplication by exactly 0 or 1 there.
+            active = None
             if mask is not None:
-                img = img.float() * mask.to(self.device)[..., None].float()
-                mask = None
+                mask = mask.to(self.device, torch.uint8).contiguous()
+                active = torch.empty(h_new, w_new, dtype=torch.uint8, device=self.device)
+                ops.resize_activity(mask, None, H, W, active)
+                img = img.float() * mask[..., None].float()
+            elif img.dtype == torch.uint8:
+                active = torch.empty(h_new, w_new, dtype=torch.uint8, device=self.device)
+                ops.resize_activity(None, img, H, W, active)
+            mask = active
             src = img.float().contiguous()
             dst = torch.empty(h_new, w_new, 3, device=self.device, dtype=torch.float32)
             ops.resize_linear(src, dst)

@@ -67,6 +67,7 @@ SCHEMAS = {
     "depth_mask_plane": "(Tensor depth_nz, int n_erode, int n_dilate, Tensor(a!) mask) -> ()",
     "rgba_to_u8": "(Tensor rgba, float alpha_thresh, Tensor(a!) out) -> ()",
     "resize_linear": "(Tensor src, Tensor(a!) dst) -> ()",
+    "resize_activity": "(Tensor? mask, Tensor? image_u8, int H, int W, Tensor(a!) active) -> ()",
     "conv3x3_nhwc_f16": "(Tensor x, Tensor weight, Tensor bias, bool relu, Tensor(a!) out) -> ()",
 }
 for _name, _schema in SCHEMAS.items():
@@ -433,6 +434,17 @@ def _resize_linear(src, dst):
                "pxt_resize_linear")
 
 
+def _resize_activity(mask, image_u8, H, W, active):
+    if (mask is None) == (image_u8 is None):
+        raise _lib.PxtError("resize_activity: exactly one of mask / image_u8")
+    src = mask if mask is not None else image_u8
+    if src.dtype != torch.uint8 or not src.is_contiguous() or active.dtype != torch.uint8 or not active.is_contiguous():
+        raise _lib.PxtError("resize_activity: contiguous uint8 tensors")
+    Ho, Wo = int(active.shape[0]), int(active.shape[1])
+    _lib.check(_lib.lib().pxt_resize_activity(_lib.dptr(mask), _lib.dptr(image_u8), int(H), int(W), Ho, Wo, active.data_ptr(),
+                                              _stream(active)), "pxt_resize_activity")
+
+
 _IMPLS = {
     "lm_refine": _lm_refine,
     "lm_refine_batch": _lm_refine_batch,
@@ -447,6 +459,7 @@ _IMPLS = {
     "depth_mask_plane": _depth_mask_plane,
     "rgba_to_u8": _rgba_to_u8,
     "resize_linear": _resize_linear,
+    "resize_activity": _resize_activity,
 }
 for _name, _fn in _IMPLS.items():
     _DEF.impl(_name, _fn, "CUDA")  # CUDA dispatch key == HIP device on torch-ROCm; nothing for CPU

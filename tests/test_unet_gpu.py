@@ -403,3 +403,28 @@ def test_constant_tile_skipping_isolated_pixels_probe_the_cone_radii(device, see
         for x, y in zip(a, b):
             assert torch.equal(x, y), float((x - y).abs().max())
     net.set_tile_skip(True)
+
+
+def test_resized_images_keep_their_constant_regions_for_the_tile_skipping(device):
+    """Images above the extractor's limit are resized (feature_extractor.py:41-45) and lose mask and uint8 type; the
+    extractor hands the UNet a conservative 'may be non-zero' plane instead (pxt_resize_activity).  It must cover every
+    non-zero pixel of the resized image, leave most of a tracker-like frame inactive, and the maps must not depend on it."""
+    from pixtrack_amd.feature_extractor import PixTrackFeatureExtractor
+
+    net = UNet(make_synthetic_unet_weights(7), device)
+    ex = PixTrackFeatureExtractor(net, device)
+    ref, query, mask = _tracker_like_images(1080, 1920, 9, device)
+    for image, m in ((query, mask), (ref, None)):
+        img, act, _sr = ex._prepare(image, 1, m)
+        assert tuple(img.shape[:2]) == (576, 1024) and act is not None and act.dtype == torch.uint8
+        nonzero = (img != 0).any(-1)
+        assert not bool((nonzero & (act == 0)).any())        # every pixel that is not exactly 0 is marked active
+        assert 0.02 < float(act.float().mean()) < 0.5          # ... and most of the frame is not
+        net.set_tile_skip(True)
+        on = [x.clone() for x in net.forward_packed(img, act, True)]
+        net.set_tile_skip(False)
+        off = net.forward_packed(img, act, True)
+        plain = net.forward_packed(img, None, True)            # (the plane multiplies by exactly 0 or 1: same maps without it)
+        for a, b, c in zip(on, off, plain):
+            assert torch.equal(a, b) and torch.equal(a, c)
+    net.set_tile_skip(True)
