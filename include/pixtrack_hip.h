@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (9), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (10), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -380,6 +380,20 @@ typedef struct {
 int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* view_host, int32_t mode, int32_t camera_from_slot,
                          const pxt_ngp_outputs* out, uint64_t* stats, void* stream);
 float* pxt_ngp_camera_slot(pxt_ngp* ctx); /* device float[12], owned by the context */
+
+/* pxt_ngp_render_frame for n_renders (<= PXT_NGP_MAX_BATCH) DIFFERENT contexts - K objects tracked in lock-step, one
+ * tracker (and one pyngp.Testbed) per object as pixtrack/pose_trackers/pixloc_tracker_r9.py:287-318 builds them - in ONE
+ * chain of launches: every launch carries the rays of all K renders (blockIdx.y = render), so the short late rounds of one
+ * render fill the launch tails of the others.  ctxs[k] / views_host[k] / outs_host[k] / stats[k] (stats or stats[k] may be
+ * NULL) are what K calls of pxt_ngp_render_frame(ctxs[k], &views_host[k], mode, camera_from_slot, &outs_host[k],
+ * stats[k], stream) would take; the images are bit for bit those calls' images.  One mode for the batch; sizes may
+ * differ.  batch_workspace: device memory of pxt_ngp_batch_workspace_bytes(n_renders) bytes holding the K parameter
+ * records; it must stay untouched until the chain has finished (a per-stream buffer is enough). */
+#define PXT_NGP_MAX_BATCH 16
+int64_t pxt_ngp_batch_workspace_bytes(int32_t n_renders);
+int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views_host, int32_t n_renders, int32_t mode,
+                               int32_t camera_from_slot, const pxt_ngp_outputs* outs_host, uint64_t* const* stats,
+                               void* batch_workspace, void* stream);
 
 /* A render of >= 2^19 rays runs as n pipelines over equal slices of the rays, on the caller's
  * stream and n-1 internal side streams joined before the final resolve: the image is bit for bit

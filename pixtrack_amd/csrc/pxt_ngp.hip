@@ -584,7 +584,7 @@ __device__ inline float ray_start(const NgpParams& P, const Ray& r, int pix, int
 // FROM_INIT: items are the enumerated rays, generated in place; else slots of the previous round.
 constexpr int kTile = 2048;
 template <bool FROM_INIT>
-__global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, const NgpWork Wk, int round) {
+__device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWork& Wk, int round) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
 // compaction and the first march in one launch; every lane builds its own ray - the 8 passes of a pixel repeat
 // make_ray, which is cheaper than the launch it saves).
 template <bool FROM_INIT, int PN>
-__global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
+__device__ __forceinline__ void ngp_compact_march_body(const NgpParams& P, const NgpWork& Wk, int round) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
 }
 
 template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
-__global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
+__device__ __forceinline__ void ngp_shade_body(const NgpParams& P, const NgpWork& Wk, int round) {
   __shared__ half8 s_w[kNumFrags * 64];
   // (the late rounds hold fewer groups than the grid has waves: those workgroups leave before copying the weights)
   if (blockIdx.x > 0 && blockIdx.x * 32 >= Wk.counters[round * kCtrStride] + 7) return;
@@ -1133,7 +1133,7 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
 // orbit - spent 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  The second marched with one lane per ray: 0.70-0.72 ms on
 // those views, 0.75-0.80 with one round before it.)
 template <int MODE>
-__global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round, int rays_per_wg) {
+__device__ __forceinline__ void ngp_tail_body(const NgpParams& P, const NgpWork& Wk, int round, int rays_per_wg) {
   __shared__ half8 s_w[kNumFrags * 64];
   __shared__ unsigned s_feat[4 * 8 * 64];
   const int n = Wk.counters[round * kCtrStride];
@@ -1229,7 +1229,7 @@ __device__ inline float srgb_to_linear(float c) {
 // The last kernel of a render also zeroes the round counters of every pipeline for the NEXT render (everything that
 // reads them has finished by now): no memset launch in front of a render's first kernel.
 struct NgpCounterList { int* p[4]; int n; };
-__global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk, const NgpCounterList zl) {
+__device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWork& Wk, const NgpCounterList& zl) {
   if (blockIdx.x == 0)
     for (int w = 0; w < zl.n; ++w)
       for (int i = threadIdx.x; i < (kMaxRounds + 2) * kCtrStride; i += 256) zl.p[w][i] = 0;
@@ -1300,6 +1300,62 @@ __global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, con
     q[2] = (uint8_t)((long long)(o.z * 255.0f) & 255);
   }
   if (P.out_nz && P.mode != 0) P.out_nz[pix] = (((long long)(depth_x * 255.0f) & 255) != 0) ? 1 : 0;
+}
+
+// ---- the launches.  One render: parameters by value in the kernel-argument segment.  A BATCH of renders (K objects
+// tracked in lock-step, pxt_ngp_render_frame_batch): the same bodies, blockIdx.y picks the object, whose parameter
+// record sits in device memory (K x ~1 KB is more than the argument segment holds).  The records are read-only for the
+// whole chain and addressed uniformly per workgroup, so the loads stay scalar.  Nothing else differs: a ray's result
+// does not depend on which rays share its launches.
+struct NgpBatchItem {
+  NgpParams P;
+  NgpWork W;
+  NgpCounterList zl;
+};
+
+template <bool FROM_INIT>
+__global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  ngp_compact_body<FROM_INIT>(P, Wk, round);
+}
+template <bool FROM_INIT, int PN>
+__global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  ngp_compact_march_body<FROM_INIT, PN>(P, Wk, round);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
+  ngp_shade_body<MODE>(P, Wk, round);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round, int rays_per_wg) {
+  ngp_tail_body<MODE>(P, Wk, round, rays_per_wg);
+}
+__global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk, const NgpCounterList zl) {
+  ngp_resolve_body(P, Wk, zl);
+}
+
+template <bool FROM_INIT>
+__global__ __launch_bounds__(256) void ngp_compact_batch_kernel(const NgpBatchItem* __restrict__ items, int round) {
+  const NgpBatchItem& it = items[blockIdx.y];
+  ngp_compact_body<FROM_INIT>(it.P, it.W, round);
+}
+template <bool FROM_INIT>
+__global__ __launch_bounds__(256) void ngp_compact_march_batch_kernel(const NgpBatchItem* __restrict__ items, int round) {
+  const NgpBatchItem& it = items[blockIdx.y];
+  ngp_compact_march_body<FROM_INIT, 1>(it.P, it.W, round);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ngp_shade_batch_kernel(const NgpBatchItem* __restrict__ items, int round) {
+  const NgpBatchItem& it = items[blockIdx.y];
+  ngp_shade_body<MODE>(it.P, it.W, round);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void ngp_tail_batch_kernel(const NgpBatchItem* __restrict__ items, int round, int rays_per_wg) {
+  const NgpBatchItem& it = items[blockIdx.y];
+  ngp_tail_body<MODE>(it.P, it.W, round, rays_per_wg);
+}
+__global__ __launch_bounds__(256) void ngp_resolve_batch_kernel(const NgpBatchItem* __restrict__ items) {
+  const NgpBatchItem& it = items[blockIdx.y];
+  ngp_resolve_body(it.P, it.W, it.zl);
 }
 
 // Network query at caller-given points (unit tests / debugging): out[n] = (logit, r, g, b).
@@ -1587,27 +1643,17 @@ static void launch_march(int grid, hipStream_t st, const NgpParams& P, const Ngp
   }
 }
 
-static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
-                       uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
-                       float* cam_out = nullptr, uint8_t* out_u8 = nullptr, uint8_t* out_nz = nullptr,
-                       bool camera_from_slot = false) {
+// The view part of a render's parameter record (everything but the device-side camera source), with the argument checks.
+static int fill_view(const pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth, uint64_t* stats,
+                     uint8_t* out_u8, uint8_t* out_nz, NgpParams& P, size_t& rays) {
   if (!ctx || !v) return PXT_E_ARG;
   // every image the mode produces needs somewhere to go: its float form or its 8-bit stand-in
   if (mode != 1 && !out_rgba && !out_u8) return PXT_E_ARG;
   if (mode == 1 && !out_rgba && !out_nz) return PXT_E_ARG;
   if (mode == 2 && !out_depth && !out_nz) return PXT_E_ARG;
   if (v->width < 1 || v->height < 1 || v->spp < 1 || !(v->focal > 0.f)) return PXT_E_ARG;
-  NgpParams P;
   fill_model(ctx, P);
   for (int i = 0; i < 12; ++i) P.cam[i] = v->cam[i];
-  if (pose_src) {  // the camera is derived on the device, in stream order, from a pose record the host has not seen
-    if (!conv) return PXT_E_ARG;
-    hipLaunchKernelGGL(ngp_pose_to_camera_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pose_src, *conv, ctx->cam_dev,
-                       cam_out);
-    P.cam_dev = ctx->cam_dev;
-  } else if (camera_from_slot) {  // written by an earlier kernel of this stream (the LM kernel's epilogue)
-    P.cam_dev = ctx->cam_dev;
-  }
   P.focal = v->focal;
   P.k1 = v->k1;
   for (int i = 0; i < 3; ++i) { P.lo[i] = v->aabb_min[i]; P.hi[i] = v->aabb_max[i]; }
@@ -1620,8 +1666,26 @@ static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out
   P.out_nz = out_nz;
   P.stats = (unsigned long long*)stats;
   // padded to whole 4x2 pixel blocks (the enumeration order of enum_ray)
-  const size_t rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
+  rays = (size_t)((v->width + 3) / 4 * 4) * ((v->height + 1) / 2 * 2) * v->spp;
   if (rays > 0x7fffffffull / kK) return PXT_E_ARG;
+  return PXT_OK;
+}
+
+static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
+                       uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
+                       float* cam_out = nullptr, uint8_t* out_u8 = nullptr, uint8_t* out_nz = nullptr,
+                       bool camera_from_slot = false) {
+  NgpParams P;
+  size_t rays = 0;
+  if (const int rcv = fill_view(ctx, v, mode, out_rgba, out_depth, stats, out_u8, out_nz, P, rays)) return rcv;
+  if (pose_src) {  // the camera is derived on the device, in stream order, from a pose record the host has not seen
+    if (!conv) return PXT_E_ARG;
+    hipLaunchKernelGGL(ngp_pose_to_camera_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pose_src, *conv, ctx->cam_dev,
+                       cam_out);
+    P.cam_dev = ctx->cam_dev;
+  } else if (camera_from_slot) {  // written by an earlier kernel of this stream (the LM kernel's epilogue)
+    P.cam_dev = ctx->cam_dev;
+  }
   hipStream_t s0 = (hipStream_t)stream;
 
   // Two pipelines over the two halves of the ray enumeration, on the caller's stream and on a
@@ -1770,6 +1834,114 @@ extern "C" int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* v, int32_t
   if (!v || !out || mode < 0 || mode > 2) return PXT_E_ARG;
   return render_impl(ctx, v, mode, out->rgba, out->depth_rgba, stats, stream, nullptr, nullptr, nullptr, out->rgb_u8,
                      out->depth_nz, camera_from_slot != 0);
+}
+
+// ---- K renders in ONE chain of launches (K objects tracked in lock-step).
+// A render is a chain of ~12 launches whose late rounds hold few rays: alone on a stream each launch pays its ramp and its
+// tail.  Here blockIdx.y picks the object - own renderer context (hash table, MLPs, occupancy), own view, own ray lists,
+// own outputs - so a launch carries the rays of all K objects and one object's tail is the next one's ramp.  One pipeline
+// per object (the other objects provide the concurrency the two half-renders of a single render give each other).
+// Results are bit for bit the single renders': no ray's result depends on which rays share its launches.
+namespace {
+struct NgpStageSlot {
+  NgpBatchItem* host = nullptr;
+  hipEvent_t copied = nullptr;
+};
+constexpr int kNgpStageSlots = 4;
+}  // namespace
+
+extern "C" int64_t pxt_ngp_batch_workspace_bytes(int32_t n_renders) {
+  if (n_renders < 1 || n_renders > PXT_NGP_MAX_BATCH) return PXT_E_ARG;
+  return (int64_t)((size_t)n_renders * sizeof(NgpBatchItem) + 255) / 256 * 256;
+}
+
+extern "C" int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views, int32_t n_renders, int32_t mode,
+                                          int32_t camera_from_slot, const pxt_ngp_outputs* outs, uint64_t* const* stats,
+                                          void* batch_workspace, void* stream) {
+  if (!ctxs || !views || !outs || !batch_workspace || mode < 0 || mode > 2) return PXT_E_ARG;
+  if (n_renders < 1 || n_renders > PXT_NGP_MAX_BATCH) return PXT_E_ARG;
+  const int K = n_renders;
+  for (int a = 0; a < K; ++a) {
+    if (!ctxs[a]) return PXT_E_ARG;
+    for (int b = a + 1; b < K; ++b)  // a context owns ONE set of ray lists
+      if (ctxs[a] == ctxs[b]) return PXT_E_ARG;
+  }
+  static thread_local NgpStageSlot stage[16][kNgpStageSlots];
+  static thread_local int stage_next[16] = {0};
+  int dev_id = 0;
+  PXT_HIP_CHECK(hipGetDevice(&dev_id));
+  if (dev_id < 0 || dev_id >= 16) return PXT_E_ARG;
+  NgpStageSlot& slot = stage[dev_id][stage_next[dev_id]];
+  stage_next[dev_id] = (stage_next[dev_id] + 1) % kNgpStageSlots;
+  if (!slot.host) {
+    PXT_HIP_CHECK(hipHostMalloc((void**)&slot.host, PXT_NGP_MAX_BATCH * sizeof(NgpBatchItem), hipHostMallocDefault));
+    PXT_HIP_CHECK(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming));
+  } else {
+    PXT_HIP_CHECK(hipEventSynchronize(slot.copied));
+  }
+  hipStream_t s0 = (hipStream_t)stream;
+  int max_pixels = 0;
+  for (int k = 0; k < K; ++k) {
+    pxt_ngp* ctx = ctxs[k];
+    NgpBatchItem& it = slot.host[k];
+    size_t rays = 0;
+    if (const int rcv = fill_view(ctx, &views[k], mode, outs[k].rgba, outs[k].depth_rgba, stats ? stats[k] : nullptr,
+                                  outs[k].rgb_u8, outs[k].depth_nz, it.P, rays))
+      return rcv;
+    if (camera_from_slot) it.P.cam_dev = ctx->cam_dev;
+    if (const int rc = ensure_scratch(ctx, rays, 1)) return rc;
+    it.P.enum_lo = 0;
+    it.P.enum_hi = (long long)rays;
+    it.W = ctx->work[0];
+    it.zl.n = std::min(ctx->scratch_pipes, 4);
+    for (int w = 0; w < 4; ++w) it.zl.p[w] = w < it.zl.n ? ctx->work[w].counters : nullptr;
+    max_pixels = std::max(max_pixels, views[k].width * views[k].height);
+    if (!ctx->counters_clean)
+      PXT_HIP_CHECK(hipMemsetAsync(ctx->work[0].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), s0));
+    ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
+  }
+  PXT_HIP_CHECK(hipMemcpyAsync(batch_workspace, slot.host, (size_t)K * sizeof(NgpBatchItem), hipMemcpyHostToDevice, s0));
+  PXT_HIP_CHECK(hipEventRecord(slot.copied, s0));
+  const NgpBatchItem* items = (const NgpBatchItem*)batch_workspace;
+  // Grid-stride kernels over device-side counts, gridDim.y = K.  Per object a QUARTER of the single render's march grid and
+  // half of its shade grid: with the single render's grids (2048 each) a launch's first object fills the chip alone and the
+  // chain loses to K single renders; measured on the eight config/*.sh objects in two lock-step groups of four
+  // (bench.py --config objects8, same box, frames/s; single renders 1026-1030): march / shade grid 2048 / 2048 945-993,
+  // 2048 / 512 1001, 1024 / 1024 1029, 1024 / 512 1025, 768 / 768 1038, 512 / 512 1043-1047, 512 / 1024 1048, 512 / 384 1040,
+  // 384 / 384 1045, 256 / 256 1031-1033, 128 / 128 905-912 (profiles/r05_experiments.md #16).
+  static const int gx_env = [] { const char* e = getenv("PXT_NGP_BATCH_GRID"); return e ? std::max(atoi(e), 64) : 0; }();
+  static const int gs_env = [] { const char* e = getenv("PXT_NGP_BATCH_GRID_SHADE"); return e ? std::max(atoi(e), 64) : 0; }();
+  const int wide = gx_env ? gx_env : 512, shade_grid = gs_env ? gs_env : (gx_env ? gx_env : 1024), cmp_grid = 1024;
+  static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kRounds; }();
+  static const int tail_grid = [] { const char* e = getenv("PXT_NGP_TAIL_GRID"); return e ? atoi(e) : 1024; }();
+  static const int tail_div = [] { const char* e = getenv("PXT_NGP_TAIL_DIV"); return e ? std::max(atoi(e), 1) : 64; }();
+  const dim3 blk(256);
+  if (n_rounds > 0)  // ray generation + compaction + the first march
+    hipLaunchKernelGGL(ngp_compact_march_batch_kernel<true>, dim3(2 * wide, K), blk, 0, s0, items, 0);
+  else
+    hipLaunchKernelGGL(ngp_compact_batch_kernel<true>, dim3(cmp_grid, K), blk, 0, s0, items, 0);
+  for (int r = 0; r < n_rounds; ++r) {
+    if (mode == 1)
+      hipLaunchKernelGGL(ngp_shade_batch_kernel<1>, dim3(shade_grid, K), blk, 0, s0, items, r);
+    else if (mode == 2)
+      hipLaunchKernelGGL(ngp_shade_batch_kernel<2>, dim3(shade_grid, K), blk, 0, s0, items, r);
+    else
+      hipLaunchKernelGGL(ngp_shade_batch_kernel<0>, dim3(shade_grid, K), blk, 0, s0, items, r);
+    if (r + 1 < n_rounds)  // compaction of round r + march of round r + 1 in one launch
+      hipLaunchKernelGGL(ngp_compact_march_batch_kernel<false>, dim3(wide, K), blk, 0, s0, items, r);
+    else
+      hipLaunchKernelGGL(ngp_compact_batch_kernel<false>, dim3(cmp_grid, K), blk, 0, s0, items, r);
+  }
+  if (mode == 1)
+    hipLaunchKernelGGL(ngp_tail_batch_kernel<1>, dim3(tail_grid, K), blk, 0, s0, items, n_rounds, tail_div);
+  else if (mode == 2)
+    hipLaunchKernelGGL(ngp_tail_batch_kernel<2>, dim3(tail_grid, K), blk, 0, s0, items, n_rounds, tail_div);
+  else
+    hipLaunchKernelGGL(ngp_tail_batch_kernel<0>, dim3(tail_grid, K), blk, 0, s0, items, n_rounds, tail_div);
+  hipLaunchKernelGGL(ngp_resolve_batch_kernel, dim3((max_pixels + 255) / 256, K), blk, 0, s0, items);
+  PXT_HIP_CHECK(hipGetLastError());
+  for (int k = 0; k < K; ++k) ctxs[k]->counters_clean = true;
+  return PXT_OK;
 }
 
 extern "C" int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n) {

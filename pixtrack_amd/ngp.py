@@ -553,6 +553,45 @@ class Testbed:
         self.n_renders += 1
         return out
 
+    @staticmethod
+    def render_frame_batch_device(testbeds, sizes, spp: int = 8, mode: int = 2, from_slot: bool = False, workspace=None):
+        """render_frame_device for K testbeds (K objects, each with its own NeRF) in ONE chain of launches
+        (pxt_ngp_render_frame_batch): every launch carries the rays of all K renders, so one render's short late rounds
+        fill the others' launch tails.  ``sizes[k]`` = (width, height); every testbed's current camera / fov (or, with
+        ``from_slot``, its camera slot) is used as render_frame_device would.  Returns one dict per testbed (``rgb_u8``,
+        ``depth_nz`` as the mode provides), bit for bit what K render_frame_device calls return.  ``workspace``: a device
+        uint8 tensor of batch_workspace_bytes(K) the caller keeps per stream (made here when None)."""
+        K = len(testbeds)
+        assert K >= 1 and len(sizes) == K
+        dev = testbeds[0].device
+        outs, views, flat_sizes, ctxs = [], [], [], []
+        for tb, (w, h) in zip(testbeds, sizes):
+            assert tb._ctx is not None, "load_snapshot first"
+            if not tb.snap_to_pixel_centers:
+                raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
+            o = {}
+            if mode != 1:
+                o["rgb_u8"] = torch.empty(h, w, 3, device=dev, dtype=torch.uint8)
+            if mode != 0:
+                o["depth_nz"] = torch.empty(h, w, device=dev, dtype=torch.uint8)
+            outs.append(o)
+            views += tb._view_for(w, h)
+            flat_sizes += [int(w), int(h)]
+            ctxs.append(tb._ctx_int())
+        if workspace is None:
+            workspace = torch.empty(Testbed.batch_workspace_bytes(K), dtype=torch.uint8, device=dev)
+        stats = [tb.stats_accum for tb in testbeds] if all(tb.stats_accum is not None for tb in testbeds) else []
+        ops.ngp_render_frame_batch(ctxs, views, flat_sizes, int(spp), int(mode), bool(from_slot),
+                                   [o["rgb_u8"] for o in outs] if mode != 1 else [],
+                                   [o["depth_nz"] for o in outs] if mode != 0 else [], workspace, stats)
+        for tb in testbeds:
+            tb.n_renders += 1
+        return outs
+
+    @staticmethod
+    def batch_workspace_bytes(n: int) -> int:
+        return int(_lib.lib().pxt_ngp_batch_workspace_bytes(int(n)))
+
     def _ctx_int(self) -> int:
         return int(self._ctx.value) if hasattr(self._ctx, "value") else int(self._ctx)
 

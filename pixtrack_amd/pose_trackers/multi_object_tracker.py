@@ -28,6 +28,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 
 from .. import _lib
@@ -43,6 +45,7 @@ class _Group:
         self.index, self.members, self.stream, self.model = index, members, stream, model
         self.render_streams: List[torch.cuda.Stream] = []  # optional sub-streams of the group's queued renders
         self.batch_ws: Optional[torch.Tensor] = None
+        self.render_ws: Optional[torch.Tensor] = None  # parameter records of the batched render chain
         self.unet_done: Optional[torch.cuda.Event] = None
         self.pend = None  # what _enqueue left for _finish
 
@@ -50,7 +53,7 @@ class _Group:
 class MultiObjectTracker:
     def __init__(self, trackers: Sequence[PixLocPoseTrackerR9], lm_workgroups: int = 0, per_image_plan: bool = False,
                  max_unet_batch: int = _lib.PXT_UNET_MAX_BATCH, n_groups: int = 1, render_pipelines: int = -1,
-                 render_streams: int = 1):
+                 render_streams: int = 1, batch_renders: Optional[bool] = None):
         """``n_groups`` > 1: the trackers are dealt to that many groups, each with its own stream, batched UNet pass and
         batched LM launch per step; the groups' UNet passes take turns (an event token), so that one group's MFMA-bound
         UNet pass runs beside the other group's latency-bound renders instead of beside its UNet pass."""
@@ -74,6 +77,9 @@ class MultiObjectTracker:
         self.groups: List[_Group] = []
         self.render_pipelines = int(render_pipelines)  # -1: one pipeline per render with several groups, else the default
         self.render_streams = int(render_streams)      # sub-streams per group for the queued renders (experiment: 1 = none)
+        # a group's queued renders as ONE chain of launches carrying the rays of all its objects (pxt_ngp_render_frame_batch;
+        # bit for bit the single renders); PXT_BATCH_RENDERS=0: one chain per object, one after the other
+        self.batch_renders = (os.environ.get("PXT_BATCH_RENDERS", "1") != "0") if batch_renders is None else bool(batch_renders)
         self.set_groups(n_groups)
         self.lm_workgroups = int(lm_workgroups)      # grid per problem of the batched launch; 0: the library's default
         self.per_image_plan = bool(per_image_plan)   # UNet layers planned as for one image (bit-identity with solo runs)
@@ -248,9 +254,12 @@ class MultiObjectTracker:
             for st in subs:
                 st.wait_event(fork)
         j = 0
+        batched = set()
+        if self.batch_renders and not subs:
+            batched = self._batched_renders_ahead(grp)
         for k, tr, path, ref_id, dbg, status, x, handle in grp.pend:
             hook = getattr(tr.localizer.refiner, "after_lm_enqueued", None)
-            if handle is not None and hook is not None:
+            if handle is not None and hook is not None and k not in batched:
                 if subs:
                     with torch.cuda.stream(subs[j % len(subs)]):
                         hook(handle)
@@ -267,6 +276,35 @@ class MultiObjectTracker:
                 ev.record(st)
                 cur.wait_event(ev)
         self._mark("ahead_enqueued")
+
+    def _batched_renders_ahead(self, grp: _Group) -> set:
+        """The group's queued renders (behind the batched LM launch, cameras from its epilogue's slots) in one batched
+        chain per (spp) - returns the members served; the others take their own _render_ahead()."""
+        from ..ngp import Testbed
+
+        by_spp = {}
+        for k, tr, path, ref_id, dbg, status, x, handle in grp.pend:
+            hook = getattr(tr.localizer.refiner, "after_lm_enqueued", None)
+            if handle is None or hook is None or getattr(hook, "__func__", None) is not PixLocPoseTrackerR9._render_ahead:
+                continue
+            req = tr._render_ahead_request()
+            if req is not None:
+                by_spp.setdefault(req[2], []).append((k, tr, req))
+        served = set()
+        for spp, items in by_spp.items():
+            if len(items) < 2:
+                continue
+            if grp.render_ws is None:
+                grp.render_ws = torch.empty(Testbed.batch_workspace_bytes(_lib.PXT_NGP_MAX_BATCH), dtype=torch.uint8,
+                                            device=self.device)
+            for a in range(0, len(items), _lib.PXT_NGP_MAX_BATCH):
+                part = items[a:a + _lib.PXT_NGP_MAX_BATCH]
+                outs = Testbed.render_frame_batch_device([tr.testbed for _k, tr, _r in part], [(r[0], r[1]) for _k, _t, r in part],
+                                                         spp, mode=2, from_slot=True, workspace=grp.render_ws)
+                for (k, tr, _r), out in zip(part, outs):
+                    tr._render_ahead_accept(out)
+                    served.add(k)
+        return served
 
     def _finish(self, grp: _Group, frames, out) -> None:
         # ---- phase E: results, per-object policy (cost gate, pose update, history), the loop's tail

@@ -456,6 +456,27 @@ class PixLocPoseTrackerR9(PoseTracker):
             torch.cuda.current_stream(self.device).wait_event(self._ahead_join)  # (a no-op if nothing was recorded since)
         self._ahead = (cams, mask, ref_u8, views)
 
+    def _render_ahead_request(self):
+        """For a caller that merges the queued renders of several trackers into one batched chain (lock-step tracking,
+        Testbed.render_frame_batch_device): (width, height, spp) of this tracker's one-march mask + reference render with
+        the testbed's view set for it - or None when the frame's render is not of that kind (two different cameras, or
+        the float-image path), in which case _render_ahead() is to be called as usual."""
+        import math
+
+        if not (self.fused_frame_outputs and self._views_coincide()):
+            return None
+        width, height, fl_x = self._coincide_cache[2]
+        self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
+        return int(width), int(height), int(self.spp)
+
+    def _render_ahead_accept(self, out):
+        """What _render_ahead() does after its render, for a render that was part of a batched chain."""
+        views = self._ahead_views_now()
+        nz, ref_u8 = out["depth_nz"], out["rgb_u8"]
+        mask = torch.empty(nz.shape[0], nz.shape[1], dtype=torch.uint8, device=self.device)
+        ops.depth_mask_plane(nz, 1, 5, mask)  # erode 5x5 once, dilate 5x5 five times (:211-213)
+        self._ahead = ([self._ahead_cam], mask, ref_u8, views)
+
     def _ahead_view_key(self, width, height, spp):
         """Everything a queued render baked in besides the camera pose: focal length, lens, render box, background,
         minimum transmittance (floats 12.. of the view record), image size and spp."""
