@@ -39,7 +39,7 @@ done
 o8="python $root/bench.py --config objects8 --steps 12 --warmup 4 --no-solo"
 rocprofv3 --kernel-trace --stats -d $out/o8 -o o8 -- $o8 > $out/${r}_objects8_under_rocprof.log 2>&1
 python $root/scripts/rocpd_summary.py $out/o8/o8_results.db > $out/${r}_objects8_kernel_stats.csv
-python $root/scripts/multiobj_trace.py $out/o8/o8_results.db 6 2 > $out/${r}_objects8_step_summary.txt 2>&1
+python $root/scripts/multiobj_trace.py $out/o8/o8_results.db 6 2 4 > $out/${r}_objects8_step_summary.txt 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS \
   --kernel-trace --output-format csv -d $out/o8sq -- $o8 --groups 1 > $out/o8sq.log 2>&1
 python $root/scripts/pmc_sq_summary.py $out/o8sq > $out/${r}_objects8_pmc_sq.json

@@ -1,6 +1,8 @@
 """Per-step summary of a rocprofv3 kernel trace (rocpd database) of a lock-step multi-object run
 (scripts/bench_multiobj.py / bench.py --config objects8): wall time per step, GPU busy (union of all queues), summed kernel
-time per family, the largest kernels.   python scripts/multiobj_trace.py results.db [steps=8] [launches_per_step=1]"""
+time per family, the largest kernels.   python scripts/multiobj_trace.py results.db [steps=8] [launches_per_step=1] [skip_last=0]
+(skip_last: trailing lm_refine_batch launches to leave out - bench.py --config objects8 ends with 4 one-group diagnostic steps
+with render-ahead off)"""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -15,10 +17,12 @@ def fam(n):
     return "other"
 
 
-def main(path, steps=8, per_step=1):
+def main(path, steps=8, per_step=1, skip_last=0):
     c = sqlite3.connect(path)
     rows = c.execute("select name,start,end,queue_id from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if "lm_refine_batch" in r[0]]
+    if skip_last:
+        idx = idx[:-skip_last]
     n_l = steps * per_step
     a, b = idx[-n_l - 1], idx[-1]
     seg = rows[a + 1:b + 1]
