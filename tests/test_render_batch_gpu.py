@@ -83,6 +83,13 @@ def test_batched_render_full_size_and_stats(device):
         assert int(want_stats[k][0]) > 100000
 
 
+def test_a_batch_of_one_is_the_single_render(device):
+    tb, (w, h) = _objects(device)[1]
+    want = tb.render_frame_device(w, h, 4, mode=2)
+    got = Testbed.render_frame_batch_device([tb], [(w, h)], 4, mode=2)[0]
+    assert torch.equal(got["rgb_u8"], want["rgb_u8"]) and torch.equal(got["depth_nz"], want["depth_nz"])
+
+
 def test_batch_argument_errors(device):
     objs = _objects(device)[:2]
     tbs, sizes = [tb for tb, _ in objs], [s for _, s in objs]
