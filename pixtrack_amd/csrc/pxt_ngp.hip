@@ -387,7 +387,7 @@ constexpr int kK = 8;          // samples per ray per round
 // other config/*.sh boxes (the straggler kernel took 2.3 ms of a lock-step step's 14 ms of kernel time): 3 / 4 / 5 rounds =
 // 653 / 656 / 645 and 650 / 654 / 655 frames/s over 200 frames of the benchmark sequence (a tie), 817 / 904 / 905 frames/s
 // for the eight objects in lock-step (profiles/r05_experiments.md).  Four.
-constexpr int kRounds = 4, kMaxRounds = 12;
+constexpr int kRounds = 4, kBatchRounds = 6, kMaxRounds = 12;
 constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
 
 struct Ray {
@@ -1927,7 +1927,15 @@ extern "C" int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_vi
   static const int gx_env = [] { const char* e = getenv("PXT_NGP_BATCH_GRID"); return e ? std::max(atoi(e), 64) : 0; }();
   static const int gs_env = [] { const char* e = getenv("PXT_NGP_BATCH_GRID_SHADE"); return e ? std::max(atoi(e), 64) : 0; }();
   const int wide = gx_env ? gx_env : 512, shade_grid = gs_env ? gs_env : (gx_env ? gx_env : 1024), cmp_grid = 1024;
-  static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kRounds; }();
+  // Six wavefront rounds before the straggler kernel (a single render: four): a round of the chain is one launch for all K
+  // objects, and the objects of config/*.sh keep more rays alive than the benchmark object (the straggler launch of four
+  // objects took 0.37 ms).  Eight objects, same box: 4 / 5 / 6 / 8 rounds = 1059 / 1063 / 1072 / 1072 frames/s.  A ray's result
+  // does not depend on the number of rounds (the straggler kernel runs the rounds' own steps).
+  static const int n_rounds = [] {
+    const char* e = getenv("PXT_NGP_BATCH_ROUNDS");
+    if (!e) e = getenv("PXT_NGP_ROUNDS");
+    return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kBatchRounds;
+  }();
   static const int tail_grid = [] { const char* e = getenv("PXT_NGP_TAIL_GRID"); return e ? atoi(e) : 1024; }();
   static const int tail_div = [] { const char* e = getenv("PXT_NGP_TAIL_DIV"); return e ? std::max(atoi(e), 1) : 64; }();
   const dim3 blk(256);
