@@ -43,11 +43,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // kernel and oracle visit identical samples.  The hash-grid interpolation of a sample's features (ngp_encode_level*) may
 // contract: 8 v_pk_fma_f32 instead of 8 v_pk_mul_f32 + 8 v_pk_add_f32 per level, one rounding less per accumulation; the
 // two features are rounded to fp16 right after, so nearly every packed feature keeps its bits (every parity test and
-// fixture unchanged: sample counts equal, masks bit-exact).  Shade launch -3 %, value +0.8 % (profiles/r05_experiments.md #19);
-// -DPXT_NGP_ENC_FMA=0 restores the uncontracted form.
-#ifndef PXT_NGP_ENC_FMA
-#define PXT_NGP_ENC_FMA 1
-#endif
+// fixture unchanged: sample counts equal, masks bit-exact).  Shade launch -3 %, value +0.8 % (profiles/r05_experiments.md #19).
 constexpr int kGrid = 128;
 constexpr int kMaxLevels = 16;
 constexpr int kNumFrags = 24;  // d1:4 d2:4 c1:4 c2:8 c3:4
@@ -159,9 +155,7 @@ __device__ inline half8 relu_pack8(const f32x16& a, int base, bool relu) {
 // One hash-grid level at a warped position in [0,1]^3 -> packed (f0, f1) fp16 pair.
 __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, const NgpLevel& Lv, float ux,
                                             float uy, float uz) {
-#if PXT_NGP_ENC_FMA
-#pragma clang fp contract(fast)
-#endif
+#pragma clang fp contract(fast)  // (this function only: see the note at kGrid)
   const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
   const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
   const float ax = qx - fx, ay = qy - fy, az = qz - fz;
@@ -201,9 +195,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned uint2_t;
 // address arithmetic per corner (18 v_mad_u64_u32 + 14 v_lshl_add_u64 per item in the first version).
 __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t grid, const NgpLevel& Lv, float ux,
                                                     float uy, float uz) {
-#if PXT_NGP_ENC_FMA
-#pragma clang fp contract(fast)
-#endif
+#pragma clang fp contract(fast)  // (this function only: see the note at kGrid)
   const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
   const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
   const float ax = qx - fx, ay = qy - fy, az = qz - fz;
