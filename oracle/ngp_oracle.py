@@ -28,7 +28,10 @@ specification the HIP kernel is tested against:
 * occupancy bitfield: one bit per 128^3 cell, x fastest, cascades concatenated;
 * empty cells are skipped by stepping t in dt increments to the next voxel border;
 * hash grid: tcnn layout (dense below 2^19 entries, else the 3-prime xor hash),
-  trilinear, fp16 table, fp16 output; SH degree 4 of the view direction (fp16);
+  trilinear, fp16 table, fp16 output; SH degree 4 of the view direction (fp16)   [the trilinear sum here is separate
+  fp32 multiplies and adds; the HIP kernel's may contract them (one rounding less per corner, round 5) - the fp16
+  rounding of the two features that follows hides it for all but a few packed values; the MARCH arithmetic stays
+  operation for operation this file's, which is what makes ray and sample counts EQUAL in the tests];
 * MLPs: fp16 weights and activations, fp32 accumulation, ReLU hidden, density =
   exp(out[0]), rgb = sigmoid(out[0..2]);
 * compositing front to back, stop when transmittance < min_transmittance with the
