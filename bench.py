@@ -1091,7 +1091,9 @@ def main():
                 "straggler_samples_per_render": round(stats[3] / max(n_renders, 1), 1),
                 "note": ("timed region: the render runs as two overlapping pipelines, so a launch shares the chip "
                          "with the other slice's march/shade and its duration is not the kernel's isolated speed"),
-                "binding_resource": ("the L1 miss path (requests to L2 x ~300 cycles of latency, L1 busy ~89 %), NOT HBM "
+                "binding_resource": ("the ISSUE of the gathers (128 gather instructions per 64 samples, a quad of lanes per clock of "
+                                     "the CU's address unit: ~0.31 ms per render against ~0.41 measured, L1 busy ~89 %; the L1 / L2 "
+                                     "misses are the last quarter - profiles/r05_experiments.md #23, #24), NOT HBM "
                                      "bytes: `bound` keeps the contract's hbm|mfma vocabulary and prices the ALGORITHMIC "
                                      "gather bytes against the HBM peak; `traffic` (fabric side) is ~0.35 x that, `l2` "
                                      "prices the L2 requests against the L2's peak"),
