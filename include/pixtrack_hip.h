@@ -46,7 +46,7 @@ extern "C" {
 #define PXT_LM_LOG_STRIDE 20 /* floats per logged iteration, see pxt_lm_refine */
 
 /* Library / device info ---------------------------------------------------- */
-int pxt_version(void);               /* ABI version (10), bumps on any signature change or added entry point */
+int pxt_version(void);               /* ABI version (11), bumps on any signature change or added entry point */
 const char* pxt_last_error(void);    /* text of the last PXT_E_HIP on this thread */
 int pxt_device_cus(int* n_cus_host); /* multiprocessor count of the current device */
 
@@ -381,28 +381,40 @@ int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* view_host, int32_t mo
                          const pxt_ngp_outputs* out, uint64_t* stats, void* stream);
 float* pxt_ngp_camera_slot(pxt_ngp* ctx); /* device float[12], owned by the context */
 
-/* pxt_ngp_render_frame for n_renders (<= PXT_NGP_MAX_BATCH) DIFFERENT contexts - K objects tracked in lock-step, one
- * tracker (and one pyngp.Testbed) per object as pixtrack/pose_trackers/pixloc_tracker_r9.py:287-318 builds them - in ONE
- * chain of launches: every launch carries the rays of all K renders (blockIdx.y = render), so the short late rounds of one
- * render fill the launch tails of the others.  ctxs[k] / views_host[k] / outs_host[k] / stats[k] (stats or stats[k] may be
- * NULL) are what K calls of pxt_ngp_render_frame(ctxs[k], &views_host[k], mode, camera_from_slot, &outs_host[k],
- * stats[k], stream) would take; the images are bit for bit those calls' images.  One mode for the batch; sizes may
- * differ.  batch_workspace: device memory of pxt_ngp_batch_workspace_bytes(n_renders) bytes holding the K parameter
- * records; it must stay untouched until the chain has finished (a per-stream buffer is enough). */
+/* pxt_ngp_render_frame for n_renders (<= PXT_NGP_MAX_BATCH) DIFFERENT contexts in ONE chain of launches on ONE stream:
+ *   - a frame's two renders of different cameras - the mask's Depth render at the query camera and the reference image's
+ *     Shade render at SfM camera 1 x reference_scale, at the same pose
+ *     (pixtrack/pose_trackers/pixloc_tracker_r9.py:145-152, 207-214): modes {1, 0}, the second context made with
+ *     pxt_ngp_create_shared;
+ *   - K objects tracked in lock-step, one tracker (and one pyngp.Testbed) per object as
+ *     pixtrack/pose_trackers/pixloc_tracker_r9.py:287-318 builds them: modes {2, 2, ...}.
+ * Every launch of the chain carries a stage of every render (the shade stage of one half of the rays beside the march stage
+ * of the other half: csrc/pxt_ngp.hip, ngp_stage_kernel), so nothing depends on how streams are dealt to hardware queues.
+ * ctxs[k] / views_host[k] / modes[k] / outs_host[k] / stats[k] (stats or stats[k] may be NULL) are what K calls of
+ * pxt_ngp_render_frame(ctxs[k], &views_host[k], modes[k], camera_from_slot, &outs_host[k], stats[k], stream) would take; the
+ * images are bit for bit those calls' images.  Modes and sizes may differ per render.  batch_workspace: device memory of
+ * pxt_ngp_batch_workspace_bytes(n_renders) bytes for the parameter records (may be NULL for n_renders <= 2, whose records
+ * travel as kernel arguments); it must stay untouched until the chain has finished (a per-stream buffer is enough). */
 #define PXT_NGP_MAX_BATCH 16
 int64_t pxt_ngp_batch_workspace_bytes(int32_t n_renders);
-int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views_host, int32_t n_renders, int32_t mode,
-                               int32_t camera_from_slot, const pxt_ngp_outputs* outs_host, uint64_t* const* stats,
-                               void* batch_workspace, void* stream);
+int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views_host, int32_t n_renders,
+                               const int32_t* modes, int32_t camera_from_slot, const pxt_ngp_outputs* outs_host,
+                               uint64_t* const* stats, void* batch_workspace, void* stream);
 
-/* A render of >= 2^19 rays runs as n pipelines over equal slices of the rays, on the caller's
- * stream and n-1 internal side streams joined before the final resolve: the image is bit for bit
- * the same, the kernel chains overlap (the latency-bound march of one slice beside the L1-bound
- * gathers / MFMA-bound MLPs of another's shade kernel).  n = 0 restores the default (2, or $PXT_NGP_PIPES);
- * n = 1 serialises the render on the caller's stream (isolated per-kernel timing); n <= 4. */
+/* A second context over the SAME snapshot as `src`: own ray lists, counters and camera slot, shared (reference-counted)
+ * hash table / MLP / occupancy tables - what a frame's second render needs (the testbed pixtrack drives is one object with
+ * one snapshot, pixtrack/utils/ingp_utils.py:22-44, rendered twice per frame with different cameras).  Destroy each context
+ * with pxt_ngp_destroy, in any order. */
+int pxt_ngp_create_shared(pxt_ngp* src, pxt_ngp** out_ctx);
+
+/* A render of >= 2^19 rays is cut into n pipes - equal slices of the rays - whose stages share the launches of the
+ * render's chain one stage apart (the latency-bound march of one slice beside the gather-bound shade stage of
+ * another): the image is bit for bit the same.  n = 0 restores the default (2, or $PXT_NGP_PIPES); n = 1: one pipe, every
+ * launch carries ONE stage (isolated per-stage timing); n <= 4. */
 int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n);
 
-/* Live HIP-event timing of the renderer's dominant kernel (the round's gather kernel, ngp_shade_kernel<MODE>), for the
+/* Live HIP-event timing of the renderer's dominant launches (those of ngp_stage_kernel that carry a shade stage: the hash-grid
+ * gathers + both MLPs + compositing of a round's samples), for the
  * roofline line of bench.py.  every_nth > 0: those launches of every every_nth-th render
  * are bracketed by an event pair recorded on the render's own stream (an event record is a
  * marker packet between kernels, so sampling keeps the measurement from slowing what it

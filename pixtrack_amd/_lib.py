@@ -20,7 +20,7 @@ LIB_PATH = Path(os.environ["PIXTRACK_HIP_LIB"]) if os.environ.get("PIXTRACK_HIP_
 PXT_MAX_LEVELS = 8
 PXT_LM_LOG_STRIDE = 20
 PXT_E_TIMEOUT = -3
-ABI_VERSION = 10
+ABI_VERSION = 11
 PXT_LM_MAX_BATCH = 16
 PXT_UNET_MAX_BATCH = 16
 PXT_NGP_MAX_BATCH = 16
@@ -179,8 +179,9 @@ PROTOTYPES = {
     "pxt_ngp_render_frame": (C.c_int, [_VP, C.POINTER(NgpView), _I32, _I32, C.POINTER(NgpOutputs), _VP, _VP]),
     "pxt_ngp_camera_slot": (_VP, [_VP]),
     "pxt_ngp_batch_workspace_bytes": (_I64, [_I32]),
-    "pxt_ngp_render_frame_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(NgpView), _I32, _I32, _I32, C.POINTER(NgpOutputs),
-                                              C.POINTER(_VP), _VP, _VP]),
+    "pxt_ngp_render_frame_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(NgpView), _I32, C.POINTER(_I32), _I32,
+                                              C.POINTER(NgpOutputs), C.POINTER(_VP), _VP, _VP]),
+    "pxt_ngp_create_shared": (C.c_int, [_VP, C.POINTER(_VP)]),
     "pxt_ngp_set_pipelines": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_enable": (C.c_int, [_VP, _I32]),
     "pxt_ngp_timing_read": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),

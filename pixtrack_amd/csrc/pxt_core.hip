@@ -28,7 +28,7 @@ hipStream_t shared_side_stream(int i) {
 }
 }  // namespace pxt
 
-extern "C" int pxt_version(void) { return 10; }
+extern "C" int pxt_version(void) { return 11; }
 extern "C" const char* pxt_last_error(void) { return pxt::g_last_error; }
 extern "C" int pxt_device_cus(int* n_cus) {
   if (!n_cus) return PXT_E_ARG;

@@ -25,6 +25,7 @@
 //        ds_read_b128 per fragment per step.
 #include "pxt_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -590,8 +591,10 @@ __device__ inline float ray_start(const NgpParams& P, const Ray& r, int pix, int
 // counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue").
 // FROM_INIT: items are the enumerated rays, generated in place; else slots of the previous round.
 constexpr int kTile = 2048;
+// (blk / nblk: this workgroup's index and the number of workgroups working on THIS pipeline's list - blockIdx.x /
+// gridDim.x of a launch that carries one pipeline, a share of the launch in the staged chain, ngp_stage_kernel)
 template <bool FROM_INIT>
-__device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWork& Wk, int round) {
+__device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWork& Wk, int round, int blk, int nblk) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
@@ -600,7 +603,7 @@ __device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWo
   int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long tiles = (n + kTile - 1) / kTile;
-  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (long long tile = blk; tile < tiles; tile += nblk) {
     const long long i0 = tile * kTile + (long long)threadIdx.x * 8;
     bool k[8];
     int cnt = 0;
@@ -677,125 +680,32 @@ __device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWo
   }
 }
 
-#if PXT_EXP_STAMPS  // timing experiment (scripts/march_stamps.py): per-wave stamps of one round of pipeline 0
-__device__ unsigned long long pxt_ngp_stamps[16384 * 8];
-__device__ int pxt_ngp_stamp_round = 0;
-#define PXT_MARCH_STAMP_BEGIN                                                                  \
-  const bool stamp = round == pxt_ngp_stamp_round && P.enum_lo == 0;                           \
-  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);                                          \
-  unsigned long long* stp = pxt_ngp_stamps + (size_t)(gw & 16383) * 8;                         \
-  const bool stamper = stamp && (threadIdx.x & 63) == 0 && gw < 16384;                         \
-  int dbg_trips = 0;                                                                           \
-  if (stamper) { stp[0] = __builtin_amdgcn_s_memrealtime(); stp[1] = __builtin_amdgcn_s_memtime(); stp[5] = 0; }
-#define PXT_MARCH_STAMP_LOADED                                                                 \
-  if (stamper) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[2] = __builtin_amdgcn_s_memtime(); stp[5] += 1; }
-#define PXT_MARCH_TRIP ++dbg_trips;
-#define PXT_MARCH_STAMP_RAY                                                                    \
-  {                                                                                            \
-    int mh = dbg_trips;                                                                        \
-    for (int m = 32; m >= 1; m >>= 1) mh = max(mh, __shfl_xor(mh, m, 64));                     \
-    if (stamper) { stp[6] = mh; stp[7] = 0; }                                                  \
-  }
-#define PXT_MARCH_STAMP_END \
-  if (stamper) { stp[3] = __builtin_amdgcn_s_memtime(); stp[4] = __builtin_amdgcn_s_memrealtime(); }
-#else
-#define PXT_MARCH_STAMP_BEGIN
-#define PXT_MARCH_STAMP_LOADED
-#define PXT_MARCH_TRIP
-#define PXT_MARCH_STAMP_RAY
-#define PXT_MARCH_STAMP_END
-#endif
-// A lane's next K = 8 samples with PN lattice points probed per trip.  The lattice t' = t + dt(t) does not depend on
-// what the cells hold, so a lane can compute PN points ahead, issue their PN occupancy loads together and then replay
-// the serial walk over the results - sample / skip to the border of the empty cell (at least one step, then every
-// point short of the border: advance_past_cell) / leave the box - bit for bit the one-point-per-trip loop, with a PN-th
-// of its dependent load round trips.  (The march is a latency chain: VALU busy 0.14, a trip = one dependent
-// occupancy load + ~100 VALU; the straggler kernel spreads the same idea over the 8 lanes of a ray, ngp_march_group.)
-// PN = 1 is the one-point loop itself.
-template <int PN>
+// A lane's next K = 8 samples: the ray walks its lattice as a flat state machine - one lattice point per loop trip, which
+// is either taken as the ray's next sample or skipped to the far side of its empty cell - so a wave makes
+// max-over-lanes(samples + empty cells) trips.  (The first version nested the empty-cell loop inside the loop over the K
+// samples: a wave then made sum-over-k max-over-lanes trips, every trip a dependent occupancy load; in-kernel stamps showed
+// a median wave at 25 us, the slowest at 110 us, and the launch waiting for those.  Rounds 4-5 also carried variants that
+// probed 2 / 4 / 8 lattice points per trip - bit-exact, a PN-th of the dependent loads, and no shorter launches: what a
+// march launch waits for is a CU slot beside the shade workgroups, not its own rays, profiles/r04_experiments.md #15 -
+// and an unfused march kernel; both were removed in round 6 with the launch path they belonged to.)
 __device__ __forceinline__ void ngp_march_lane(const NgpParams& P, const NgpWork& Wk, const Ray& r, size_t s0, float& t,
                                                bool& out) {
   int k = 0;
   out = false;
-  if (PN == 1) {
-    while (k < kK) {
-      if (t >= r.tmax) { out = true; break; }
-      float pos[3], dt;
-      int mip;
-      if (probe_cell(P, r, t, pos, dt, mip)) {
-        Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
-        Wk.st_t[s0 + k] = t;
-        t = t + dt;
-        ++k;
-      } else {
-        advance_past_cell(P, r, t, pos, mip);
-      }
-    }
-  } else {
-    float pending = -INFINITY;  // the border of the empty cell being skipped
-    while (k < kK && !out) {
-      float tt[PN + 1];
-      tt[0] = t;
-#pragma unroll
-      for (int i = 0; i < PN; ++i) tt[i + 1] = tt[i] + calc_dt(tt[i], P.cone_angle, P.dt_lo, P.dt_hi);
-      bool occ[PN];
-      float target[PN];
-#pragma unroll
-      for (int i = 0; i < PN; ++i) {
-        occ[i] = false;
-        target[i] = -INFINITY;
-        if (tt[i] < r.tmax && tt[i] >= pending) {  // (the walk cannot reach the other points)
-          float pos[3], dt;
-          int mip;
-          occ[i] = probe_cell(P, r, tt[i], pos, dt, mip);
-          if (!occ[i]) target[i] = cell_exit_t(r, tt[i], pos, mip);
-        }
-      }
-      float t_next = tt[PN];
-      bool fin = false;
-#pragma unroll
-      for (int i = 0; i < PN; ++i) {
-        if (fin || tt[i] < pending) continue;  // done, or still inside the skipped cell
-        if (tt[i] >= r.tmax) { out = true; fin = true; t_next = tt[i]; continue; }
-        if (occ[i]) {
-          const float ts = tt[i];
-          Wk.spos[s0 + k] = make_float4(r.o[0] + ts * r.d[0], r.o[1] + ts * r.d[1], r.o[2] + ts * r.d[2],
-                                        calc_dt(ts, P.cone_angle, P.dt_lo, P.dt_hi));
-          Wk.st_t[s0 + k] = ts;
-          ++k;
-          if (k == kK) { fin = true; t_next = tt[i + 1]; }
-        } else {
-          pending = target[i];
-        }
-      }
-      t = t_next;
+  while (k < kK) {
+    if (t >= r.tmax) { out = true; break; }
+    float pos[3], dt;
+    int mip;
+    if (probe_cell(P, r, t, pos, dt, mip)) {
+      Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
+      Wk.st_t[s0 + k] = t;
+      t = t + dt;
+      ++k;
+    } else {
+      advance_past_cell(P, r, t, pos, mip);
     }
   }
   for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// One thread per live ray.  The ray walks its lattice as a flat state machine - one lattice point per
-// loop trip, which is either taken as the ray's next sample or skipped to the far side of its empty
-// cell - so a wave makes max-over-lanes(samples + empty cells) trips.  (The first version nested the
-// empty-cell loop inside the loop over the K samples: a wave then made sum-over-k max-over-lanes trips,
-// every trip a dependent occupancy load; in-kernel stamps showed a median wave at 25 us, the slowest
-// at 110 us, and the launch waiting for those.)
-template <int PN>
-__global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  const int n = Wk.counters[round * kCtrStride];
-  const RayState& S = Wk.st[round & 1];
-  PXT_MARCH_STAMP_BEGIN
-  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < n; slot += gridDim.x * 256) {
-    const Ray r = ray_from_record(P, Wk.raydir[S.rid[slot]]);
-    float t = S.t[slot];
-    PXT_MARCH_STAMP_LOADED
-    bool out;
-    ngp_march_lane<PN>(P, Wk, r, (size_t)slot * kK, t, out);
-    S.t[slot] = t;
-    Wk.exhausted[slot] = out ? 1 : 0;
-    PXT_MARCH_STAMP_RAY
-  }
-  PXT_MARCH_STAMP_END
 }
 
 // Compaction of round r's survivors AND round r + 1's march in one launch: a workgroup compacts a tile of 256
@@ -807,8 +717,8 @@ __global__ __launch_bounds__(256) void ngp_march_kernel(const NgpParams P, const
 // FROM_INIT: the tile's items are enumerated rays generated in place (round 0: ray generation, box test,
 // compaction and the first march in one launch; every lane builds its own ray - the 8 passes of a pixel repeat
 // make_ray, which is cheaper than the launch it saves).
-template <bool FROM_INIT, int PN>
-__device__ __forceinline__ void ngp_compact_march_body(const NgpParams& P, const NgpWork& Wk, int round) {
+template <bool FROM_INIT>
+__device__ __forceinline__ void ngp_compact_march_body(const NgpParams& P, const NgpWork& Wk, int round, int blk, int nblk) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
@@ -817,7 +727,7 @@ __device__ __forceinline__ void ngp_compact_march_body(const NgpParams& P, const
   int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long tiles = (n + 255) / 256;
-  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (long long tile = blk; tile < tiles; tile += nblk) {
     const long long i = tile * 256 + threadIdx.x;
     bool kept;
     // the survivor's record is fetched (or the new ray built) while the tile's base is still being negotiated
@@ -869,7 +779,7 @@ __device__ __forceinline__ void ngp_compact_march_body(const NgpParams& P, const
       D.acc[slot] = acc_;
       D.accd[slot] = accd_;
       bool out;
-      ngp_march_lane<PN>(P, Wk, r, (size_t)slot * kK, t, out);
+      ngp_march_lane(P, Wk, r, (size_t)slot * kK, t, out);
       D.t[slot] = t;
       Wk.exhausted[slot] = out ? 1 : 0;
     }
@@ -1013,13 +923,14 @@ __device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWor
                                    n_samples, Wk.spos[si], MODE != 0 ? Wk.st_t[si] : 0.f, Wk.exhausted[sl] != 0);
 }
 
+// s_w [kNumFrags * 64] / s_feat [4 * 8 * 64]: the workgroup's LDS areas (MLP weight fragments; feature staging), declared by
+// the kernel so that the modes' instantiations inside one kernel share them.
 template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
-__device__ __forceinline__ void ngp_shade_body(const NgpParams& P, const NgpWork& Wk, int round) {
-  __shared__ half8 s_w[kNumFrags * 64];
+__device__ __forceinline__ void ngp_shade_body(const NgpParams& P, const NgpWork& Wk, int round, int blk, int nblk, half8* s_w,
+                                               unsigned* s_feat) {
   // (the late rounds hold fewer groups than the grid has waves: those workgroups leave before copying the weights)
-  if (blockIdx.x > 0 && blockIdx.x * 32 >= Wk.counters[round * kCtrStride] + 7) return;
+  if (blk > 0 && blk * 32 >= Wk.counters[round * kCtrStride] + 7) return;
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
-  __shared__ unsigned s_feat[4 * 8 * 64];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
   __syncthreads();
@@ -1029,7 +940,7 @@ __device__ __forceinline__ void ngp_shade_body(const NgpParams& P, const NgpWork
   const int rlane = lane >> 3;
   unsigned long long n_samples = 0;
   const int n_groups = (n + 7) / 8;
-  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+  for (int g = blk * 4 + wave; g < n_groups; g += nblk * 4) {
     const int slot = g * 8 + rlane;
     ngp_shade_group<MODE>(P, Wk, S, Wk.keep[round & 1], s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, slot < n, 0, n_samples);
   }
@@ -1140,11 +1051,10 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
 // orbit - spent 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  The second marched with one lane per ray: 0.70-0.72 ms on
 // those views, 0.75-0.80 with one round before it.)
 template <int MODE>
-__device__ __forceinline__ void ngp_tail_body(const NgpParams& P, const NgpWork& Wk, int round, int rays_per_wg) {
-  __shared__ half8 s_w[kNumFrags * 64];
-  __shared__ unsigned s_feat[4 * 8 * 64];
+__device__ __forceinline__ void ngp_tail_body(const NgpParams& P, const NgpWork& Wk, int round, int rays_per_wg, int blk, int nblk,
+                                              half8* s_w, unsigned* s_feat) {
   const int n = Wk.counters[round * kCtrStride];
-  if (P.stats && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (P.stats && blk == 0 && threadIdx.x == 0) {
     atomicAdd(P.stats + 1, (unsigned long long)Wk.counters[0]);
     atomicAdd(P.stats + 2, (unsigned long long)n);  // rays left for this kernel
   }
@@ -1152,8 +1062,8 @@ __device__ __forceinline__ void ngp_tail_body(const NgpParams& P, const NgpWork&
   // as their longest ray, and four of them fill a CU's registers: a full grid of them keeps the OTHER pipeline's next
   // launches waiting for a slot (its 5-us compaction took 10-90 us beside this kernel), a small one leaves a long list
   // to too few waves.
-  const int n_wg = min((int)gridDim.x, max((int)gridDim.x / 4, (n + rays_per_wg - 1) / rays_per_wg));
-  if ((int)blockIdx.x >= n_wg || blockIdx.x * 32 >= n) return;  // (workgroup-uniform)
+  const int n_wg = min(nblk, max(nblk / 4, (n + rays_per_wg - 1) / rays_per_wg));
+  if (blk >= n_wg || blk * 32 >= n) return;  // (workgroup-uniform)
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
@@ -1168,7 +1078,7 @@ __device__ __forceinline__ void ngp_tail_body(const NgpParams& P, const NgpWork&
   // samples per step until its share of the list runs out.  (Shares drawn from a shared counter instead, 64 entries per
   // atomic: 0.85-1.4 ms per render against 0.63-0.70 - returning atomics on one word are served one per ~100 ns, and the
   // 4096 waves' first draw alone takes 0.4 ms.  The grid is larger than what is resident instead: the dispatcher is the queue.)
-  const int n_waves = n_wg * 4, wave_id = blockIdx.x * 4 + wave;
+  const int n_waves = n_wg * 4, wave_id = blk * 4 + wave;
   auto stream_slot = [&](int s) { return ((s >> 3) * n_waves + wave_id) * 8 + (s & 7); };
   int cursor = 8;
   int slot = stream_slot(rlane);
@@ -1236,8 +1146,8 @@ __device__ inline float srgb_to_linear(float c) {
 // The last kernel of a render also zeroes the round counters of every pipeline for the NEXT render (everything that
 // reads them has finished by now): no memset launch in front of a render's first kernel.
 struct NgpCounterList { int* p[4]; int n; };
-__device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWork& Wk, const NgpCounterList& zl) {
-  if (blockIdx.x == 0)
+__device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWork& Wk, const NgpCounterList& zl, int blk) {
+  if (blk == 0)
     for (int w = 0; w < zl.n; ++w)
       for (int i = threadIdx.x; i < (kMaxRounds + 2) * kCtrStride; i += 256) zl.p[w][i] = 0;
   // One lane per pixel: it reads the pixel's spp finished rays (contiguous: 16 B x spp, whole lines per lane)
@@ -1246,7 +1156,7 @@ __device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWo
   // zero-fills the buffers.  (The first version spread a pixel over 8 lanes and funnelled the passes through
   // 40 ds_bpermute shuffles per pixel: 21.6 us per 640x480x8 resolve.)
   const int wh = P.W * P.H;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int pix = blk * 256 + threadIdx.x;
   if (pix >= wh) return;
   const bool hit = make_ray(P, pix % P.W, pix / P.W).hit;
   float ar = 0.f, ag = 0.f, ab = 0.f, aa = 0.f, ad = 0.f;
@@ -1309,60 +1219,123 @@ __device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWo
   if (P.out_nz && P.mode != 0) P.out_nz[pix] = (((long long)(depth_x * 255.0f) & 255) != 0) ? 1 : 0;
 }
 
-// ---- the launches.  One render: parameters by value in the kernel-argument segment.  A BATCH of renders (K objects
-// tracked in lock-step, pxt_ngp_render_frame_batch): the same bodies, blockIdx.y picks the object, whose parameter
-// record sits in device memory (K x ~1 KB is more than the argument segment holds).  The records are read-only for the
-// whole chain and addressed uniformly per workgroup, so the loads stay scalar.  Nothing else differs: a ray's result
-// does not depend on which rays share its launches.
+// ---- the launches: a STAGED CHAIN on one stream (round 6).
+//
+// A render is cut into PIPES (one for a small render, two halves of the ray enumeration otherwise); a chain carries the
+// pipes of one render, of a frame's two renders (the mask's Depth at the query camera + the reference image's Shade at the
+// reference camera, pixtrack/pose_trackers/pixloc_tracker_r9.py:145-152,207-214) or of K objects tracked in lock-step.
+// A pipe's stages depend on each other - generate + march, shade, compact + march, shade, ..., stragglers - but pipes do
+// not, and the two kinds of stage want different things of the chip: the march is a chain of dependent occupancy loads
+// (latency), the shade kernel is bound by the issue of its gathers.  Rounds 2-5 ran the halves as two chains on two HIP
+// streams (a third stream for a frame's second render) and left the overlap to how HIP deals streams to hardware queues:
+// the same command measured 396 and 544 frames/s on two boxes of one pool.  Here the overlap is
+// written down: the pipes are dealt to two PHASES one stage apart, and ONE launch carries a stage of every pipe - phase
+// A's shade beside phase B's march, then A's compaction + march beside B's shade, ... - with the workgroups of the launch
+// dealt to the pipes in an interleaved pattern (8 consecutive workgroups - one per XCD - to a pipe, then the next pipe),
+// so that what is resident at any time is a mix of both kinds.  No side stream, no event, nothing for a queue
+// assignment to decide; and a ray's result never depended on which rays share its launches: every image is bit for bit
+// what the separate launches produced.
+constexpr int kMaxChainPipes = 2 * PXT_NGP_MAX_BATCH;
+constexpr int kMaxSlots = 128;
+enum NgpRole : unsigned char {
+  kRoleIdle = 0, kRoleInitMarch, kRoleInitCompact, kRoleCompactMarch, kRoleCompact, kRoleShade
+};
 struct NgpBatchItem {
   NgpParams P;
   NgpWork W;
   NgpCounterList zl;
 };
+// One launch of the chain (kernel argument).  A pipe with multiplicity m runs m * rows * 8 workgroups: chunk c = 8
+// consecutive workgroups belongs to slot c % n_slots, a pipe owns m slots.
+struct NgpStage {
+  int n_slots, rows;
+  unsigned char slot_pipe[kMaxSlots], slot_sub[kMaxSlots];
+  unsigned char mult[kMaxChainPipes], role[kMaxChainPipes], round[kMaxChainPipes];
+};
+// The pipes' parameter records: by value in the kernel-argument segment while they fit (<= 4 pipes: a render, a frame's
+// pair), else in device memory (K objects in lock-step; uploaded from a pinned ring ahead of the chain).  Read-only for
+// the whole chain and addressed uniformly per workgroup: scalar loads either way.
+// (By value they MUST be the kernel's first parameter: the kernels address them through the kernel-argument segment
+// pointer - indexing the by-value aggregate itself makes the compiler copy all of it to scratch first, 3 KB per lane.  In
+// memory the pointer is a __restrict__ kernel parameter, which is what lets the compiler keep the loads scalar.)
+template <int NV>
+struct NgpItemsByValue {
+  NgpBatchItem it[NV];
+};
+__device__ __forceinline__ const NgpBatchItem& ngp_kernarg_item(int i) {
+  return ((const NgpBatchItem*)__builtin_amdgcn_kernarg_segment_ptr())[i];
+}
 
-template <bool FROM_INIT>
-__global__ __launch_bounds__(256) void ngp_compact_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  ngp_compact_body<FROM_INIT>(P, Wk, round);
+// MODES: 0 / 1 / 2 = every pipe of the chain renders in that mode; 3 = per pipe (P.mode; a frame's Depth + Shade pair).
+template <int MODES>
+__device__ __forceinline__ void ngp_stage_impl(const NgpBatchItem& it, int role, int round, int blk, int nblk, half8* s_w,
+                                               unsigned* s_feat) {
+  const int mode = MODES == 3 ? it.P.mode : MODES;
+  switch (role) {
+    case kRoleInitMarch: ngp_compact_march_body<true>(it.P, it.W, round, blk, nblk); break;
+    case kRoleInitCompact: ngp_compact_body<true>(it.P, it.W, round, blk, nblk); break;
+    case kRoleCompactMarch: ngp_compact_march_body<false>(it.P, it.W, round, blk, nblk); break;
+    case kRoleCompact: ngp_compact_body<false>(it.P, it.W, round, blk, nblk); break;
+    case kRoleShade:
+      if (mode == 0) ngp_shade_body<0>(it.P, it.W, round, blk, nblk, s_w, s_feat);
+      else if (mode == 1) ngp_shade_body<1>(it.P, it.W, round, blk, nblk, s_w, s_feat);
+      else ngp_shade_body<2>(it.P, it.W, round, blk, nblk, s_w, s_feat);
+      break;
+    default: break;
+  }
 }
-template <bool FROM_INIT, int PN>
-__global__ __launch_bounds__(256) void ngp_compact_march_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  ngp_compact_march_body<FROM_INIT, PN>(P, Wk, round);
+#define PXT_NGP_STAGE_PROLOGUE                                                              \
+  __shared__ half8 s_w[kNumFrags * 64];                                                     \
+  __shared__ unsigned s_feat[4 * 8 * 64];                                                   \
+  const int chunk = blockIdx.x >> 3;                                                        \
+  const int slot = chunk % st.n_slots;                                                      \
+  const int pipe = st.slot_pipe[slot];                                                      \
+  const int m = st.mult[pipe];                                                              \
+  const int blk = ((chunk / st.n_slots) * m + st.slot_sub[slot]) * 8 + (blockIdx.x & 7);    \
+  const int nblk = st.rows * m * 8;
+template <int MODES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_stage_kernel_v(const NgpItemsByValue<4> items,
+                                                                                                  const NgpStage st) {
+  PXT_NGP_STAGE_PROLOGUE
+  ngp_stage_impl<MODES>(ngp_kernarg_item(pipe), st.role[pipe], st.round[pipe], blk, nblk, s_w, s_feat);
 }
-template <int MODE>
-__global__ __launch_bounds__(256) void ngp_shade_kernel(const NgpParams P, const NgpWork Wk, int round) {
-  ngp_shade_body<MODE>(P, Wk, round);
-}
-template <int MODE>
-__global__ __launch_bounds__(256) void ngp_tail_kernel(const NgpParams P, const NgpWork Wk, int round, int rays_per_wg) {
-  ngp_tail_body<MODE>(P, Wk, round, rays_per_wg);
-}
-__global__ __launch_bounds__(256) void ngp_resolve_kernel(const NgpParams P, const NgpWork Wk, const NgpCounterList zl) {
-  ngp_resolve_body(P, Wk, zl);
+template <int MODES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_stage_kernel_m(
+    const NgpBatchItem* __restrict__ items, const NgpStage st) {
+  PXT_NGP_STAGE_PROLOGUE
+  ngp_stage_impl<MODES>(items[pipe], st.role[pipe], st.round[pipe], blk, nblk, s_w, s_feat);
 }
 
-template <bool FROM_INIT>
-__global__ __launch_bounds__(256) void ngp_compact_batch_kernel(const NgpBatchItem* __restrict__ items, int round) {
-  const NgpBatchItem& it = items[blockIdx.y];
-  ngp_compact_body<FROM_INIT>(it.P, it.W, round);
+// The stragglers of every pipe of the chain in one launch: blockIdx.y = pipe.  (Its own kernel: the straggler loop holds
+// the march AND the shade state of a wave, ~10 VGPRs more than the stage kernel's widest stage takes.)
+template <int MODES>
+__device__ __forceinline__ void ngp_tail_impl(const NgpBatchItem& it, int round, int rays_per_wg) {
+  __shared__ half8 s_w[kNumFrags * 64];
+  __shared__ unsigned s_feat[4 * 8 * 64];
+  const int mode = MODES == 3 ? it.P.mode : MODES;
+  if (mode == 0) ngp_tail_body<0>(it.P, it.W, round, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
+  else if (mode == 1) ngp_tail_body<1>(it.P, it.W, round, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
+  else ngp_tail_body<2>(it.P, it.W, round, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
 }
-template <bool FROM_INIT>
-__global__ __launch_bounds__(256) void ngp_compact_march_batch_kernel(const NgpBatchItem* __restrict__ items, int round) {
-  const NgpBatchItem& it = items[blockIdx.y];
-  ngp_compact_march_body<FROM_INIT, 1>(it.P, it.W, round);
+template <int MODES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_tail_kernel_v(const NgpItemsByValue<4> items,
+                                                                                                 int round, int rays_per_wg) {
+  ngp_tail_impl<MODES>(ngp_kernarg_item(blockIdx.y), round, rays_per_wg);
 }
-template <int MODE>
-__global__ __launch_bounds__(256) void ngp_shade_batch_kernel(const NgpBatchItem* __restrict__ items, int round) {
-  const NgpBatchItem& it = items[blockIdx.y];
-  ngp_shade_body<MODE>(it.P, it.W, round);
+template <int MODES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_tail_kernel_m(
+    const NgpBatchItem* __restrict__ items, int round, int rays_per_wg) {
+  ngp_tail_impl<MODES>(items[blockIdx.y], round, rays_per_wg);
 }
-template <int MODE>
-__global__ __launch_bounds__(256) void ngp_tail_batch_kernel(const NgpBatchItem* __restrict__ items, int round, int rays_per_wg) {
-  const NgpBatchItem& it = items[blockIdx.y];
-  ngp_tail_body<MODE>(it.P, it.W, round, rays_per_wg);
+
+// blockIdx.y = render (the items here are per RENDER: the whole view, the shared per-ray result buffers, every counter block)
+__global__ __launch_bounds__(256) void ngp_resolve_kernel_v(const NgpItemsByValue<4> items) {
+  const NgpBatchItem& it = ngp_kernarg_item(blockIdx.y);
+  ngp_resolve_body(it.P, it.W, it.zl, blockIdx.x);
 }
-__global__ __launch_bounds__(256) void ngp_resolve_batch_kernel(const NgpBatchItem* __restrict__ items) {
+__global__ __launch_bounds__(256) void ngp_resolve_kernel_m(const NgpBatchItem* __restrict__ items) {
   const NgpBatchItem& it = items[blockIdx.y];
-  ngp_resolve_body(it.P, it.W, it.zl);
+  ngp_resolve_body(it.P, it.W, it.zl, blockIdx.x);
 }
 
 // Network query at caller-given points (unit tests / debugging): out[n] = (logit, r, g, b).
@@ -1400,26 +1373,32 @@ __global__ __launch_bounds__(256) void ngp_query_kernel(const NgpParams P, const
 
 }  // namespace pxt
 
-struct pxt_ngp {
-  pxt_ngp_model model;
+// The read-only tables of a snapshot: shared by a context and the contexts made from it with pxt_ngp_create_shared (a frame's
+// second render - another view of the SAME NeRF - needs its own ray lists, counters and camera slot, not a second copy of
+// 30 MB of tables competing for the same caches).
+struct NgpTables {
   unsigned* grid = nullptr;
   unsigned grid_bytes = 0;
   pxt::half8* wfrag = nullptr;
   uint8_t* occ = nullptr;
+  int refs = 1;
+};
+
+struct pxt_ngp {
+  pxt_ngp_model model;
+  NgpTables* tab = nullptr;
   float* cam_dev = nullptr;  // 12 floats: the camera of a render enqueued ahead of its pose (render_both_from_pose)
   pxt::NgpLevel lv[pxt::kMaxLevels];
   // scratch of the wavefront renderer, grown on demand (rays = W*H*spp)
   void* scratch = nullptr;
   size_t scratch_rays = 0;
-  size_t scratch_cap = 0;   // rays one pipeline's buffers hold
-  int scratch_pipes = 0;    // pipelines the scratch was laid out for
-  bool counters_clean = false;  // the previous render's resolve kernel zeroed every pipeline's round counters
+  size_t scratch_cap = 0;   // rays one pipe's buffers hold
+  int scratch_pipes = 0;    // pipes the scratch was laid out for
+  bool counters_clean = false;  // the previous render's resolve kernel zeroed every pipe's round counters
   static constexpr int kMaxPipes = 4;
-  pxt::NgpWork work[kMaxPipes];            // independent pipelines over equal slices of the rays
-  hipStream_t side[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};  // streams of pipelines 1..
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr};
-  int pipelines = 0;     // 0: default (PXT_NGP_PIPES or 2); else the number of ray slices rendered side by side
-  int timing = 0;        // > 0: HIP events around the encode launches of every timing-th render
+  pxt::NgpWork work[kMaxPipes];            // independent pipes over equal slices of the rays
+  int pipelines = 0;     // 0: default (PXT_NGP_PIPES or 2); else the number of ray slices a large render is cut into
+  int timing = 0;        // > 0: HIP events around the shade-carrying launches of every timing-th render
   long long renders = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // recorded, not yet read
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;    // created once, reused
@@ -1451,6 +1430,25 @@ void pack_layer(const uint16_t* W, int n_out, int n_in, int kind, int frag0, std
           const uint16_t v = (row < n_out) ? W[(size_t)row * n_in + col] : (uint16_t)0;
           dst[((size_t)(frag0 + rb * n_q + q) * 64 + lane) * 8 + j] = v;
         }
+}
+
+void release_tables(NgpTables* t) {
+  if (!t || --t->refs > 0) return;
+  if (t->grid) (void)hipFree(t->grid);
+  if (t->wfrag) (void)hipFree(t->wfrag);
+  if (t->occ) (void)hipFree(t->occ);
+  delete t;
+}
+
+// A context's camera slot holds a valid camera from the start: a render queued with camera_from_slot behind a refinement
+// that failed (the LM epilogue then leaves the slot alone, pxt_lm.hip) must march SOMETHING well defined - its frame is
+// dropped afterwards, but its kernels run.
+int init_camera_slot(pxt_ngp* ctx) {
+  const float cam0[16] = {1.f, 0.f, 0.f, 0.5f, 0.f, 1.f, 0.f, 0.5f, 0.f, 0.f, 1.f, -1.f, 0.f, 0.f, 0.f, 0.f};
+  hipError_t e = hipMalloc((void**)&ctx->cam_dev, sizeof(cam0));
+  if (e == hipSuccess) e = hipMemcpy(ctx->cam_dev, cam0, sizeof(cam0), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_last_error("pxt_ngp camera slot", e); return PXT_E_HIP; }
+  return PXT_OK;
 }
 
 }  // namespace
@@ -1491,44 +1489,54 @@ extern "C" int pxt_ngp_create(const pxt_ngp_model* model, const void* grid_param
   pack_layer(mp + 3072, 64, 32, 2, kFragC1, frag);
   pack_layer(mp + 5120, 64, 64, 1, kFragC2, frag);
   pack_layer(mp + 9216, 16, 64, 1, kFragC3, frag);
-  ctx->grid_bytes = (unsigned)((size_t)off * 4);
-  hipError_t e = hipMalloc((void**)&ctx->grid, (size_t)off * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->wfrag, frag.size() * 2);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->occ, (size_t)n_occ_bytes);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->cam_dev, 16 * sizeof(float));
-  if (e == hipSuccess) e = hipMemcpy(ctx->grid, grid_params, (size_t)off * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(ctx->wfrag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(ctx->occ, occupancy, (size_t)n_occ_bytes, hipMemcpyHostToDevice);
+  NgpTables* t = ctx->tab = new NgpTables();
+  t->grid_bytes = (unsigned)((size_t)off * 4);
+  hipError_t e = hipMalloc((void**)&t->grid, (size_t)off * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->wfrag, frag.size() * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->occ, (size_t)n_occ_bytes);
+  if (e == hipSuccess) e = hipMemcpy(t->grid, grid_params, (size_t)off * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->wfrag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->occ, occupancy, (size_t)n_occ_bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     set_last_error("pxt_ngp_create", e);
     pxt_ngp_destroy(ctx);
     return PXT_E_HIP;
   }
+  if (const int rc = init_camera_slot(ctx)) { pxt_ngp_destroy(ctx); return rc; }
+  *out_ctx = ctx;
+  return PXT_OK;
+}
+
+extern "C" int pxt_ngp_create_shared(pxt_ngp* src, pxt_ngp** out_ctx) {
+  if (!src || !src->tab || !out_ctx) return PXT_E_ARG;
+  pxt_ngp* ctx = new pxt_ngp();
+  ctx->model = src->model;
+  for (int l = 0; l < kMaxLevels; ++l) ctx->lv[l] = src->lv[l];
+  ctx->tab = src->tab;
+  ++ctx->tab->refs;
+  ctx->pipelines = src->pipelines;
+  if (const int rc = init_camera_slot(ctx)) { pxt_ngp_destroy(ctx); return rc; }
   *out_ctx = ctx;
   return PXT_OK;
 }
 
 extern "C" int pxt_ngp_destroy(pxt_ngp* ctx) {
   if (!ctx) return PXT_E_ARG;
-  if (ctx->grid) (void)hipFree(ctx->grid);
-  if (ctx->wfrag) (void)hipFree(ctx->wfrag);
-  if (ctx->occ) (void)hipFree(ctx->occ);
+  release_tables(ctx->tab);
   if (ctx->cam_dev) (void)hipFree(ctx->cam_dev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
-  for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
-    if (ctx->ev_join[w]) (void)hipEventDestroy(ctx->ev_join[w]);
-  }
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& ev : ctx->pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   delete ctx;
   return PXT_OK;
 }
 
 static void fill_model(const pxt_ngp* ctx, NgpParams& P) {
   std::memset(&P, 0, sizeof(P));
-  P.grid = ctx->grid;
-  P.grid_bytes = ctx->grid_bytes;
-  P.wfrag = ctx->wfrag;
-  P.occ = ctx->occ;
+  P.grid = ctx->tab->grid;
+  P.grid_bytes = ctx->tab->grid_bytes;
+  P.wfrag = ctx->tab->wfrag;
+  P.occ = ctx->tab->occ;
   for (int l = 0; l < kMaxLevels; ++l) P.lv[l] = ctx->lv[l < ctx->model.n_levels ? l : 0];
   P.n_levels = ctx->model.n_levels;
   P.cascades = ctx->model.grid_cascades;
@@ -1551,19 +1559,15 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
   return PXT_OK;
 }
 
-// Carves the wavefront scratch for `rays` rays out of one allocation (grown on demand).
-// Scratch for a render of `rays` enumerated rays.  Per-pipeline buffers (live-ray state, samples,
-// features) are sized for half the rays each; the per-ray result buffers indexed by ray id
-// (finished passes, direction records) are shared.
-// Per-pipeline buffers hold the pipeline's whole slice of the rays (every ray of a slice may hit the box): `cap` =
-// the largest slice.  (The first version sized them for half the rays whatever the number of pipelines: a
-// one-pipeline render - any render below 2^19 rays - whose camera sees the box in more than half of its pixels
-// wrote past them.)
-static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe, size_t min_cap = 0) {
-  size_t cap = std::max(min_cap, (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile);
+// Carves the wavefront scratch for `rays` rays out of one allocation (grown on demand).  Per-pipe buffers (live-ray state,
+// samples) hold the pipe's whole slice of the rays (every ray of a slice may hit the box): `cap` = the largest slice; the
+// per-ray result buffers indexed by ray id (finished passes, direction records) are shared by the pipes of the render.
+// (The first version sized the per-pipe buffers for half the rays whatever the number of pipes: a one-pipe render - any
+// render below 2^19 rays - whose camera sees the box in more than half of its pixels wrote past them.)
+static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
+  size_t cap = (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile;
   if (ctx->scratch && ctx->scratch_rays >= rays && ctx->scratch_cap >= cap && ctx->scratch_pipes >= n_pipe) return PXT_OK;
-  // grow only: a context that alternates between pipeline counts (bench: the isolated one-pipeline pass) keeps
-  // the larger layout
+  // grow only: a context that alternates between pipe counts (bench: the isolated one-pipe pass) keeps the larger layout
   cap = std::max(cap, ctx->scratch_cap);
   n_pipe = std::max(n_pipe, ctx->scratch_pipes);
   rays = std::max(rays, ctx->scratch_rays);
@@ -1619,37 +1623,6 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe, size_t min_cap 
   return PXT_OK;
 }
 
-// Lattice points a marching lane probes per trip (ngp_march_lane): PXT_NGP_PROBE = 1 / 2 / 4 / 8.  Default 1: probing
-// ahead is bit-exact and cuts a lane's dependent occupancy loads to a PN-th, but the march launches do not get shorter
-// (round 4, rocprofv3 kernel trace of bench.py: compact+march 38.7 / 55.4 us at PN = 1, 42.0 / 54.6 us at PN = 4; the
-// compaction-only kernel, which marches nothing, takes 23.7 us) - what these launches wait for is a CU slot beside the
-// other pipeline's shade workgroups, not their own rays (profiles/r04_experiments.md #15).
-static int march_probe() {
-  static const int pn = [] {
-    const char* e = getenv("PXT_NGP_PROBE");
-    const int v = e ? atoi(e) : 1;
-    return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 1;
-  }();
-  return pn;
-}
-template <bool FROM_INIT>
-static void launch_compact_march(int grid, hipStream_t st, const NgpParams& P, const NgpWork& W, int round) {
-  switch (march_probe()) {
-    case 1: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 1>), dim3(grid), dim3(256), 0, st, P, W, round); break;
-    case 2: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 2>), dim3(grid), dim3(256), 0, st, P, W, round); break;
-    case 8: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 8>), dim3(grid), dim3(256), 0, st, P, W, round); break;
-    default: hipLaunchKernelGGL((ngp_compact_march_kernel<FROM_INIT, 4>), dim3(grid), dim3(256), 0, st, P, W, round); break;
-  }
-}
-static void launch_march(int grid, hipStream_t st, const NgpParams& P, const NgpWork& W, int round) {
-  switch (march_probe()) {
-    case 1: hipLaunchKernelGGL(ngp_march_kernel<1>, dim3(grid), dim3(256), 0, st, P, W, round); break;
-    case 2: hipLaunchKernelGGL(ngp_march_kernel<2>, dim3(grid), dim3(256), 0, st, P, W, round); break;
-    case 8: hipLaunchKernelGGL(ngp_march_kernel<8>, dim3(grid), dim3(256), 0, st, P, W, round); break;
-    default: hipLaunchKernelGGL(ngp_march_kernel<4>, dim3(grid), dim3(256), 0, st, P, W, round); break;
-  }
-}
-
 // The view part of a render's parameter record (everything but the device-side camera source), with the argument checks.
 static int fill_view(const pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth, uint64_t* stats,
                      uint8_t* out_u8, uint8_t* out_nz, NgpParams& P, size_t& rays) {
@@ -1678,137 +1651,275 @@ static int fill_view(const pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float*
   return PXT_OK;
 }
 
+// ---- the staged chain (see ngp_stage_kernel): host side.
+namespace {
+
+struct ChainRender {
+  pxt_ngp* ctx;
+  NgpParams P;   // the whole view
+  size_t rays;
+};
+
+int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  return e ? std::min(std::max(atoi(e), lo), hi) : dflt;
+}
+
+// Workgroups per pipe and stage, wavefront rounds before the straggler stage.  One render / a frame's pair: the grids the
+// single launches had per pipeline (grid-stride kernels: full grids measured best, rounds 3-5).  K >= 3 objects in
+// lock-step: a launch's first object would fill the chip alone with those (profiles/r05_experiments.md #16: 512 / 1024 per
+// object measured best of 128 ... 2048) - per half-object pipe half of that - and six rounds (a round of the chain is one
+// launch for all objects, and the config/*.sh objects keep more rays alive than the benchmark object).
+struct ChainTune {
+  int g_init, g_march, g_shade, g_compact, g_tail, tail_div, n_rounds;
+};
+ChainTune chain_tune(int n_renders, int pipes_per_render) {
+  static const int e_init = env_int("PXT_NGP_G_INIT", 0, 0, 8192), e_march = env_int("PXT_NGP_G_MARCH", 0, 0, 8192),
+                   e_shade = env_int("PXT_NGP_G_SHADE", 0, 0, 8192), e_compact = env_int("PXT_NGP_G_COMPACT", 0, 0, 8192),
+                   e_tail = env_int("PXT_NGP_TAIL_GRID", 0, 0, 8192), e_div = env_int("PXT_NGP_TAIL_DIV", 64, 1, 1 << 20),
+                   e_rounds = env_int("PXT_NGP_ROUNDS", -1, -1, kMaxRounds),
+                   e_brounds = env_int("PXT_NGP_BATCH_ROUNDS", -1, -1, kMaxRounds);
+  ChainTune t;
+  if (n_renders <= 2) {
+    t = {4096, 2048, 2048, 1024, 1024, e_div, e_rounds >= 0 ? e_rounds : kRounds};
+  } else {
+    const int d = pipes_per_render > 1 ? 2 : 1;
+    t = {1024 / d, 512 / d, 1024 / d, 1024 / d, 1024 / d, e_div, e_brounds >= 0 ? e_brounds : (e_rounds >= 0 ? e_rounds : kBatchRounds)};
+  }
+  if (e_init) t.g_init = e_init;
+  if (e_march) t.g_march = e_march;
+  if (e_shade) t.g_shade = e_shade;
+  if (e_compact) t.g_compact = e_compact;
+  if (e_tail) t.g_tail = e_tail;
+  return t;
+}
+
+struct NgpStageSlot {
+  NgpBatchItem* host = nullptr;
+  hipEvent_t copied = nullptr;
+};
+constexpr int kNgpStageSlots = 4;
+constexpr int kChainItems = kMaxChainPipes + PXT_NGP_MAX_BATCH;  // pipe records, then one record per render (resolve)
+
+// (items: by value when `pv` is given, else the device records `pm`)
+void launch_stage(int modes, const NgpItemsByValue<4>* pv, const NgpBatchItem* pm, const NgpStage& st, hipStream_t s) {
+  const dim3 grid(st.n_slots * st.rows * 8), blk(256);
+#define PXT_LAUNCH_STAGE(M)                                                                  \
+  if (pv) hipLaunchKernelGGL(ngp_stage_kernel_v<M>, grid, blk, 0, s, *pv, st);               \
+  else hipLaunchKernelGGL(ngp_stage_kernel_m<M>, grid, blk, 0, s, pm, st);
+  switch (modes) {
+    case 0: PXT_LAUNCH_STAGE(0) break;
+    case 1: PXT_LAUNCH_STAGE(1) break;
+    case 2: PXT_LAUNCH_STAGE(2) break;
+    default: PXT_LAUNCH_STAGE(3) break;
+  }
+#undef PXT_LAUNCH_STAGE
+}
+void launch_tail(int modes, const NgpItemsByValue<4>* pv, const NgpBatchItem* pm, dim3 grid, int round, int rays_per_wg,
+                 hipStream_t s) {
+  const dim3 blk(256);
+#define PXT_LAUNCH_TAIL(M)                                                                               \
+  if (pv) hipLaunchKernelGGL(ngp_tail_kernel_v<M>, grid, blk, 0, s, *pv, round, rays_per_wg);            \
+  else hipLaunchKernelGGL(ngp_tail_kernel_m<M>, grid, blk, 0, s, pm, round, rays_per_wg);
+  switch (modes) {
+    case 0: PXT_LAUNCH_TAIL(0) break;
+    case 1: PXT_LAUNCH_TAIL(1) break;
+    case 2: PXT_LAUNCH_TAIL(2) break;
+    default: PXT_LAUNCH_TAIL(3) break;
+  }
+#undef PXT_LAUNCH_TAIL
+}
+
+// The stage of a pipe `step` launches after its first: generate + march, then per round shade and compaction (+ the next
+// round's march), the stragglers last.  (n_rounds = 0: generate + compact, then the straggler stage does the whole render.)
+void stage_of(int step, int n_rounds, unsigned char& role, unsigned char& round) {
+  role = kRoleIdle;
+  round = 0;
+  if (step < 0) return;
+  if (step == 0) { role = n_rounds > 0 ? kRoleInitMarch : kRoleInitCompact; return; }
+  const int r = (step - 1) >> 1;
+  if (r >= n_rounds) return;
+  round = (unsigned char)r;
+  if ((step - 1) & 1) role = (r + 1 < n_rounds) ? kRoleCompactMarch : kRoleCompact;
+  else role = kRoleShade;
+}
+
+// The chain for K renders on stream s0.  ws_dev: device memory for the parameter records when they do not fit the
+// kernel-argument segment (more than 4 pipes), else unused.
+int run_chain(ChainRender* R, int K, hipStream_t s0, void* ws_dev) {
+  static const int env_pipes = env_int("PXT_NGP_PIPES", 2, 1, pxt_ngp::kMaxPipes);
+  static const int env_batch_pipes = env_int("PXT_NGP_BATCH_PIPES", 2, 1, 2);
+  static const int env_skew = env_int("PXT_NGP_SKEW", 1, 0, 1);
+  struct Pipe { int render, w, phase; };
+  Pipe pipes[kMaxChainPipes];
+  int n_pipes = 0, n_per[PXT_NGP_MAX_BATCH];
+  for (int k = 0; k < K; ++k) {
+    pxt_ngp* ctx = R[k].ctx;
+    const int want = K <= 2 ? (ctx->pipelines > 0 ? ctx->pipelines : env_pipes) : env_batch_pipes;
+    n_per[k] = R[k].rays >= ((size_t)1 << 19) ? std::min(std::max(want, 1), pxt_ngp::kMaxPipes) : 1;
+    if (n_pipes + n_per[k] > kMaxChainPipes) return PXT_E_ARG;
+    if (const int rc = ensure_scratch(ctx, R[k].rays, n_per[k])) return rc;
+    for (int w = 0; w < n_per[k]; ++w, ++n_pipes) pipes[n_pipes] = {k, w, env_skew ? (n_pipes & 1) : 0};
+  }
+  const bool by_value = n_pipes <= 4;
+  if (!by_value && !ws_dev) return PXT_E_ARG;
+  // the records
+  static thread_local NgpStageSlot stage[16][kNgpStageSlots];
+  static thread_local int stage_next[16] = {0};
+  NgpItemsByValue<4> pv{}, rv{};  // (by_value: pipes / renders)
+  NgpBatchItem* rec = nullptr;  // (!by_value: the pinned staging block, pipes then renders)
+  NgpStageSlot* slot = nullptr;
+  if (!by_value) {
+    int dev_id = 0;
+    PXT_HIP_CHECK(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 16) return PXT_E_ARG;
+    slot = &stage[dev_id][stage_next[dev_id]];
+    stage_next[dev_id] = (stage_next[dev_id] + 1) % kNgpStageSlots;
+    if (!slot->host) {
+      PXT_HIP_CHECK(hipHostMalloc((void**)&slot->host, kChainItems * sizeof(NgpBatchItem), hipHostMallocDefault));
+      PXT_HIP_CHECK(hipEventCreateWithFlags(&slot->copied, hipEventDisableTiming));
+    } else {
+      PXT_HIP_CHECK(hipEventSynchronize(slot->copied));
+    }
+    rec = slot->host;
+  }
+  int modes = R[0].P.mode, max_pixels = 0;
+  for (int k = 0; k < K; ++k) {
+    pxt_ngp* ctx = R[k].ctx;
+    if (R[k].P.mode != modes) modes = 3;
+    max_pixels = std::max(max_pixels, R[k].P.W * R[k].P.H);
+    NgpBatchItem& ri = by_value ? rv.it[k] : rec[n_pipes + k];
+    ri.P = R[k].P;
+    ri.P.enum_lo = 0;
+    ri.P.enum_hi = (long long)R[k].rays;
+    ri.W = ctx->work[0];
+    ri.zl.n = std::min(ctx->scratch_pipes, 4);
+    for (int w = 0; w < 4; ++w) ri.zl.p[w] = w < ri.zl.n ? ctx->work[w].counters : nullptr;
+    if (!ctx->counters_clean)
+      for (int w = 0; w < ctx->scratch_pipes; ++w)
+        PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), s0));
+    ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
+  }
+  for (int p = 0; p < n_pipes; ++p) {
+    const int k = pipes[p].render, w = pipes[p].w, np = n_per[k];
+    NgpBatchItem& it = by_value ? pv.it[p] : rec[p];
+    it.P = R[k].P;
+    const long long total = (long long)R[k].rays;
+    const long long per = np > 1 ? ((total / np + kTile - 1) / kTile) * kTile : total;
+    it.P.enum_lo = std::min(total, per * w);
+    it.P.enum_hi = (w == np - 1) ? total : std::min(total, per * (w + 1));
+    it.W = R[k].ctx->work[w];
+    it.zl.n = 0;
+  }
+  const NgpBatchItem *pm = nullptr, *rm = nullptr;
+  if (!by_value) {
+    PXT_HIP_CHECK(hipMemcpyAsync(ws_dev, rec, (size_t)(n_pipes + K) * sizeof(NgpBatchItem), hipMemcpyHostToDevice, s0));
+    PXT_HIP_CHECK(hipEventRecord(slot->copied, s0));
+    pm = (const NgpBatchItem*)ws_dev;
+    rm = pm + n_pipes;
+  }
+  const ChainTune tune = chain_tune(K, n_per[0]);
+  const int n_rounds = tune.n_rounds;
+  const int max_phase = (n_pipes > 1 && env_skew) ? 1 : 0;
+  const int last_step = 2 * n_rounds;               // a pipe's last stage before the stragglers
+  const int j_end = last_step + max_phase;          // (the stragglers of every pipe follow in ONE launch: a straggler
+                                                    // workgroup lives as long as its longest ray; two launches = two waits)
+  pxt_ngp* tctx = R[0].ctx;
+  const bool timed = K == 1 && tctx->timing > 0 && (tctx->renders++ % tctx->timing) == 0;
+  for (int j = 0; j <= j_end; ++j) {
+    NgpStage st;
+    std::memset(&st, 0, sizeof(st));
+    int g_of[kMaxChainPipes], g_min = 1 << 30, n_active = 0;
+    bool has_shade = false;
+    for (int p = 0; p < n_pipes; ++p) {
+      unsigned char role, round;
+      stage_of(j - pipes[p].phase, n_rounds, role, round);
+      st.role[p] = role;
+      st.round[p] = round;
+      g_of[p] = 0;
+      if (role == kRoleIdle) continue;
+      g_of[p] = role == kRoleInitMarch ? tune.g_init : role == kRoleCompactMarch ? tune.g_march : role == kRoleShade ? tune.g_shade
+                                                                                                                   : tune.g_compact;
+      g_of[p] = std::max(g_of[p], 64);
+      g_min = std::min(g_min, g_of[p]);
+      has_shade = has_shade || role == kRoleShade;
+      ++n_active;
+    }
+    if (!n_active) continue;
+    // slots: a pipe of g workgroups owns m = g / unit of them; unit = the smallest grid of the launch (doubled until the
+    // table holds the slots), the slots of the pipes interleaved in proportion (march-like stages first on ties: their
+    // workgroups are the short ones and should be resident from the start)
+    int unit = std::max(8, g_min / 8 * 8);
+    for (;;) {
+      int tot = 0;
+      for (int p = 0; p < n_pipes; ++p) tot += g_of[p] ? std::max(1, g_of[p] / unit) : 0;
+      if (tot <= kMaxSlots) break;
+      unit *= 2;
+    }
+    st.rows = unit / 8;
+    struct Ent { float pos; int prio, pipe, sub; } ent[kMaxSlots];
+    int n_slots = 0;
+    for (int p = 0; p < n_pipes; ++p) {
+      if (!g_of[p]) continue;
+      const int m = std::min(255, std::max(1, g_of[p] / unit));
+      st.mult[p] = (unsigned char)m;
+      for (int sub = 0; sub < m; ++sub)
+        ent[n_slots++] = {((float)sub + 0.5f) / (float)m, st.role[p] == kRoleShade ? 1 : 0, p, sub};
+    }
+    std::stable_sort(ent, ent + n_slots, [](const Ent& a, const Ent& b) {
+      return a.pos != b.pos ? a.pos < b.pos : a.prio < b.prio;
+    });
+    st.n_slots = n_slots;
+    for (int i = 0; i < n_slots; ++i) {
+      st.slot_pipe[i] = (unsigned char)ent[i].pipe;
+      st.slot_sub[i] = (unsigned char)ent[i].sub;
+    }
+    // the launches that carry a shade stage are the ones the timing events bracket (bench.py's roofline)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed && has_shade) {
+      if (tctx->pool.empty()) {
+        PXT_HIP_CHECK(hipEventCreate(&e0));
+        PXT_HIP_CHECK(hipEventCreate(&e1));
+      } else {
+        e0 = tctx->pool.back().first;
+        e1 = tctx->pool.back().second;
+        tctx->pool.pop_back();
+      }
+      PXT_HIP_CHECK(hipEventRecord(e0, s0));
+    }
+    launch_stage(modes, by_value ? &pv : nullptr, pm, st, s0);
+    if (e0) {
+      PXT_HIP_CHECK(hipEventRecord(e1, s0));
+      tctx->events.emplace_back(e0, e1);
+    }
+  }
+  launch_tail(modes, by_value ? &pv : nullptr, pm, dim3(tune.g_tail, n_pipes), n_rounds, tune.tail_div, s0);
+  const dim3 rgrid((max_pixels + 255) / 256, K);
+  if (by_value) hipLaunchKernelGGL(ngp_resolve_kernel_v, rgrid, dim3(256), 0, s0, rv);
+  else hipLaunchKernelGGL(ngp_resolve_kernel_m, rgrid, dim3(256), 0, s0, rm);
+  PXT_HIP_CHECK(hipGetLastError());
+  for (int k = 0; k < K; ++k) R[k].ctx->counters_clean = true;
+  return PXT_OK;
+}
+
+}  // namespace
+
 static int render_impl(pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float* out_rgba, float* out_depth,
                        uint64_t* stats, void* stream, const float* pose_src = nullptr, const PoseConv* conv = nullptr,
                        float* cam_out = nullptr, uint8_t* out_u8 = nullptr, uint8_t* out_nz = nullptr,
                        bool camera_from_slot = false) {
-  NgpParams P;
-  size_t rays = 0;
-  if (const int rcv = fill_view(ctx, v, mode, out_rgba, out_depth, stats, out_u8, out_nz, P, rays)) return rcv;
+  ChainRender R;
+  R.ctx = ctx;
+  if (const int rcv = fill_view(ctx, v, mode, out_rgba, out_depth, stats, out_u8, out_nz, R.P, R.rays)) return rcv;
   if (pose_src) {  // the camera is derived on the device, in stream order, from a pose record the host has not seen
     if (!conv) return PXT_E_ARG;
     hipLaunchKernelGGL(ngp_pose_to_camera_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pose_src, *conv, ctx->cam_dev,
                        cam_out);
-    P.cam_dev = ctx->cam_dev;
+    R.P.cam_dev = ctx->cam_dev;
   } else if (camera_from_slot) {  // written by an earlier kernel of this stream (the LM kernel's epilogue)
-    P.cam_dev = ctx->cam_dev;
+    R.P.cam_dev = ctx->cam_dev;
   }
-  hipStream_t s0 = (hipStream_t)stream;
-
-  // Two pipelines over the two halves of the ray enumeration, on the caller's stream and on a
-  // side stream.  Every ray is processed exactly as before (its result does not depend on which
-  // rays share its launches), but the chains overlap: the VALU-bound march of one half runs
-  // beside the L1-bound encode or the MFMA-bound shade of the other, and one half's launch
-  // tails are filled by the other's workgroups.  Small renders keep one pipeline.
-  static const int env_pipes = [] { const char* e = getenv("PXT_NGP_PIPES"); return e ? atoi(e) : 2; }();
-  const int want_pipes = ctx->pipelines > 0 ? ctx->pipelines : env_pipes;
-  const int n_pipe = rays >= ((size_t)1 << 19) ? std::min(std::max(want_pipes, 1), pxt_ngp::kMaxPipes) : 1;
-  // PXT_NGP_SPLIT = percent of the rays the FIRST of two pipelines takes (default 50; experiment: the side stream's
-  // chain starts a fork event later and trails the caller's by 20-50 us per stage - does a larger first slice even
-  // them out?  Measured in round 4: profiles/r04_experiments.md)
-  static const int split_pct = [] { const char* e = getenv("PXT_NGP_SPLIT"); return e ? std::min(std::max(atoi(e), 10), 90) : 50; }();
-  int rc = ensure_scratch(ctx, rays, n_pipe,
-                          (n_pipe == 2 && split_pct != 50) ? rays * (size_t)std::max(split_pct, 100 - split_pct) / 100 + 3 * kTile : 0);
-  if (rc != PXT_OK) return rc;
-  if (n_pipe > 1 && !ctx->ev_fork) {
-    PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    for (int w = 1; w < pxt_ngp::kMaxPipes; ++w) {
-      ctx->side[w] = pxt::shared_side_stream(w - 1);  // shared by all contexts of the device (pxt_core.hip)
-      if (!ctx->side[w]) return PXT_E_HIP;
-      PXT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join[w], hipEventDisableTiming));
-    }
-  }
-  hipStream_t st[pxt_ngp::kMaxPipes];
-  NgpParams Pp[pxt_ngp::kMaxPipes];
-  const long long total = (long long)rays;
-  const long long per = n_pipe > 1 ? ((total / n_pipe + kTile - 1) / kTile) * kTile : total;
-  const long long first = (n_pipe == 2 && split_pct != 50) ? ((total * split_pct / 100 + kTile - 1) / kTile) * kTile : per;
-  for (int w = 0; w < n_pipe; ++w) {
-    st[w] = w == 0 ? s0 : ctx->side[w];
-    Pp[w] = P;
-    Pp[w].enum_lo = w == 0 ? 0 : std::min(total, n_pipe == 2 ? first : per * w);
-    Pp[w].enum_hi = (w == n_pipe - 1) ? total : std::min(total, n_pipe == 2 ? first : per * (w + 1));
-  }
-  if (n_pipe > 1) {
-    PXT_HIP_CHECK(hipEventRecord(ctx->ev_fork, s0));  // the side streams start after the caller's earlier work
-    for (int w = 1; w < n_pipe; ++w) PXT_HIP_CHECK(hipStreamWaitEvent(ctx->side[w], ctx->ev_fork, 0));
-  }
-  const int wide = 2048, cmp_grid = 1024;  // grid-stride kernels: full grids measured best
-  constexpr int shade_grid = 2048;  // (1024 / 1536 / 3072 / 4096 measured in round 3: 2048 best; no knob)
-  static const bool fuse_cm = [] { const char* e = getenv("PXT_NGP_FUSE_COMPACT_MARCH"); return e ? atoi(e) != 0 : true; }();
-  // (ray generation fused with the first march as well: no gain beside the level-major encoder, 0.716 -> 0.709 ms
-  // per render / 614 -> 624 frames/s with the fused shade kernel; PXT_NGP_FUSE_INIT=0 keeps the two launches.)
-  static const bool fuse_init = [] { const char* e = getenv("PXT_NGP_FUSE_INIT"); return e ? atoi(e) != 0 : true; }();
-  static const int n_rounds = [] { const char* e = getenv("PXT_NGP_ROUNDS"); return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kRounds; }();
-  static const int tail_grid = [] { const char* e = getenv("PXT_NGP_TAIL_GRID"); return e ? atoi(e) : 1024; }();
-  static const int tail_div = [] { const char* e = getenv("PXT_NGP_TAIL_DIV"); return e ? std::max(atoi(e), 1) : 64; }();
-  const bool counters_clean = ctx->counters_clean;
-  ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
-  for (int w = 0; w < n_pipe; ++w) {
-    if (!counters_clean)
-      PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), st[w]));
-    if (fuse_init && n_rounds > 0)  // ray generation + compaction + the first march
-      launch_compact_march<true>(2 * wide, st[w], Pp[w], ctx->work[w], 0);
-    else
-      hipLaunchKernelGGL(ngp_compact_kernel<true>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], 0);
-  }
-  const bool timed = ctx->timing > 0 && (ctx->renders++ % ctx->timing) == 0;
-  for (int r = 0; r < n_rounds; ++r) {
-    if ((r == 0 && !fuse_init) || (r > 0 && !fuse_cm))
-      for (int w = 0; w < n_pipe; ++w)
-        launch_march(wide, st[w], Pp[w], ctx->work[w], r);
-    // the round's shade kernel (gathers + MLPs + compositing) is the one the timing events bracket (bench.py's roofline)
-    for (int w = 0; w < n_pipe; ++w) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (timed) {
-        if (ctx->pool.empty()) {
-          PXT_HIP_CHECK(hipEventCreate(&e0));
-          PXT_HIP_CHECK(hipEventCreate(&e1));
-        } else {
-          e0 = ctx->pool.back().first;
-          e1 = ctx->pool.back().second;
-          ctx->pool.pop_back();
-        }
-        PXT_HIP_CHECK(hipEventRecord(e0, st[w]));
-      }
-      if (mode == 1) {
-        hipLaunchKernelGGL(ngp_shade_kernel<1>, dim3(shade_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-      } else if (mode == 2) {
-        hipLaunchKernelGGL(ngp_shade_kernel<2>, dim3(shade_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-      } else {
-        hipLaunchKernelGGL(ngp_shade_kernel<0>, dim3(shade_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-      }
-      if (timed) {
-        PXT_HIP_CHECK(hipEventRecord(e1, st[w]));
-        ctx->events.emplace_back(e0, e1);
-      }
-    }
-    for (int w = 0; w < n_pipe; ++w) {
-      if (fuse_cm && r + 1 < n_rounds)  // compaction of round r + march of round r + 1 in one launch
-        launch_compact_march<false>(wide, st[w], Pp[w], ctx->work[w], r);
-      else
-        hipLaunchKernelGGL(ngp_compact_kernel<false>, dim3(cmp_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], r);
-    }
-  }
-  for (int w = 0; w < n_pipe; ++w) {
-    if (mode == 1)
-      hipLaunchKernelGGL(ngp_tail_kernel<1>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds, tail_div);
-    else if (mode == 2)
-      hipLaunchKernelGGL(ngp_tail_kernel<2>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds, tail_div);
-    else
-      hipLaunchKernelGGL(ngp_tail_kernel<0>, dim3(tail_grid), dim3(256), 0, st[w], Pp[w], ctx->work[w], n_rounds, tail_div);
-  }
-  for (int w = 1; w < n_pipe; ++w) {
-    PXT_HIP_CHECK(hipEventRecord(ctx->ev_join[w], ctx->side[w]));
-    PXT_HIP_CHECK(hipStreamWaitEvent(s0, ctx->ev_join[w], 0));
-  }
-  NgpCounterList zl;
-  zl.n = std::min(ctx->scratch_pipes, 4);
-  for (int w = 0; w < 4; ++w) zl.p[w] = w < zl.n ? ctx->work[w].counters : nullptr;
-  hipLaunchKernelGGL(ngp_resolve_kernel, dim3((v->width * v->height + 255) / 256), dim3(256), 0, s0, P, ctx->work[0], zl);
-  PXT_HIP_CHECK(hipGetLastError());
-  ctx->counters_clean = true;
-  return PXT_OK;
+  return run_chain(&R, 1, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* v, float* out_rgba, uint64_t* stats,
@@ -1843,120 +1954,33 @@ extern "C" int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* v, int32_t
                      out->depth_nz, camera_from_slot != 0);
 }
 
-// ---- K renders in ONE chain of launches (K objects tracked in lock-step).
-// A render is a chain of ~12 launches whose late rounds hold few rays: alone on a stream each launch pays its ramp and its
-// tail.  Here blockIdx.y picks the object - own renderer context (hash table, MLPs, occupancy), own view, own ray lists,
-// own outputs - so a launch carries the rays of all K objects and one object's tail is the next one's ramp.  One pipeline
-// per object (the other objects provide the concurrency the two half-renders of a single render give each other).
-// Results are bit for bit the single renders': no ray's result depends on which rays share its launches.
-namespace {
-struct NgpStageSlot {
-  NgpBatchItem* host = nullptr;
-  hipEvent_t copied = nullptr;
-};
-constexpr int kNgpStageSlots = 4;
-}  // namespace
-
 extern "C" int64_t pxt_ngp_batch_workspace_bytes(int32_t n_renders) {
   if (n_renders < 1 || n_renders > PXT_NGP_MAX_BATCH) return PXT_E_ARG;
-  return (int64_t)((size_t)n_renders * sizeof(NgpBatchItem) + 255) / 256 * 256;
+  return (int64_t)((size_t)3 * n_renders * sizeof(NgpBatchItem) + 255) / 256 * 256;  // <= 2 pipes + 1 resolve record each
 }
 
-extern "C" int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views, int32_t n_renders, int32_t mode,
-                                          int32_t camera_from_slot, const pxt_ngp_outputs* outs, uint64_t* const* stats,
-                                          void* batch_workspace, void* stream) {
-  if (!ctxs || !views || !outs || !batch_workspace || mode < 0 || mode > 2) return PXT_E_ARG;
+// K renders of K contexts - a frame's Depth + Shade pair, or K objects tracked in lock-step - as ONE staged chain.
+extern "C" int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views, int32_t n_renders,
+                                          const int32_t* modes, int32_t camera_from_slot, const pxt_ngp_outputs* outs,
+                                          uint64_t* const* stats, void* batch_workspace, void* stream) {
+  if (!ctxs || !views || !outs || !modes) return PXT_E_ARG;
   if (n_renders < 1 || n_renders > PXT_NGP_MAX_BATCH) return PXT_E_ARG;
+  if (n_renders > 2 && !batch_workspace) return PXT_E_ARG;
   const int K = n_renders;
   for (int a = 0; a < K; ++a) {
-    if (!ctxs[a]) return PXT_E_ARG;
+    if (!ctxs[a] || modes[a] < 0 || modes[a] > 2) return PXT_E_ARG;
     for (int b = a + 1; b < K; ++b)  // a context owns ONE set of ray lists
       if (ctxs[a] == ctxs[b]) return PXT_E_ARG;
   }
-  static thread_local NgpStageSlot stage[16][kNgpStageSlots];
-  static thread_local int stage_next[16] = {0};
-  int dev_id = 0;
-  PXT_HIP_CHECK(hipGetDevice(&dev_id));
-  if (dev_id < 0 || dev_id >= 16) return PXT_E_ARG;
-  NgpStageSlot& slot = stage[dev_id][stage_next[dev_id]];
-  stage_next[dev_id] = (stage_next[dev_id] + 1) % kNgpStageSlots;
-  if (!slot.host) {
-    PXT_HIP_CHECK(hipHostMalloc((void**)&slot.host, PXT_NGP_MAX_BATCH * sizeof(NgpBatchItem), hipHostMallocDefault));
-    PXT_HIP_CHECK(hipEventCreateWithFlags(&slot.copied, hipEventDisableTiming));
-  } else {
-    PXT_HIP_CHECK(hipEventSynchronize(slot.copied));
-  }
-  hipStream_t s0 = (hipStream_t)stream;
-  int max_pixels = 0;
+  ChainRender R[PXT_NGP_MAX_BATCH];
   for (int k = 0; k < K; ++k) {
-    pxt_ngp* ctx = ctxs[k];
-    NgpBatchItem& it = slot.host[k];
-    size_t rays = 0;
-    if (const int rcv = fill_view(ctx, &views[k], mode, outs[k].rgba, outs[k].depth_rgba, stats ? stats[k] : nullptr,
-                                  outs[k].rgb_u8, outs[k].depth_nz, it.P, rays))
+    R[k].ctx = ctxs[k];
+    if (const int rcv = fill_view(ctxs[k], &views[k], modes[k], outs[k].rgba, outs[k].depth_rgba, stats ? stats[k] : nullptr,
+                                  outs[k].rgb_u8, outs[k].depth_nz, R[k].P, R[k].rays))
       return rcv;
-    if (camera_from_slot) it.P.cam_dev = ctx->cam_dev;
-    if (const int rc = ensure_scratch(ctx, rays, 1)) return rc;
-    it.P.enum_lo = 0;
-    it.P.enum_hi = (long long)rays;
-    it.W = ctx->work[0];
-    it.zl.n = std::min(ctx->scratch_pipes, 4);
-    for (int w = 0; w < 4; ++w) it.zl.p[w] = w < it.zl.n ? ctx->work[w].counters : nullptr;
-    max_pixels = std::max(max_pixels, views[k].width * views[k].height);
-    if (!ctx->counters_clean)
-      PXT_HIP_CHECK(hipMemsetAsync(ctx->work[0].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), s0));
-    ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
+    if (camera_from_slot) R[k].P.cam_dev = ctxs[k]->cam_dev;
   }
-  PXT_HIP_CHECK(hipMemcpyAsync(batch_workspace, slot.host, (size_t)K * sizeof(NgpBatchItem), hipMemcpyHostToDevice, s0));
-  PXT_HIP_CHECK(hipEventRecord(slot.copied, s0));
-  const NgpBatchItem* items = (const NgpBatchItem*)batch_workspace;
-  // Grid-stride kernels over device-side counts, gridDim.y = K.  Per object a QUARTER of the single render's march grid and
-  // half of its shade grid: with the single render's grids (2048 each) a launch's first object fills the chip alone and the
-  // chain loses to K single renders; measured on the eight config/*.sh objects in two lock-step groups of four
-  // (bench.py --config objects8, same box, frames/s; single renders 1026-1030): march / shade grid 2048 / 2048 945-993,
-  // 2048 / 512 1001, 1024 / 1024 1029, 1024 / 512 1025, 768 / 768 1038, 512 / 512 1043-1047, 512 / 1024 1048, 512 / 384 1040,
-  // 384 / 384 1045, 256 / 256 1031-1033, 128 / 128 905-912 (profiles/r05_experiments.md #16).
-  static const int gx_env = [] { const char* e = getenv("PXT_NGP_BATCH_GRID"); return e ? std::max(atoi(e), 64) : 0; }();
-  static const int gs_env = [] { const char* e = getenv("PXT_NGP_BATCH_GRID_SHADE"); return e ? std::max(atoi(e), 64) : 0; }();
-  const int wide = gx_env ? gx_env : 512, shade_grid = gs_env ? gs_env : (gx_env ? gx_env : 1024), cmp_grid = 1024;
-  // Six wavefront rounds before the straggler kernel (a single render: four): a round of the chain is one launch for all K
-  // objects, and the objects of config/*.sh keep more rays alive than the benchmark object (the straggler launch of four
-  // objects took 0.37 ms).  Eight objects, same box: 4 / 5 / 6 / 8 rounds = 1059 / 1063 / 1072 / 1072 frames/s.  A ray's result
-  // does not depend on the number of rounds (the straggler kernel runs the rounds' own steps).
-  static const int n_rounds = [] {
-    const char* e = getenv("PXT_NGP_BATCH_ROUNDS");
-    if (!e) e = getenv("PXT_NGP_ROUNDS");
-    return e ? std::min(std::max(atoi(e), 0), kMaxRounds) : kBatchRounds;
-  }();
-  static const int tail_grid = [] { const char* e = getenv("PXT_NGP_TAIL_GRID"); return e ? atoi(e) : 1024; }();
-  static const int tail_div = [] { const char* e = getenv("PXT_NGP_TAIL_DIV"); return e ? std::max(atoi(e), 1) : 64; }();
-  const dim3 blk(256);
-  if (n_rounds > 0)  // ray generation + compaction + the first march
-    hipLaunchKernelGGL(ngp_compact_march_batch_kernel<true>, dim3(2 * wide, K), blk, 0, s0, items, 0);
-  else
-    hipLaunchKernelGGL(ngp_compact_batch_kernel<true>, dim3(cmp_grid, K), blk, 0, s0, items, 0);
-  for (int r = 0; r < n_rounds; ++r) {
-    if (mode == 1)
-      hipLaunchKernelGGL(ngp_shade_batch_kernel<1>, dim3(shade_grid, K), blk, 0, s0, items, r);
-    else if (mode == 2)
-      hipLaunchKernelGGL(ngp_shade_batch_kernel<2>, dim3(shade_grid, K), blk, 0, s0, items, r);
-    else
-      hipLaunchKernelGGL(ngp_shade_batch_kernel<0>, dim3(shade_grid, K), blk, 0, s0, items, r);
-    if (r + 1 < n_rounds)  // compaction of round r + march of round r + 1 in one launch
-      hipLaunchKernelGGL(ngp_compact_march_batch_kernel<false>, dim3(wide, K), blk, 0, s0, items, r);
-    else
-      hipLaunchKernelGGL(ngp_compact_batch_kernel<false>, dim3(cmp_grid, K), blk, 0, s0, items, r);
-  }
-  if (mode == 1)
-    hipLaunchKernelGGL(ngp_tail_batch_kernel<1>, dim3(tail_grid, K), blk, 0, s0, items, n_rounds, tail_div);
-  else if (mode == 2)
-    hipLaunchKernelGGL(ngp_tail_batch_kernel<2>, dim3(tail_grid, K), blk, 0, s0, items, n_rounds, tail_div);
-  else
-    hipLaunchKernelGGL(ngp_tail_batch_kernel<0>, dim3(tail_grid, K), blk, 0, s0, items, n_rounds, tail_div);
-  hipLaunchKernelGGL(ngp_resolve_batch_kernel, dim3((max_pixels + 255) / 256, K), blk, 0, s0, items);
-  PXT_HIP_CHECK(hipGetLastError());
-  for (int k = 0; k < K; ++k) ctxs[k]->counters_clean = true;
-  return PXT_OK;
+  return run_chain(R, K, (hipStream_t)stream, batch_workspace);
 }
 
 extern "C" int pxt_ngp_set_pipelines(pxt_ngp* ctx, int32_t n) {
@@ -1995,10 +2019,3 @@ extern "C" int pxt_ngp_timing_read(pxt_ngp* ctx, float* total_ms, int32_t* n_lau
   ctx->events.clear();
   return PXT_OK;
 }
-
-#if PXT_EXP_STAMPS
-extern "C" int pxt_debug_ngp_stamps(void* host, int64_t bytes, int32_t round) {
-  if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(pxt::pxt_ngp_stamps), (size_t)bytes) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(pxt::pxt_ngp_stamp_round), &round, sizeof(int)) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -398,14 +398,16 @@ class Testbed:
         self.nerf.cone_angle_constant = snap.cone_angle
 
     def _side_ctx_int(self) -> int:
-        """A second context over the same snapshot (its own scratch, counters and camera slot; the 30-MB tables are
-        duplicated): two renders of DIFFERENT views - the tracker's mask at the query camera and its reference image at
-        the reference camera - run side by side on two streams, each as one pipeline, instead of one after the other
-        as two pipelines each.  Same images bit for bit (a ray's result does not depend on the pipeline count)."""
-        assert self._snap is not None, "load_snapshot first"
+        """A second context over the same snapshot (pxt_ngp_create_shared: its own ray lists, counters and camera slot; the
+        30 MB of tables are SHARED with the first): what the second of a frame's two renders of different views - the
+        tracker's mask at the query camera, its reference image at the reference camera - runs through, both in one
+        chain of launches (render_frame_pair_device)."""
+        assert self._ctx is not None, "load_snapshot first"
         if self._ctx_side is None:
-            self._ctx_side = self._create_ctx(self._snap)
-            _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx_side, 1), "pxt_ngp_set_pipelines")
+            ctx = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().pxt_ngp_create_shared(self._ctx, C.byref(ctx)), "pxt_ngp_create_shared")
+            self._ctx_side = ctx
         c = self._ctx_side
         return int(c.value) if hasattr(c, "value") else int(c)
 
@@ -421,10 +423,10 @@ class Testbed:
                 + [float(x) for x in self.render_aabb.min] + [float(x) for x in self.render_aabb.max]
                 + [float(x) for x in self.background_color] + [float(self.nerf.rendering_min_transmittance)])
 
-    def _view_for(self, width: int, height: int) -> list:
+    def _view_for(self, width: int, height: int, fov=None) -> list:
         v = self._view()
         res = width if self.fov_axis == 0 else height
-        v[12] = float(np.float32(0.5 * res / math.tan(0.5 * math.radians(self.fov))))
+        v[12] = float(np.float32(0.5 * res / math.tan(0.5 * math.radians(self.fov if fov is None else fov))))
         return v
 
     def render_device(self, width: int, height: int, spp: int = 8, linear: bool = True,
@@ -554,39 +556,56 @@ class Testbed:
         return out
 
     @staticmethod
-    def render_frame_batch_device(testbeds, sizes, spp: int = 8, mode: int = 2, from_slot: bool = False, workspace=None):
-        """render_frame_device for K testbeds (K objects, each with its own NeRF) in ONE chain of launches
-        (pxt_ngp_render_frame_batch): every launch carries the rays of all K renders, so one render's short late rounds
-        fill the others' launch tails.  ``sizes[k]`` = (width, height); every testbed's current camera / fov (or, with
-        ``from_slot``, its camera slot) is used as render_frame_device would.  Returns one dict per testbed (``rgb_u8``,
-        ``depth_nz`` as the mode provides), bit for bit what K render_frame_device calls return.  ``workspace``: a device
-        uint8 tensor of batch_workspace_bytes(K) the caller keeps per stream (made here when None)."""
+    def render_frame_batch_device(testbeds, sizes, spp: int = 8, mode=2, from_slot: bool = False, workspace=None,
+                                  sides=None, fovs=None):
+        """render_frame_device for K renders as ONE staged chain of launches (pxt_ngp_render_frame_batch): K testbeds (K objects,
+        each with its own NeRF), or - ``sides[k]`` true - a testbed's second context (the second of a frame's two renders of one
+        NeRF).  ``sizes[k]`` = (width, height); ``mode``: one int for all or one per render; ``fovs[k]`` (optional): the
+        render's field of view instead of the testbed's current one.  Every testbed's current camera (or, with
+        ``from_slot``, the context's camera slot) is used as render_frame_device would.  Returns one dict per render
+        (``rgb_u8``, ``depth_nz`` as its mode provides), bit for bit what K render_frame_device calls return.
+        ``workspace``: a device uint8 tensor of batch_workspace_bytes(K) the caller keeps per stream (made here when None;
+        K <= 2 needs none: the records travel as kernel arguments)."""
         K = len(testbeds)
         assert K >= 1 and len(sizes) == K
+        modes = [int(mode)] * K if isinstance(mode, int) else [int(m) for m in mode]
+        assert len(modes) == K
         dev = testbeds[0].device
         outs, views, flat_sizes, ctxs = [], [], [], []
-        for tb, (w, h) in zip(testbeds, sizes):
+        for k, (tb, (w, h)) in enumerate(zip(testbeds, sizes)):
             assert tb._ctx is not None, "load_snapshot first"
             if not tb.snap_to_pixel_centers:
                 raise _lib.PxtError("only snap_to_pixel_centers=True is implemented (ingp_utils.py:36)")
             o = {}
-            if mode != 1:
+            if modes[k] != 1:
                 o["rgb_u8"] = torch.empty(h, w, 3, device=dev, dtype=torch.uint8)
-            if mode != 0:
+            if modes[k] != 0:
                 o["depth_nz"] = torch.empty(h, w, device=dev, dtype=torch.uint8)
             outs.append(o)
-            views += tb._view_for(w, h)
+            views += tb._view_for(w, h, None if fovs is None else fovs[k])
             flat_sizes += [int(w), int(h)]
-            ctxs.append(tb._ctx_int())
+            ctxs.append(tb._side_ctx_int() if (sides is not None and sides[k]) else tb._ctx_int())
         if workspace is None:
-            workspace = torch.empty(Testbed.batch_workspace_bytes(K), dtype=torch.uint8, device=dev)
+            workspace = torch.empty(Testbed.batch_workspace_bytes(K) if K > 2 else 256, dtype=torch.uint8, device=dev)
         stats = [tb.stats_accum for tb in testbeds] if all(tb.stats_accum is not None for tb in testbeds) else []
-        ops.ngp_render_frame_batch(ctxs, views, flat_sizes, int(spp), int(mode), bool(from_slot),
-                                   [o["rgb_u8"] for o in outs] if mode != 1 else [],
-                                   [o["depth_nz"] for o in outs] if mode != 0 else [], workspace, stats)
+        ops.ngp_render_frame_batch(ctxs, views, flat_sizes, int(spp), modes, bool(from_slot),
+                                   [o["rgb_u8"] for o in outs if "rgb_u8" in o],
+                                   [o["depth_nz"] for o in outs if "depth_nz" in o], workspace, stats)
         for tb in testbeds:
             tb.n_renders += 1
         return outs
+
+    def render_frame_pair_device(self, depth_view, shade_view, spp: int = 8, from_slot: bool = False, workspace=None):
+        """A frame's two renders of DIFFERENT cameras at one pose - ``depth_view`` = (width, height, fov) of the mask's Depth
+        render (the query camera), ``shade_view`` of the reference image's Shade render (SfM camera 1 x reference_scale) - as
+        ONE chain of launches on the current stream (pixtrack/pose_trackers/pixloc_tracker_r9.py:145-152, 207-214 render them
+        one after the other through one testbed).  The Depth render runs through this testbed's first context, the Shade
+        render through its second (shared tables).  Returns (depth_nz, rgb_u8), bit for bit what render_frame_device
+        returns for each."""
+        (dw, dh, dfov), (sw, sh, sfov) = depth_view, shade_view
+        outs = Testbed.render_frame_batch_device([self, self], [(dw, dh), (sw, sh)], spp, mode=[1, 0], from_slot=from_slot,
+                                                 workspace=workspace, sides=[False, True], fovs=[dfov, sfov])
+        return outs[0]["depth_nz"], outs[1]["rgb_u8"]
 
     @staticmethod
     def batch_workspace_bytes(n: int) -> int:
@@ -599,17 +618,17 @@ class Testbed:
         return self.render_device(width, height, spp, linear).cpu().numpy()
 
     def set_pipelines(self, n: int = 0):
-        """Number of ray slices a large render processes side by side (0: default of 2).  Per-call `pipelines=`
-        overrides of render_device / render_from_pose_device return to this value afterwards."""
+        """Number of ray slices (pipes) a large render is cut into (0: default of 2; 1: every launch carries one stage).
+        Per-call `pipelines=` overrides of render_device / render_from_pose_device return to this value afterwards."""
         _lib.check(_lib.lib().pxt_ngp_set_pipelines(self._ctx, int(n)), "pxt_ngp_set_pipelines")
         self._pipelines = int(n)
 
     def timing_enable(self, every_nth: int = 1):
-        """HIP events around the gather-kernel (ngp_shade_kernel) launches of every ``every_nth``-th render (0 / False: off)."""
+        """HIP events around the launches that carry a shade stage (ngp_stage_kernel) of every ``every_nth``-th render (0 / False: off)."""
         _lib.check(_lib.lib().pxt_ngp_timing_enable(self._ctx, int(every_nth)), "pxt_ngp_timing_enable")
 
     def timing_read(self):
-        """(total ms, launches) of ngp_shade_kernel since the last read (HIP events on the render stream)."""
+        """(total ms, launches) of the shade-carrying launches since the last read (HIP events on the render stream)."""
         ms, n = C.c_float(0), C.c_int32(0)
         _lib.check(_lib.lib().pxt_ngp_timing_read(self._ctx, C.byref(ms), C.byref(n)), "pxt_ngp_timing_read")
         return float(ms.value), int(n.value)

@@ -63,10 +63,11 @@ SCHEMAS = {
     "ngp_render_frame": (
         "(int ctx, float[] view, int width, int height, int spp, int mode, bool camera_from_slot, Tensor(a!)? rgba, "
         "Tensor(b!)? depth, Tensor(c!)? rgb_u8, Tensor(d!)? depth_nz, Tensor(e!)? stats) -> ()"),
-    # K renders of K different contexts in one chain of launches (pxt_ngp_render_frame_batch): views = K x 25 floats, sizes =
-    # K x (width, height); rgb_u8 / depth_nz: one tensor per render for the planes the mode produces, else empty lists
+    # K renders of K different contexts as one chain of launches (pxt_ngp_render_frame_batch): views = K x 25 floats, sizes =
+    # K x (width, height), modes = K x {0 Shade, 1 Depth, 2 both}; rgb_u8: one tensor per render whose mode is 0 / 2, in render
+    # order; depth_nz: one per render whose mode is 1 / 2
     "ngp_render_frame_batch": (
-        "(int[] ctxs, float[] views, int[] sizes, int spp, int mode, bool camera_from_slot, Tensor(a!)[] rgb_u8, "
+        "(int[] ctxs, float[] views, int[] sizes, int spp, int[] modes, bool camera_from_slot, Tensor(a!)[] rgb_u8, "
         "Tensor(b!)[] depth_nz, Tensor(c!) workspace, Tensor(d!)[] stats) -> ()"),
     "depth_mask": "(Tensor depth_rgba, int n_erode, int n_dilate, Tensor(a!) mask, Tensor(b!) scratch) -> ()",
     "depth_mask_plane": "(Tensor depth_nz, int n_erode, int n_dilate, Tensor(a!) mask) -> ()",
@@ -395,19 +396,19 @@ def _ngp_render_frame(ctx, view, width, height, spp, mode, camera_from_slot, rgb
                                                _lib.dptr(stats), _stream(ref)), "pxt_ngp_render_frame")
 
 
-def _ngp_render_frame_batch(ctxs, views, sizes, spp, mode, camera_from_slot, rgb_u8, depth_nz, workspace, stats):
-    """pxt_ngp_render_frame_batch: K renders (one renderer context per object) in ONE chain of launches, every launch
-    carrying the rays of all K; bit for bit K calls of ngp_render_frame.  8-bit outputs only (what the tracker consumes)."""
-    K, mode = len(ctxs), int(mode)
-    if not (1 <= K <= _lib.PXT_NGP_MAX_BATCH) or len(views) != K * VIEW_FLOATS or len(sizes) != 2 * K:
-        raise _lib.PxtError(f"ngp_render_frame_batch: {K} renders (1..{_lib.PXT_NGP_MAX_BATCH}) need {VIEW_FLOATS} view floats "
-                            "and (width, height) each")
-    if mode not in (0, 1, 2):
-        raise _lib.PxtError("ngp_render_frame_batch: mode is 0 (Shade), 1 (Depth) or 2 (both)")
-    if len(rgb_u8) != (K if mode != 1 else 0) or len(depth_nz) != (K if mode != 0 else 0):
-        raise _lib.PxtError("ngp_render_frame_batch: one rgb_u8 per render in modes 0 / 2, one depth_nz in modes 1 / 2")
+def _ngp_render_frame_batch(ctxs, views, sizes, spp, modes, camera_from_slot, rgb_u8, depth_nz, workspace, stats):
+    """pxt_ngp_render_frame_batch: K renders of K renderer contexts - a frame's Depth + Shade pair, or K objects in lock-step -
+    as ONE staged chain of launches; bit for bit K calls of ngp_render_frame.  8-bit outputs only (what the tracker consumes)."""
+    K, modes = len(ctxs), [int(m) for m in modes]
+    if not (1 <= K <= _lib.PXT_NGP_MAX_BATCH) or len(views) != K * VIEW_FLOATS or len(sizes) != 2 * K or len(modes) != K:
+        raise _lib.PxtError(f"ngp_render_frame_batch: {K} renders (1..{_lib.PXT_NGP_MAX_BATCH}) need {VIEW_FLOATS} view floats, "
+                            "(width, height) and a mode each")
+    if any(m not in (0, 1, 2) for m in modes):
+        raise _lib.PxtError("ngp_render_frame_batch: a mode is 0 (Shade), 1 (Depth) or 2 (both)")
+    if len(rgb_u8) != sum(m != 1 for m in modes) or len(depth_nz) != sum(m != 0 for m in modes):
+        raise _lib.PxtError("ngp_render_frame_batch: one rgb_u8 per render of mode 0 / 2, one depth_nz per render of mode 1 / 2")
     L = _lib.lib()
-    need = int(L.pxt_ngp_batch_workspace_bytes(K))
+    need = int(L.pxt_ngp_batch_workspace_bytes(K)) if K > 2 else 0  # (<= 2 renders: the records travel as kernel arguments)
     if workspace.dtype != torch.uint8 or not workspace.is_cuda or not workspace.is_contiguous() or workspace.numel() < need:
         raise _lib.PxtError(f"ngp_render_frame_batch: workspace is a contiguous device uint8 tensor of >= {need} bytes")
     if len(stats) not in (0, K) or any(t.dtype != torch.int64 or t.numel() < 4 or not t.is_contiguous() for t in stats):
@@ -415,12 +416,17 @@ def _ngp_render_frame_batch(ctxs, views, sizes, spp, mode, camera_from_slot, rgb
     vs = (_lib.NgpView * K)()
     outs = (_lib.NgpOutputs * K)()
     cp = (C.c_void_p * K)(*[int(c) for c in ctxs])
+    mp = (C.c_int32 * K)(*modes)
     sp = (C.c_void_p * K)()
+    i_u8 = i_nz = 0
     for k in range(K):
         w, h = int(sizes[2 * k]), int(sizes[2 * k + 1])
-        vs[k] = _view(views[k * VIEW_FLOATS:(k + 1) * VIEW_FLOATS], w, h, spp, 0 if mode == 2 else mode)
-        u8 = rgb_u8[k] if mode != 1 else None
-        nz = depth_nz[k] if mode != 0 else None
+        vs[k] = _view(views[k * VIEW_FLOATS:(k + 1) * VIEW_FLOATS], w, h, spp, 0 if modes[k] == 2 else modes[k])
+        u8 = nz = None
+        if modes[k] != 1:
+            u8, i_u8 = rgb_u8[i_u8], i_u8 + 1
+        if modes[k] != 0:
+            nz, i_nz = depth_nz[i_nz], i_nz + 1
         if u8 is not None and (u8.dtype != torch.uint8 or tuple(u8.shape) != (h, w, 3) or not u8.is_contiguous()
                                or u8.device != workspace.device):
             raise _lib.PxtError("ngp_render_frame_batch: rgb_u8 is a contiguous device uint8 [H, W, 3]")
@@ -429,8 +435,9 @@ def _ngp_render_frame_batch(ctxs, views, sizes, spp, mode, camera_from_slot, rgb
             raise _lib.PxtError("ngp_render_frame_batch: depth_nz is a contiguous device uint8 [H, W]")
         outs[k] = _lib.NgpOutputs(None, None, _lib.dptr(u8), _lib.dptr(nz))
         sp[k] = stats[k].data_ptr() if stats else None
-    _lib.check(L.pxt_ngp_render_frame_batch(cp, vs, K, mode, int(bool(camera_from_slot)), outs,
-                                            sp if stats else None, workspace.data_ptr(), _stream(workspace)),
+    _lib.check(L.pxt_ngp_render_frame_batch(cp, vs, K, mp, int(bool(camera_from_slot)), outs,
+                                            sp if stats else None, workspace.data_ptr() if workspace.numel() else None,
+                                            _stream(workspace)),
                "pxt_ngp_render_frame_batch")
 
 

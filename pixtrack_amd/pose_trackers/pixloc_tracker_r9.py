@@ -41,9 +41,6 @@ from ..visualization.run_vis_on_poses import get_nerf_image_device, rgba_to_u8
 from .base_pose_tracker import PoseTracker
 
 
-_AHEAD_STREAMS = {}  # device index -> the process's second render stream (see PixLocPoseTrackerR9._two_streams)
-
-
 def infer_camera_from_image(width: int, height: int) -> ColmapCamera:
     """pycolmap.infer_camera_from_image without EXIF: SIMPLE_RADIAL, f = 1.2 max(w, h),
     principal point at the image centre, k = 0."""
@@ -123,16 +120,15 @@ class PixLocPoseTrackerR9(PoseTracker):
         self._coincide_cache = None
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
         self.steady_multiscale = [1]  # image scales of a tracked (non-cold-start) frame (:223)
-        # The next frame's render needs only this frame's pose.  With `render_ahead` it is enqueued BEHIND this
-        # frame's LM launch, its camera derived on the device from the LM kernel's pose record, instead of after
-        # the host has read the result, run the policy and converted the pose (~0.1 ms of GPU idle per frame).  It is
-        # consumed only if the host, once it knows the pose, arrives at the same 12 camera floats; otherwise
-        # (failed frame, cost gate, relocalisation, a different last bit) the frame renders as before.
+        # A frame's mask (Depth, query camera) and reference image (Shade, SfM camera 1 x reference_scale) are rendered at
+        # the same pose: ONE march when the two cameras coincide, else both renders as ONE chain of launches
+        # (Testbed.render_frame_pair_device); the renderer's last kernel writes the 8-bit reference image and the mask's
+        # `!= 0` plane itself.  The next frame's renders need only this frame's pose: with `render_ahead` they are enqueued
+        # BEHIND this frame's LM launch, their camera taken from the slot(s) the LM kernel's epilogue fills, instead of
+        # after the host has read the result, run the policy and converted the pose (~0.1 ms of GPU idle per frame).  They
+        # are consumed only if the host, once it knows the pose, arrives at the same 12 camera floats; otherwise (failed
+        # frame, cost gate, relocalisation, a different last bit) the frame renders as before.  PXT_RENDER_AHEAD=0: off.
         self.render_ahead = os.environ.get("PXT_RENDER_AHEAD", "1") != "0"
-        # Between-stage fusion (round 4): the renderer's last kernel writes the 8-bit reference image and the mask's
-        # `!= 0` plane itself (no rgba_to_u8 launch, no float images), and the camera of a queued render comes from the
-        # LM kernel's epilogue (no conversion launch).  PXT_FRAME_FUSION=0 keeps the separate launches (A/B, tests).
-        self.fused_frame_outputs = os.environ.get("PXT_FRAME_FUSION", "1") != "0"
         self._ahead_cam = None   # the pinned camera record the LM epilogue of this frame writes
         self._ahead = None       # the render queued behind the last LM launch
         self._ahead_ok = None    # ... once verified: (pose object it is valid for, mask, uint8 reference image)
@@ -283,83 +279,39 @@ class PixLocPoseTrackerR9(PoseTracker):
                 return mask
             self.renders_ahead_stale += 1
         self._ahead_ok = None
-        if self.fused_frame_outputs:
-            return self._mask_and_reference_fused(pose, from_slot=False)[0]
-        if self._views_coincide():
-            import math
+        return self._mask_and_reference(pose, from_slot=False)[0]
 
-            width, height, fl_x = self._coincide_cache[2]
-            self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
-            self.testbed.set_nerf_camera_matrix(np.asarray(self._nerf_pose(pose))[:3, :])
-            rgba, depth = self.testbed.render_both_device(width, height, self.spp)
-            self._fused_reference = (pose, rgba_to_u8(rgba, 0.0))
-        elif os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0":
-            # the frame's two renders - this mask's depth at the query camera, the reference image at the reference
-            # camera (get_reference_image is asked for it at the same pose next) - side by side on two streams
-            main, side = self._two_streams()
-            self._ahead_fork.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(self._ahead_fork)
-                rgba = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self._reference_camera(), spp=self.spp,
-                                             side=True)
-                ref_u8 = rgba_to_u8(rgba, 0.0)
-                self._ahead_join.record(side)
-            ref_u8.record_stream(main)
-            depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp,
-                                          pipelines=1)
-            main.wait_event(self._ahead_join)
-            self._fused_reference = (pose, ref_u8)
-        else:
-            depth = get_nerf_image_device(self.testbed, self._nerf_pose(pose), self.camera, depth=True, spp=self.spp)
-        H, W = int(depth.shape[0]), int(depth.shape[1])
-        mask = torch.empty(H, W, dtype=torch.uint8, device=self.device)
-        tmp = torch.empty(2 * H * W, dtype=torch.uint8, device=self.device)
-        ops.depth_mask(depth, 1, 5, mask, tmp)  # erode 5x5 once, dilate 5x5 five times (:211-213)
-        return mask
-
-    def _mask_and_reference_fused(self, pose, from_slot: bool):
-        """The frame's mask and 8-bit reference image through pxt_ngp_render_frame: ONE march when the two views
-        coincide, otherwise the Depth render (query camera) on this stream and the Shade render (reference camera) on
-        a second stream through the testbed's second context.  ``from_slot``: the camera is the one the LM kernel ahead
-        in the stream derived from its final pose (render-ahead); otherwise the host's conversion of ``pose``.  Sets
-        ``_fused_reference`` when a pose object is given; returns (mask, ref_u8)."""
+    def _frame_views(self):
+        """(width, height, fov in degrees on x) of the frame's renders as get_nerf_image sets them up
+        (run_vis_on_poses.py:30-38): [query camera] when mask and reference cameras coincide (one march yields both
+        images), else [query camera (Depth), reference camera (Shade)]."""
         import math
 
+        def fov_of(cam):
+            w, h = (int(v) for v in cam.size)
+            return w, h, math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
+
+        return [fov_of(self.camera)] if self._views_coincide() else [fov_of(self.camera), fov_of(self._reference_camera())]
+
+    def _mask_and_reference(self, pose, from_slot: bool):
+        """The frame's mask and 8-bit reference image at one pose (reference :145-152, :207-214): ONE march when the two
+        views coincide, otherwise the Depth render (query camera) and the Shade render (reference camera) as one chain of
+        launches on this stream.  ``from_slot``: the camera is the one the LM kernel ahead in the stream derived from its
+        final pose (render-ahead); otherwise the host's conversion of ``pose``.  Sets ``_fused_reference`` when a pose
+        object is given; returns (mask, ref_u8)."""
         tb, spp = self.testbed, int(self.spp)
         if not from_slot:
             tb.set_nerf_camera_matrix(np.asarray(self._nerf_pose(pose))[:3, :])
-        if self._views_coincide():
-            width, height, fl_x = self._coincide_cache[2]
-            tb.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
+        views = self._frame_views()
+        width, height, fov_q = views[0]
+        if len(views) == 1:
+            tb.fov = fov_q
             out = tb.render_frame_device(width, height, spp, mode=2, from_slot=from_slot)
             ref_u8, nz = out["rgb_u8"], out["depth_nz"]
         else:
-            def fov_of(cam):
-                w, h = (int(v) for v in cam.size)
-                return w, h, math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
-
-            width, height, fov_q = fov_of(self.camera)
-            rw, rh, fov_r = fov_of(self._reference_camera())
-            two = os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0"
-            if two:
-                main, side = self._two_streams()
-                self._ahead_fork.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(self._ahead_fork)
-                    tb.fov = fov_r
-                    ref_u8 = tb.render_frame_device(rw, rh, spp, mode=0, from_slot=from_slot, side=True)["rgb_u8"]
-                    self._ahead_join.record(side)
-                ref_u8.record_stream(main)
-            tb.fov = fov_q
-            nz = tb.render_frame_device(width, height, spp, mode=1, from_slot=from_slot,
-                                        pipelines=1 if two else 0)["depth_nz"]
-            if not two:
-                tb.fov = fov_r
-                ref_u8 = tb.render_frame_device(rw, rh, spp, mode=0, from_slot=from_slot)["rgb_u8"]
+            nz, ref_u8 = tb.render_frame_pair_device(views[0], views[1], spp, from_slot=from_slot)
         mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
         ops.depth_mask_plane(nz, 1, 5, mask)  # erode 5x5 once, dilate 5x5 five times (:211-213)
-        if not self._views_coincide() and self.__dict__.get("_ahead_stream") is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._ahead_join)
         if pose is not None:
             self._fused_reference = (pose, ref_u8)
         return mask, ref_u8
@@ -371,99 +323,27 @@ class PixLocPoseTrackerR9(PoseTracker):
         if conv is None:
             conv = self._pose_conv = self.testbed.pose_conversion(self.nerf2sfm)
         slots = [self.testbed.camera_slot()]
-        if not self._views_coincide() and os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0":
+        if not self._views_coincide():  # the pair's Shade render runs through the testbed's second context
             slots.append(self.testbed.camera_slot(side=True))
         self._ahead_cam = self.testbed._next_cam_out()
         return conv, slots, self._ahead_cam
 
     # ------------------------------------------------------------------ the next frame's render, ahead of the host
-    def _two_streams(self):
-        """(current stream, the stream the second of a frame's two renders runs on) + the fork / join events."""
-        if self.__dict__.get("_ahead_stream") is None:
-            # ONE such stream per device and process, shared by every tracker: HIP deals streams to its four hardware
-            # queues in creation order, so a stream made by the fourth tracker of a process may share a queue with the
-            # stream it is meant to run beside (bench.py: value_r9_phone 457 inside the full run, 530-550 on its own)
-            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            if key not in _AHEAD_STREAMS:
-                _AHEAD_STREAMS[key] = torch.cuda.Stream(self.device)
-            self._ahead_stream = _AHEAD_STREAMS[key]
-            self._ahead_fork, self._ahead_join = torch.cuda.Event(), torch.cuda.Event()
-        return torch.cuda.current_stream(self.device), self._ahead_stream
-
     def _render_ahead(self, pending):
-        """Called between the LM launch and the wait for its result: the mask + reference render of the NEXT frame,
-        whose camera a one-thread kernel derives from the LM kernel's pose record on the device."""
-        import math
-
-        if self.fused_frame_outputs:  # camera from the LM epilogue's slot, 8-bit outputs from the resolve kernel
-            views = self._ahead_views_now()
-            mask, ref_u8 = self._mask_and_reference_fused(None, from_slot=True)
-            self._ahead = ([self._ahead_cam], mask, ref_u8, views)
-            return
-        conv = self.__dict__.get("_pose_conv")
-        if conv is None:
-            conv = self._pose_conv = self.testbed.pose_conversion(self.nerf2sfm)
-
-        def fov_of(cam):
-            w, h = (int(v) for v in cam.size)
-            return w, h, math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
-
-        spp = int(self.spp)
-        if self._views_coincide():  # one march yields the mask's depth and the reference image
-            width, height, fl_x = self._coincide_cache[2]
-            self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
-            views = [self._ahead_view_key(width, height, spp)]
-            rgba, depth, cam_out = self.testbed.render_both_from_pose_device(width, height, spp, pending.buf, conv)
-            cams = [cam_out]
-        else:  # two renders: Depth with the query camera, Shade with SfM camera 1 x reference_scale (:145-152, :207-214)
-            # ... side by side: the reference image on a second stream through the testbed's second context, the mask's
-            # depth on this one, one pipeline each (PXT_AHEAD_TWO_STREAMS=0: one after the other, two pipelines each)
-            width, height, fov_q = fov_of(self.camera)
-            rw, rh, fov_r = fov_of(self._reference_camera())
-            self.testbed.fov = fov_q
-            views = [self._ahead_view_key(width, height, spp)]
-            self.testbed.fov = fov_r
-            views.append(self._ahead_view_key(rw, rh, spp))
-            two = os.environ.get("PXT_AHEAD_TWO_STREAMS", "1") != "0"
-            if two:
-                main, _ = self._two_streams()
-                self._ahead_fork.record(main)  # behind the LM launch
-                with torch.cuda.stream(self._ahead_stream):
-                    self._ahead_stream.wait_event(self._ahead_fork)
-                    self.testbed.fov = fov_r
-                    rgba, cam_ref = self.testbed.render_from_pose_device(rw, rh, spp, pending.buf, conv, side=True)
-                    ref_u8 = rgba_to_u8(rgba, 0.0)
-                    self._ahead_join.record(self._ahead_stream)
-                ref_u8.record_stream(main)
-            self.testbed.fov = fov_q
-            self.testbed.render_mode = self.testbed.render_mode.Depth
-            try:
-                depth, cam_out = self.testbed.render_from_pose_device(width, height, spp, pending.buf, conv,
-                                                                      pipelines=1 if two else 0)
-            finally:
-                self.testbed.render_mode = self.testbed.render_mode.Shade
-            if not two:
-                self.testbed.fov = fov_r
-                rgba, cam_ref = self.testbed.render_from_pose_device(rw, rh, spp, pending.buf, conv)
-                ref_u8 = rgba_to_u8(rgba, 0.0)
-            cams = [cam_out, cam_ref]  # both records stay referenced until their kernels have been observed
-        if self._views_coincide():
-            ref_u8 = rgba_to_u8(rgba, 0.0)
-        mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
-        tmp = torch.empty(2 * height * width, dtype=torch.uint8, device=self.device)
-        ops.depth_mask(depth, 1, 5, mask, tmp)
-        if self.__dict__.get("_ahead_stream") is not None and not self._views_coincide():
-            torch.cuda.current_stream(self.device).wait_event(self._ahead_join)  # (a no-op if nothing was recorded since)
-        self._ahead = (cams, mask, ref_u8, views)
+        """Called between the LM launch and the wait for its result: the mask + reference render(s) of the NEXT frame, whose
+        camera the LM kernel's epilogue writes into the renderer's camera slot(s)."""
+        views = self._ahead_views_now()
+        mask, ref_u8 = self._mask_and_reference(None, from_slot=True)
+        self._ahead = ([self._ahead_cam], mask, ref_u8, views)
 
     def _render_ahead_request(self):
         """For a caller that merges the queued renders of several trackers into one batched chain (lock-step tracking,
         Testbed.render_frame_batch_device): (width, height, spp) of this tracker's one-march mask + reference render with
-        the testbed's view set for it - or None when the frame's render is not of that kind (two different cameras, or
-        the float-image path), in which case _render_ahead() is to be called as usual."""
+        the testbed's view set for it - or None when the frame's render is not of that kind (two different cameras), in
+        which case _render_ahead() is to be called as usual."""
         import math
 
-        if not (self.fused_frame_outputs and self._views_coincide()):
+        if not self._views_coincide():
             return None
         width, height, fl_x = self._coincide_cache[2]
         self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
@@ -477,26 +357,12 @@ class PixLocPoseTrackerR9(PoseTracker):
         ops.depth_mask_plane(nz, 1, 5, mask)  # erode 5x5 once, dilate 5x5 five times (:211-213)
         self._ahead = ([self._ahead_cam], mask, ref_u8, views)
 
-    def _ahead_view_key(self, width, height, spp):
-        """Everything a queued render baked in besides the camera pose: focal length, lens, render box, background,
-        minimum transmittance (floats 12.. of the view record), image size and spp."""
-        return (tuple(self.testbed._view_for(width, height)[12:]), int(width), int(height), int(spp))
-
     def _ahead_views_now(self):
-        """The view keys get_mask / get_reference_image would render with right now."""
-        import math
-
+        """What a render queued now bakes in besides the camera pose, per render of the frame: focal length, lens, render
+        box, background, minimum transmittance (floats 12.. of the view record), image size and spp - the keys
+        get_mask / get_reference_image would render with right now."""
         spp = int(self.spp)
-        fov0 = self.testbed.fov
-        try:
-            keys = []
-            for cam in ([self.camera] if self._views_coincide() else [self.camera, self._reference_camera()]):
-                w, h = (int(v) for v in cam.size)
-                self.testbed.fov = math.atan(w / (float(cam.f[0]) * 2)) * 2 * 180 / np.pi
-                keys.append(self._ahead_view_key(w, h, spp))
-            return keys
-        finally:
-            self.testbed.fov = fov0
+        return [(tuple(self.testbed._view_for(w, h, fov)[12:]), w, h, spp) for w, h, fov in self._frame_views()]
 
     def _verify_render_ahead(self, success: bool):
         """The render queued behind the LM launch is kept for the next frame only if the pose was accepted and the
@@ -570,7 +436,7 @@ class PixLocPoseTrackerR9(PoseTracker):
                   and refiner.conf.multiscale == [1] and len(self.reference_ids) == 1)
         self._ahead = None
         refiner.after_lm_enqueued = self._render_ahead if (self.render_ahead and steady) else None
-        refiner.lm_camera = self._lm_camera if (self.render_ahead and steady and self.fused_frame_outputs) else None
+        refiner.lm_camera = self._lm_camera if (self.render_ahead and steady) else None
         return "steady" if steady else kind
 
     def _frame_pose_init(self) -> Pose:

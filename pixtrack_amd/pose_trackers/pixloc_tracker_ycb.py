@@ -110,7 +110,7 @@ class PixLocPoseTrackerYCB(PixLocPoseTrackerR9):
         steady = self.render_ahead and list(refiner.conf.multiscale or [1]) == [1] and len(self.reference_ids) == 1
         self._ahead = None
         refiner.after_lm_enqueued = self._render_ahead if steady else None
-        refiner.lm_camera = self._lm_camera if (steady and self.fused_frame_outputs) else None
+        refiner.lm_camera = self._lm_camera if steady else None
 
         self.dynamic_id = self.get_dynamic_id(self.pose)
         rotation, translation = self.pose.numpy()

@@ -1,0 +1,74 @@
+"""Does the CPU ORACLE drift from the synthetic ground truth on the two config/*.sh boxes where the HIP path does?
+
+VERDICT r5 weak #3: over 60 steps of `bench.py --config objects8` (640 x 480, spp 8, cold-start sigma 24) the HIP tracks of
+bottle and roncelli_blankk - lock-step AND solo - end 0.136 / 0.222 rad from the synthetic ground truth
+(profiles/r05_bench_objects8.json).  Nobody had run the oracle on those boxes, so nobody knew whether that is the algorithm on
+a degenerate synthetic scene (a 0.079-thick slab seen edge-on; a bottle's rotation about its long axis) or the HIP path.
+
+This script tracks the SAME scenes (make_tracking_assets(seed=1002 + object index, aabb=the object's box): the bench's own
+assets and ground-truth orbit) with oracle/frame_oracle.track_sequence at the bench's size.  The query frames are ORACLE
+renders at the ground-truth poses + Gaussian noise of the bench's sigmas (24 on the cold-start frame, 2 afterwards) - the noise
+realisation differs from the bench's (numpy vs torch generators), the statistics do not.  CPU only, hours: run it in the
+background.  One line per frame: rotation / translation error against ground truth, cost, gate decision.
+
+    PXT_ORACLE_PROCS=3 python scripts/oracle_drift_long.py bottle 65 > profiles/r06_oracle_drift_bottle.log
+"""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+
+
+def main():
+    name, n_frames = sys.argv[1], int(sys.argv[2])
+    W, H, SPP = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (640, 480, 8)
+    import torch
+
+    torch.set_num_threads(2)
+    from oracle import frame_oracle as FO
+    from oracle import ngp_oracle as NO
+    from pixtrack_amd import parallel
+    from pixtrack_amd.synthetic import make_tracking_assets
+
+    objs = parallel.load_object_configs()
+    u = [o["name"] for o in objs].index(name)
+    assets = make_tracking_assets(seed=1002 + u, width=W, height=H, n_frames=n_frames, aabb=objs[u]["aabb"])
+    ngp = FO.ngp_model(assets["snapshot"])
+    qcam = FO.colmap_camera_to_pix(assets["query_camera"])
+    rng = np.random.default_rng(1002 + u + 177)
+    model3d = assets["model3d"]
+    ref_id = model3d.name2id[assets["upright_ref_img"]]
+    im = model3d.dbs[ref_id]
+    R, t = im.qvec2rotmat(), np.asarray(im.tvec, np.float64)
+    cold, success, thr, multiscale = True, True, None, (1,)
+    print(f"# {name} box {objs[u]['aabb']} {W}x{H} spp {SPP} frames {n_frames} procs {NO.DEFAULT_PROCS}", flush=True)
+    print("# frame masked lm_ok tracked cost thr rot_err_gt_rad trans_err_gt iters seconds", flush=True)
+    for i, (Rg, tg) in enumerate(assets["gt_poses"]):
+        t0 = time.time()
+        rgba = NO.render(ngp, FO.nerf_view(assets["snapshot"], assets["nerf2sfm"], assets["aabb"], Rg, tg, qcam, 0, SPP))
+        u8 = FO.to_u8(rgba).astype(np.float32)
+        frame = np.clip(np.rint(u8 + rng.normal(size=u8.shape) * (24.0 if i == 0 else 2.0)), 0, 255).astype(np.float32)
+        use_mask = False
+        if cold:
+            multiscale, cold = (4, 1), False
+        elif success:
+            multiscale, use_mask = (1,), True
+        res = FO.track_frame(assets, R, t, frame, ref_id, multiscale=multiscale, use_mask=use_mask, spp=SPP)
+        cost = res["cost"]
+        if thr is None:
+            thr = cost + 0.1 * cost
+        ok = bool(res["success"] and cost <= thr)
+        if ok:
+            R, t = res["R"].numpy().astype(np.float64), res["t"].numpy().astype(np.float64)
+        success = ok
+        rot = float(np.arccos(np.clip((np.trace(R @ Rg.T) - 1) / 2, -1, 1)))
+        tra = float(np.linalg.norm(t - tg))
+        print(i, int(use_mask), int(bool(res["success"])), int(ok), f"{cost:.5f} {thr:.5f} {rot:.5f} {tra:.5f}",
+              "/".join(str(v) for v in res["iters"]), round(time.time() - t0, 1), flush=True)
+
+
+if __name__ == "__main__":
+    main()

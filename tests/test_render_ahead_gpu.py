@@ -53,16 +53,16 @@ def test_device_camera_and_render_equal_the_host_path(device):
     assert same >= 22  # the two chains may differ in a last float64 bit (BLAS vs sequential products); the tracker checks
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_tracking_is_identical_with_and_without_render_ahead(device, fused, monkeypatch):
+@pytest.mark.parametrize("coincide", [True, False])
+def test_tracking_is_identical_with_and_without_render_ahead(device, coincide):
+    """coincide False: mask and reference image are two renders of different cameras (the real-asset case), queued as ONE
+    chain behind the LM launch, each context's camera from its own slot."""
     n = 14
     assets = make_tracking_assets(seed=1002, width=320, height=240, n_frames=n)
     hist = {}
-    # "serial": the two renders of the unfused case one after the other instead of side by side on two streams
-    for ahead in (False, True) + (() if fused else ("serial",)):
-        monkeypatch.setenv("PXT_AHEAD_TWO_STREAMS", "0" if ahead == "serial" else "1")
+    for ahead in (False, True):
         tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
-        tr.fuse_identical_views = fused  # False: mask and reference image are two renders (the real-asset case)
+        tr.fuse_identical_views = coincide
         tr.render_ahead = bool(ahead)
         frames = render_query_frames(assets, tr.testbed)
         for i in range(n):
@@ -72,8 +72,6 @@ def test_tracking_is_identical_with_and_without_render_ahead(device, fused, monk
         if ahead:
             assert tr.renders_ahead_used >= n - 3
     assert np.array_equal(hist[False], hist[True])
-    if not fused:
-        assert np.array_equal(hist[False], hist["serial"])
 
 
 def test_a_queued_render_is_not_used_after_the_view_settings_changed(device):
@@ -234,26 +232,42 @@ def test_lm_epilogue_camera_equals_the_conversion_kernel(device):
         PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws, camera=(conv, [], None)).result()
 
 
-@pytest.mark.parametrize("coincide", [True, False])
-def test_tracking_is_identical_with_and_without_frame_fusion(device, coincide):
-    """PXT_FRAME_FUSION on / off (the resolve kernel's 8-bit outputs + the LM epilogue's camera against the separate
-    rgba_to_u8 / conversion launches), with the render-ahead on and off: the same poses, bit for bit."""
-    n = 12
+@pytest.mark.parametrize("ahead", [True, False])
+def test_tracking_with_the_pair_chain_equals_two_separate_renders(device, ahead, monkeypatch):
+    """A frame's Depth + Shade pair as ONE chain (Testbed.render_frame_pair_device) against the same two renders made one
+    after the other through the float-image entry points + rgba_to_u8 / the `!= 0` plane (what the tracker did before the
+    renderer wrote the 8-bit planes itself): the same poses, bit for bit, over a tracked sequence."""
+    from pixtrack_amd.visualization.run_vis_on_poses import rgba_to_u8
+
+    n = 10
     assets = make_tracking_assets(seed=1002, width=320, height=240, n_frames=n)
     hist = {}
-    for fusion in (True, False):
-        for ahead in (True, False):
-            tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
-            tr.fuse_identical_views = coincide
-            tr.fused_frame_outputs = fusion
-            tr.render_ahead = ahead
-            frames = render_query_frames(assets, tr.testbed)
-            for i in range(n):
-                tr.run_single_frame((f"{i:06d}.png", frames[i]))
-            hist[(fusion, ahead)] = np.stack(
-                [np.concatenate([a.ravel() for a in tr.pose_history[f"{i:06d}.png"]["T_refined"].numpy()]) for i in range(n)])
-            if ahead:
-                assert tr.renders_ahead_used >= n - 3, (fusion, tr.renders_ahead_used, tr.renders_ahead_rejected)
-    base = hist[(False, False)]
-    for k, v in hist.items():
-        assert np.array_equal(v, base), k
+    for separate in (False, True):
+        tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+        tr.fuse_identical_views = False
+        tr.render_ahead = ahead and not separate  # (the separate renders take the host's camera)
+        tb = tr.testbed
+        if separate:
+            def two_renders(depth_view, shade_view, spp=8, from_slot=False, workspace=None, tb=tb):
+                assert not from_slot
+                (dw, dh, dfov), (sw, sh, sfov) = depth_view, shade_view
+                fov0, mode0 = tb.fov, tb.render_mode
+                try:
+                    tb.fov, tb.render_mode = dfov, tb.render_mode.Depth
+                    depth = tb.render_device(dw, dh, spp)
+                    tb.fov, tb.render_mode = sfov, tb.render_mode.Shade
+                    rgba = tb.render_device(sw, sh, spp)
+                finally:
+                    tb.fov, tb.render_mode = fov0, mode0
+                nz = (((depth[..., 0] * 255.0).to(torch.int64) & 255) != 0).to(torch.uint8)
+                return nz, rgba_to_u8(rgba, 0.0)
+
+            monkeypatch.setattr(tb, "render_frame_pair_device", two_renders)
+        frames = render_query_frames(assets, tr.testbed)
+        for i in range(n):
+            tr.run_single_frame((f"{i:06d}.png", frames[i]))
+        hist[separate] = np.stack(
+            [np.concatenate([a.ravel() for a in tr.pose_history[f"{i:06d}.png"]["T_refined"].numpy()]) for i in range(n)])
+        if tr.render_ahead:
+            assert tr.renders_ahead_used >= n - 3, (tr.renders_ahead_used, tr.renders_ahead_rejected)
+    assert np.array_equal(hist[False], hist[True])

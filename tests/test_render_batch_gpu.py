@@ -1,5 +1,7 @@
-"""pxt_ngp_render_frame_batch: K renders of K different renderer contexts (K objects tracked in lock-step) in ONE chain of
-launches.  Every image must be bit for bit the single render's: no ray's result depends on which rays share its launches."""
+"""pxt_ngp_render_frame_batch: K renders of K different renderer contexts - K objects tracked in lock-step, or a frame's Depth
+(query camera) + Shade (reference camera) pair through a testbed's two contexts - as ONE staged chain of launches on one
+stream.  Every image must be bit for bit the single render's: no ray's result depends on which rays share its launches."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -92,13 +94,50 @@ def test_a_batch_of_one_is_the_single_render(device):
     assert torch.equal(got["rgb_u8"], want["rgb_u8"]) and torch.equal(got["depth_nz"], want["depth_nz"])
 
 
+@pytest.mark.parametrize("sizes", [((160, 120), (240, 180)), ((640, 480), (960, 720)), ((203, 131), (96, 64))])
+def test_a_frames_depth_and_shade_pair_equals_the_two_single_renders(device, sizes):
+    """Modes {1, 0} with different sizes and focal lengths at ONE pose - the mask's Depth render at the query camera and the
+    reference image's Shade render at the reference camera (reference pixloc_tracker_r9.py:145-152, 207-214) - through
+    render_frame_pair_device: one chain, the second render through the testbed's second context (shared tables)."""
+    (dw, dh), (sw, sh) = sizes
+    tb = _testbed(device, 11, PREMIER_PROTEIN_AABB, dw, 1.7, [0.9, 0.5, 0.3])
+    fov_d = math.degrees(2 * math.atan(dw / (2 * 1.2 * dw)))
+    fov_s = math.degrees(2 * math.atan(sw / (2 * 1.05 * sw)))
+    spp = 8 if dw >= 640 else 4
+    tb.fov = fov_d
+    want_nz = tb.render_frame_device(dw, dh, spp, mode=1)["depth_nz"]
+    tb.fov = fov_s
+    want_u8 = tb.render_frame_device(sw, sh, spp, mode=0)["rgb_u8"]
+    tb.fov = 33.0  # (the pair takes its fields of view from its arguments)
+    for rep in range(2):
+        nz, u8 = tb.render_frame_pair_device((dw, dh, fov_d), (sw, sh, fov_s), spp)
+        torch.cuda.synchronize()
+        assert torch.equal(nz, want_nz) and torch.equal(u8, want_u8), rep
+    assert 0.01 < float(want_nz.float().mean()) < 0.99
+    # the camera slots: a pair queued with from_slot reads each context's own slot
+    cam = torch.from_numpy(np.asarray(tb._cam_ngp, np.float32).reshape(-1)).to(device)
+    for side in (False, True):
+        slot = tb.camera_slot(side=side)
+        # (in the product the LM kernel's epilogue fills the slots; here a device-to-device copy does)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(slot), C.c_void_p(cam.data_ptr()), 48, 3) == 0
+    tb._cam_ngp = np.eye(4)[:3]  # the host-side camera must NOT be what the slot render uses
+    nz, u8 = tb.render_frame_pair_device((dw, dh, fov_d), (sw, sh, fov_s), spp, from_slot=True)
+    assert torch.equal(nz, want_nz) and torch.equal(u8, want_u8)
+
+
 def test_batch_argument_errors(device):
     objs = _objects(device)[:2]
     tbs, sizes = [tb for tb, _ in objs], [s for _, s in objs]
     with pytest.raises(_lib.PxtError):  # the same context twice: one set of ray lists
         Testbed.render_frame_batch_device([tbs[0], tbs[0]], sizes, 4)
-    with pytest.raises(_lib.PxtError):  # workspace too small
-        Testbed.render_frame_batch_device(tbs, sizes, 4, workspace=torch.empty(64, dtype=torch.uint8, device=device))
+    three = _objects(device)[:3]
+    with pytest.raises(_lib.PxtError):  # workspace too small (three renders: the records live in device memory)
+        Testbed.render_frame_batch_device([tb for tb, _ in three], [s for _, s in three], 4,
+                                          workspace=torch.empty(64, dtype=torch.uint8, device=device))
+    with pytest.raises(_lib.PxtError):  # a mode per render
+        Testbed.render_frame_batch_device(tbs, sizes, 4, mode=[2, 3])
     L = _lib.lib()
     assert L.pxt_ngp_batch_workspace_bytes(0) < 0 and L.pxt_ngp_batch_workspace_bytes(_lib.PXT_NGP_MAX_BATCH + 1) < 0
-    assert L.pxt_ngp_render_frame_batch(None, None, 1, 2, 0, None, None, None, None) == -1
+    assert L.pxt_ngp_render_frame_batch(None, None, 1, None, 0, None, None, None, None) == -1
+    assert L.pxt_ngp_create_shared(None, None) == -1
