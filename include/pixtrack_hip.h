@@ -336,8 +336,8 @@ typedef struct {
 
 /* out_rgba: float32 [height][width][4], linear colour (render(..., linear=True)). */
 int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
-                   uint64_t* stats /* device, 4 counters (added to) or NULL: samples composited, rays that hit the
-                                      box, rays left to the straggler kernel, samples composited there */, void* stream);
+                   uint64_t* stats /* device, 4 counters (added to) or NULL: [0] samples composited, [1] rays that hit the
+                                      render box; [2], [3] unused since ABI 11 */, void* stream);
 
 /* Shade AND Depth of the SAME view in one march: bit-for-bit what two pxt_ngp_render calls
  * (mode 0, then mode 1) of this view produce, with the per-sample gathers and the density

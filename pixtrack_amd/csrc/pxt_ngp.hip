@@ -341,47 +341,36 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 }
 
 // ===========================================================================
-// Wavefront renderer.
+// The renderer: three launches per render (or per chain of K renders), all on the caller's stream.
 //
-// A render is a short chain of kernels over a COMPACT list of live rays (wavefront style):
+//   raygen   : ngp_raygen_kernel - a ray per (pixel, spp pass), box test, start jitter, order-preserving compaction of the
+//              rays that hit the render box into a list (ray id, start t, unit direction)
+//   render   : ngp_render_kernel - PERSISTENT waves: a wave holds 8 rays of the list and repeats two steps until its
+//              share of the list is used up: every ray's next K = 8 occupied lattice samples (ngp_march_group: the 8 lanes
+//              of a ray probe 8 lattice points per trip), then the wave's 8 x 8 samples through the hash grid (16 levels x
+//              8 corners of 4-byte gathers per lane), both MLPs on MFMA, in-order compositing; a ray that terminated or
+//              left the box is replaced by the next one of the wave's share.  Samples travel from the march to the shade
+//              step in registers, a ray's transmittance and colour stay in registers from its first sample to its last.
+//   resolve  : fixed-order mean over spp + background (+ the 8-bit planes the tracking loop consumes)
 //
-//   round 0  : ray generation (ray per (pixel, spp), box test, start jitter) + tile compaction + first march in
-//              one launch (ngp_compact_march_kernel<true>)
-//   round r  : march   -- each live ray collects its next K occupied lattice samples (fused with the compaction of
-//                         the previous round's survivors: ngp_compact_march_kernel<false>)
-//              shade   -- ngp_shade_kernel<MODE, true>: 8 rays x K=8 samples per wave; the wave gathers the hash-grid
-//                         features of its own 64 samples (16 levels x 8 corners), runs both MLPs on MFMA, composites
-//                         in order, terminates rays early
-//   tail     : after the wavefront rounds the remaining rays (grazing the soft shell) finish in a per-WAVE loop of the
-//              same march + shade steps (8 rays x 8 samples per trip)
-//   resolve  : fixed-order mean over spp + background
+// History (profiles/HISTORY.md, profiles/r06_experiments.md).  Rounds 1-5 ran a render as a chain of
+// WAVEFRONT rounds - march kernel -> sample buffers -> shade kernel -> compaction, 4 rounds, the rays still alive left to a
+// "straggler" kernel, which was this persistent loop - as two chains over the halves of the rays on two HIP streams, so
+// that one half's latency-bound march ran beside the other's gather-bound shade kernel.  That overlap was HIP's to grant
+// (how streams are dealt to hardware queues): the same command ran at 396 and 544 frames/s on two boxes of one pool.  Round 6
+// wrote the overlap down - one launch carrying the shade stage of one half and the march stage of the other - and
+// measured that it is not an overlap at all: such a launch takes the SUM of its two stages' times (a marching workgroup
+// holds registers and issue slots like any other), the two-stream chains had merely hidden launch ramps and tails; and
+// hipExtAnyOrderLaunch is ignored on gfx9.  On ONE stream the persistent loop alone beats every rounds configuration
+// (render of the benchmark view: 0.68 ms against 0.82 for 4 rounds, 0.75 for 1; a frame's Depth + Shade pair 1.19 against
+// 1.39): no sample buffers (160 MB written and read back per round), no per-round state traffic, no compaction, 3
+// launches instead of 12 - and nothing left for a queue assignment to decide.  The rounds were removed.
 //
-// History (profiles/r02_ngp_experiments.md): round 1 gathered in a separate LEVEL-MAJOR kernel
-// (ngp_encode_kernel: blocks dispatched in level order, one ~2 MB level hot in every XCD's L2 at a time, features
-// round-tripped through feat[level][sample]) because its first all-levels-per-wave kernel, at one wave per SIMD and
-// without the ray order below, re-fetched ~3 KB of lines per 512 algorithmic bytes (7 ms per render).  With
-// sample-fastest ray order, four waves per SIMD and the lanes transposed for the gathers, the all-levels-per-wave
-// kernel is the faster one again (0.92 -> 0.68 ms per render).  The level-major path, the dense levels in LDS
-// (north_star's variant: measured slower, experiment #6) and the x-pair gathers were removed in round 3 (git history).
-//
-// Every ray performs exactly the arithmetic of oracle/ngp_oracle.py on exactly the same
-// samples; samples a round evaluates past a ray's termination point are discarded.
+// Every ray performs exactly the arithmetic of oracle/ngp_oracle.py on exactly the same samples; samples a step evaluates
+// past a ray's termination point are discarded.
 // ===========================================================================
-constexpr int kK = 8;          // samples per ray per round
-// Wavefront rounds before the straggler kernel.  Round 3, with the per-wave straggler kernel (render_both, ms, frames 0 / 30 /
-// 60 / 100 / 150 / 200 / 250 / 300 of the synthetic orbit): 1 round 0.75 / 0.71 / 0.73 / 0.76 / 0.79 / 0.79 / 0.76 / 0.69;
-// 2: 0.66 / 0.63 / 0.65 / 0.69 / 0.70 / 0.72 / 0.67 / 0.62; **3: 0.66 / 0.61 / 0.64 / 0.68 / 0.70 / 0.71 / 0.67 / 0.62**;
-// 4: 0.66 / 0.61 / 0.65 / 0.70 / 0.69 / 0.71 / 0.69 / 0.63; 5: 0.67 / 0.61 / 0.64 / 0.72 / 0.72 / 0.74 / 0.71 / 0.64; 6: 0.66 /
-// 0.62 / 0.65 / 0.72 / 0.74 / 0.75 / 0.71 / 0.64.  (Rounds 1-2 used 5 with the one-ray-per-lane straggler kernel, which took
-// 0.15-0.45 ms on the views of frames 100-250.)  PXT_NGP_ROUNDS=n (0 .. kMaxRounds) overrides the count: a ray's result
-// does not depend on it (tests/test_variants_gpu.py).
-// Round 5: with mip_from_dt's factor corrected (coarser occupancy cells from t = 1 on: +6 % samples per render) the rays
-// left after three rounds grew from ~1 % to 4 % of a render's samples on the benchmark object and far more on the
-// other config/*.sh boxes (the straggler kernel took 2.3 ms of a lock-step step's 14 ms of kernel time): 3 / 4 / 5 rounds =
-// 653 / 656 / 645 and 650 / 654 / 655 frames/s over 200 frames of the benchmark sequence (a tie), 817 / 904 / 905 frames/s
-// for the eight objects in lock-step (profiles/r05_experiments.md).  Four.
-constexpr int kRounds = 4, kBatchRounds = 6, kMaxRounds = 12;
-constexpr int kCtrStride = 16; // ints between round counters (separate 64-B lines)
+constexpr int kK = 8;          // samples per ray per step
+constexpr int kCtrWords = 16;  // ints per counter block (one 64-B line per pipe)
 
 struct Ray {
   float o[3], d[3], idir[3];
@@ -523,23 +512,12 @@ __device__ inline bool next_sample(const NgpParams& P, const Ray& r, float& t, f
   }
 }
 
-struct RayState {  // SoA, indexed by compact slot; two copies ping-pong between rounds
-  unsigned* rid;   // pixel * spp + spp_index
-  float* t;        // next lattice position
-  float* T;        // transmittance so far
-  float4* acc;     // premultiplied colour (or depth) + alpha so far
-  float* accd;     // mode 2 only: premultiplied depth so far
-};
-
-struct NgpWork {
-  RayState st[2];
-  int* counters;       // [(kMaxRounds + 2) * kCtrStride]: live rays entering round r
-  float4* spos;        // [slot * kK + k] = (x, y, z, dt); dt == 0 marks "no sample"
-  float* st_t;         // t of each sample (depth mode)
-  uint8_t* exhausted;  // per slot: the ray left the box during this round's march
-  uint8_t* keep[2];    // [round & 1] per slot: the ray continues into the next round (written by shade)
-  float4* raydir;      // [pixel * spp + s] = (unit direction, d . camera z): what shading needs of a ray
-  float4* sppbuf;      // [pixel][spp] finished rays
+struct NgpWork {       // one pipe: a slice of a render's ray enumeration
+  unsigned* rid;       // [slot] pixel * spp + spp_index of the slot's ray (the compact list raygen writes)
+  float* t0;           // [slot] its first lattice position
+  float4* dir;         // [slot] (unit direction, d . camera z)
+  int* counters;       // [0]: rays in the list
+  float4* sppbuf;      // [pixel][spp] finished rays (shared by the pipes of a render)
   float* sppbuf_d;     // mode 2: finished rays' depth
 };
 
@@ -587,28 +565,22 @@ __device__ inline float ray_start(const NgpParams& P, const Ray& r, int pix, int
   return t + ray_jitter(pix, s) * calc_dt(t, P.cone_angle, P.dt_lo, P.dt_hi);
 }
 
-// Order-preserving compaction of 2048-item tiles: ONE global atomic per tile (a single
-// counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue").
-// FROM_INIT: items are the enumerated rays, generated in place; else slots of the previous round.
+// Ray generation + order-preserving compaction of 2048-ray tiles: ONE global atomic per tile (a single
+// counter word sustains only ~90 atomics/us, MI355X_MICROARCH.md "dequeue").  Tiles land in the order of their atomics,
+// i.e. roughly in dispatch order: neighbours in the list are neighbours in the image.
+// (blk / nblk: this workgroup's index among the workgroups working on THIS pipe's slice.)
 constexpr int kTile = 2048;
-// (blk / nblk: this workgroup's index and the number of workgroups working on THIS pipeline's list - blockIdx.x /
-// gridDim.x of a launch that carries one pipeline, a share of the launch in the staged chain, ngp_stage_kernel)
-template <bool FROM_INIT>
-__device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWork& Wk, int round, int blk, int nblk) {
+__device__ __forceinline__ void ngp_raygen_body(const NgpParams& P, const NgpWork& Wk, int blk, int nblk) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
-  const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
-  const RayState& S = Wk.st[round & 1];
-  const RayState& D = FROM_INIT ? Wk.st[0] : Wk.st[(round + 1) & 1];
-  int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
+  const long long n = P.enum_hi - P.enum_lo;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long tiles = (n + kTile - 1) / kTile;
   for (long long tile = blk; tile < tiles; tile += nblk) {
     const long long i0 = tile * kTile + (long long)threadIdx.x * 8;
     bool k[8];
     int cnt = 0;
-    // FROM_INIT: the rays are generated here (no separate init pass, no candidate buffer).  A
-    // thread's 8 consecutive rays are the passes of one pixel when spp = 8: one make_ray for all.
+    // A thread's 8 consecutive rays are the passes of one pixel when spp = 8: one make_ray for all.
     float t_start[8];
     unsigned rid_new[8];
     int last_pix = -1;
@@ -617,26 +589,19 @@ __device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWo
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const long long i = i0 + j;
-      if (FROM_INIT) {
-        int px, py, sp;
-        k[j] = false;
-        t_start[j] = -1.f;
-        rid_new[j] = 0u;
-        if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
-          const int pix = py * P.W + px;
-          if (pix != last_pix) {
-            r = make_ray(P, px, py);
-            last_pix = pix;
-          }
-          t_start[j] = ray_start(P, r, pix, sp);
-          rid_new[j] = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
-          k[j] = t_start[j] >= 0.f;
-          // the shade kernel runs 8 lanes per ray per round: it reads the direction instead of
-          // redoing make_ray's fourteen divisions in every lane
-          if (k[j]) Wk.raydir[rid_new[j]] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
+      int px, py, sp;
+      k[j] = false;
+      t_start[j] = -1.f;
+      rid_new[j] = 0u;
+      if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
+        const int pix = py * P.W + px;
+        if (pix != last_pix) {
+          r = make_ray(P, px, py);
+          last_pix = pix;
         }
-      } else {
-        k[j] = i < n && Wk.keep[round & 1][i] != 0;
+        t_start[j] = ray_start(P, r, pix, sp);
+        rid_new[j] = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
+        k[j] = t_start[j] >= 0.f;
       }
       cnt += k[j] ? 1 : 0;
     }
@@ -654,303 +619,27 @@ __device__ __forceinline__ void ngp_compact_body(const NgpParams& P, const NgpWo
       if (w < wave) wave_off += s_wave[w];
       tile_total += s_wave[w];
     }
-    if (threadIdx.x == 0) s_base = tile_total ? atomicAdd(out_count, tile_total) : 0;
+    if (threadIdx.x == 0) s_base = tile_total ? atomicAdd(Wk.counters, tile_total) : 0;
     __syncthreads();
     int dst = s_base + wave_off + inc - cnt;
+    // the render kernel runs 8 lanes per ray: it reads the direction instead of redoing make_ray's fourteen divisions
+    const float4 rdir = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (!k[j]) continue;
-      const long long i = i0 + j;
-      if (FROM_INIT) {
-        D.rid[dst] = rid_new[j];
-        D.t[dst] = t_start[j];
-        D.T[dst] = 1.f;
-        D.acc[dst] = make_float4(0.f, 0.f, 0.f, 0.f);
-        D.accd[dst] = 0.f;
+      Wk.rid[dst] = rid_new[j];
+      Wk.t0[dst] = t_start[j];
+      // (a thread's kept rays share one pixel unless spp is not 8: then the ray is rebuilt for the pixel at hand)
+      if (P.spp == 8) {
+        Wk.dir[dst] = rdir;
       } else {
-        D.rid[dst] = S.rid[i];
-        D.t[dst] = S.t[i];
-        D.T[dst] = S.T[i];
-        D.acc[dst] = S.acc[i];
-        D.accd[dst] = S.accd[i];
+        const int pix = (int)(rid_new[j] / (unsigned)P.spp);
+        const Ray rr = make_ray(P, pix % P.W, pix / P.W);
+        Wk.dir[dst] = make_float4(rr.d[0], rr.d[1], rr.d[2], rr.zdot);
       }
       ++dst;
     }
     __syncthreads();
-  }
-}
-
-// A lane's next K = 8 samples: the ray walks its lattice as a flat state machine - one lattice point per loop trip, which
-// is either taken as the ray's next sample or skipped to the far side of its empty cell - so a wave makes
-// max-over-lanes(samples + empty cells) trips.  (The first version nested the empty-cell loop inside the loop over the K
-// samples: a wave then made sum-over-k max-over-lanes trips, every trip a dependent occupancy load; in-kernel stamps showed
-// a median wave at 25 us, the slowest at 110 us, and the launch waiting for those.  Rounds 4-5 also carried variants that
-// probed 2 / 4 / 8 lattice points per trip - bit-exact, a PN-th of the dependent loads, and no shorter launches: what a
-// march launch waits for is a CU slot beside the shade workgroups, not its own rays, profiles/r04_experiments.md #15 -
-// and an unfused march kernel; both were removed in round 6 with the launch path they belonged to.)
-__device__ __forceinline__ void ngp_march_lane(const NgpParams& P, const NgpWork& Wk, const Ray& r, size_t s0, float& t,
-                                               bool& out) {
-  int k = 0;
-  out = false;
-  while (k < kK) {
-    if (t >= r.tmax) { out = true; break; }
-    float pos[3], dt;
-    int mip;
-    if (probe_cell(P, r, t, pos, dt, mip)) {
-      Wk.spos[s0 + k] = make_float4(pos[0], pos[1], pos[2], dt);
-      Wk.st_t[s0 + k] = t;
-      t = t + dt;
-      ++k;
-    } else {
-      advance_past_cell(P, r, t, pos, mip);
-    }
-  }
-  for (; k < kK; ++k) Wk.spos[s0 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// Compaction of round r's survivors AND round r + 1's march in one launch: a workgroup compacts a tile of 256
-// slots (ballot + prefix, ONE atomic per tile for the tile's base, survivors keep their order inside the tile)
-// and every thread marches its own surviving ray straight away, writing to the ray's NEW slot.  Saves the
-// compaction launch of every round but the last (15-30 us each on a pipeline's serial chain).  Tiles land in
-// the order of their atomics, i.e. roughly in dispatch order: neighbours in the new list are still neighbours
-// in the image (unlike the per-wave queues tried in the shade kernel, profiles/r02_ngp_experiments.md #10).
-// FROM_INIT: the tile's items are enumerated rays generated in place (round 0: ray generation, box test,
-// compaction and the first march in one launch; every lane builds its own ray - the 8 passes of a pixel repeat
-// make_ray, which is cheaper than the launch it saves).
-template <bool FROM_INIT>
-__device__ __forceinline__ void ngp_compact_march_body(const NgpParams& P, const NgpWork& Wk, int round, int blk, int nblk) {
-  __shared__ int s_wave[4];
-  __shared__ int s_base;
-  const long long n = FROM_INIT ? (P.enum_hi - P.enum_lo) : (long long)Wk.counters[round * kCtrStride];
-  const RayState& S = Wk.st[round & 1];
-  const RayState& D = FROM_INIT ? Wk.st[0] : Wk.st[(round + 1) & 1];
-  int* out_count = Wk.counters + (FROM_INIT ? 0 : (round + 1) * kCtrStride);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long tiles = (n + 255) / 256;
-  for (long long tile = blk; tile < tiles; tile += nblk) {
-    const long long i = tile * 256 + threadIdx.x;
-    bool kept;
-    // the survivor's record is fetched (or the new ray built) while the tile's base is still being negotiated
-    unsigned rid = 0;
-    float t = 0.f, T_ = 1.f, accd_ = 0.f;
-    float4 acc_ = make_float4(0.f, 0.f, 0.f, 0.f);
-    Ray r;
-    if (FROM_INIT) {
-      int px, py, sp;
-      kept = false;
-      if (i < n && enum_ray(P, P.enum_lo + i, px, py, sp)) {
-        const int pix = py * P.W + px;
-        r = make_ray(P, px, py);
-        t = ray_start(P, r, pix, sp);
-        rid = (unsigned)pix * (unsigned)P.spp + (unsigned)sp;
-        kept = t >= 0.f;
-        // the shade kernel runs 8 lanes per ray per round: it reads the direction instead of redoing
-        // make_ray's fourteen divisions in every lane
-        if (kept) Wk.raydir[rid] = make_float4(r.d[0], r.d[1], r.d[2], r.zdot);
-      }
-    } else {
-      kept = i < n && Wk.keep[round & 1][i] != 0;
-      float4 rdir = make_float4(0.f, 0.f, 1.f, 0.f);
-      if (kept) {
-        rid = S.rid[i];
-        t = S.t[i];
-        T_ = S.T[i];
-        acc_ = S.acc[i];
-        accd_ = S.accd[i];
-        rdir = Wk.raydir[rid];
-      }
-      r = ray_from_record(P, rdir);
-    }
-    const unsigned long long m = __ballot(kept);
-    if (lane == 0) s_wave[wave] = __popcll(m);
-    __syncthreads();
-    int wave_off = 0, tile_total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) wave_off += s_wave[w];
-      tile_total += s_wave[w];
-    }
-    if (threadIdx.x == 0) s_base = tile_total ? atomicAdd(out_count, tile_total) : 0;
-    __syncthreads();
-    if (kept) {
-      const int slot = s_base + wave_off + __popcll(m & ((1ull << lane) - 1ull));
-      D.rid[slot] = rid;
-      D.T[slot] = T_;
-      D.acc[slot] = acc_;
-      D.accd[slot] = accd_;
-      bool out;
-      ngp_march_lane(P, Wk, r, (size_t)slot * kK, t, out);
-      D.t[slot] = t;
-      Wk.exhausted[slot] = out ? 1 : 0;
-    }
-    __syncthreads();
-  }
-}
-
-
-// Shared by the shade and tail kernels: close a finished ray.
-__device__ inline void finish_ray(const NgpWork& Wk, unsigned rid, float4 acc, bool terminated) {
-  if (terminated) {
-    acc.x /= acc.w; acc.y /= acc.w; acc.z /= acc.w; acc.w = 1.0f;
-  }
-  Wk.sppbuf[rid] = acc;
-}
-
-// One group of 8 rays x 8 samples (this wave's 64 lanes): the wave gathers the hash-grid features of its own 64
-// samples (all levels) and feeds them to the MLPs - no encoder launch, no feature round trip through HBM (16 x 4 B
-// written and read back per sample in the level-major design of round 1), and the gathers of one wave overlap the
-// matrix work of the others.  Render 0.92 -> 0.715 ms.  The level loop stays rolled (unrolled, all 128 gathers are
-// hoisted: 256 VGPRs, one wave per SIMD) and runs in two halves of 8 levels through an 8-KB LDS staging area, which
-// keeps Flo / Fhi on static register indices at 4 waves per SIMD.  Then both MLPs, in-order compositing,
-// termination; lane (rlane, k) handles sample k of the ray in `slot`.  A ray's result does not depend on which
-// rays share its group.
-// (sp, sample_t, exhausted: the lane's sample and whether its ray left the box during the march - from the march's
-// buffers in a wavefront round, straight from the marching lanes' registers in the straggler kernel.)  Returns whether the
-// ray goes on (the same value in the 8 lanes of a ray).
-template <int MODE>
-__device__ __forceinline__ bool ngp_shade_group_core(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
-                                                     const half8* s_w, unsigned* s_feat,
-                                                     const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
-                                                     int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples,
-                                                     const float4 sp, const float sample_t, const bool exhausted) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = lane & 7, rlane = lane >> 3;  // 8 rays x 8 samples per wave
-  const int sl = ray_ok ? slot : safe_slot;  // lanes beyond the list read a slot that is known to be filled
-  const float dt = ray_ok ? sp.w : 0.f;
-  const bool valid = dt != 0.f;
-  const unsigned rid = S.rid[sl];
-  const float4 rd = Wk.raydir[rid];
-  const float rdir[3] = {rd.x, rd.y, rd.z};
-  unsigned shB0[4], shB1[4];
-  sh_fragments(rdir, shB0, shB1);
-  unsigned Flo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Fhi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
-  // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
-  // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
-  if (__any(valid)) {
-    // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
-    float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
-    // the features pass through the lane's own LDS column
-    unsigned* col = s_feat + wave * (8 * 64) + lane;
-    // gather in ray-fastest lane order: lane 8 a + b fetches the sample of lane 8 b + a, so that adjacent lanes hold
-    // the same step of neighbouring rays (the passes of one pixel: positions a fraction of a step apart on one line)
-    // instead of consecutive steps of one ray: the address unit merges the lanes of a quad that share a line.
-    // Render 0.713 -> 0.676 ms.  (Rays ranked by distance within a step on top of that: 0.688, the ranking costs more.)
-    const int tl = ((lane & 7) << 3) | (lane >> 3);
-    ux = __shfl(ux, tl, 64); uy = __shfl(uy, tl, 64); uz = __shfl(uz, tl, 64);
-    unsigned* wcol = s_feat + wave * (8 * 64) + tl;
-#pragma unroll 4
-    for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
-    ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
-  }
-  // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
-  const float T0 = S.T[sl];
-  float alpha = 0.f;
-  if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
-  float depth = 0.f;
-  if (MODE != 0) depth = (sample_t * rd.w) * P.depth_scale;
-  if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
-  // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
-  float pinc = 1.0f - alpha;
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    const float o = __shfl_up(pinc, m, 8);
-    if (k >= m) pinc = pinc * o;
-  }
-  float pexc = __shfl_up(pinc, 1, 8);
-  if (k == 0) pexc = 1.0f;
-  const float T_before = T0 * pexc, T_after = T0 * pinc;
-  // the first sample after which T drops below the threshold ends the ray (it is included)
-  const bool ends = valid && (T_after < P.min_T);
-  const unsigned long long bal = __ballot(ends);
-  const unsigned grp = (unsigned)((bal >> (rlane * 8)) & 0xFFull);
-  const int k_term = grp ? (__ffs((int)grp) - 1) : 8;
-  const bool contributes = valid && k <= k_term;
-  const float wgt = contributes ? alpha * T_before : 0.f;
-  float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt, cd = wgt * depth;
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    cr += __shfl_xor(cr, m, 8);
-    cg += __shfl_xor(cg, m, 8);
-    cb += __shfl_xor(cb, m, 8);
-    ca += __shfl_xor(ca, m, 8);
-    if (MODE == 2) cd += __shfl_xor(cd, m, 8);
-  }
-  if (contributes) n_samples += 1;
-  // last valid sample's T_after (or the terminating one) is the ray's new transmittance
-  const unsigned long long vb = __ballot(valid);
-  const unsigned vgrp = (unsigned)((vb >> (rlane * 8)) & 0xFFull);
-  const int n_valid = __popc(vgrp);
-  const int k_last = grp ? k_term : n_valid - 1;
-  const float T_new = (k_last >= 0) ? __shfl(T_after, rlane * 8 + max(k_last, 0), 64) : T0;
-  if (k == 0 && ray_ok) {
-    float4 acc = S.acc[slot];
-    acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
-    float accd = 0.f;
-    if (MODE == 2) accd = S.accd[slot] + cd;
-    const bool terminated = grp != 0;
-    if (terminated || exhausted) {
-      if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
-      finish_ray(Wk, rid, acc, terminated);
-      keep_out[slot] = 0;
-    } else {  // the compaction kernel moves the survivors into the next round's list
-      S.T[slot] = T_new;
-      S.acc[slot] = acc;
-      if (MODE == 2) S.accd[slot] = accd;
-      keep_out[slot] = 1;
-    }
-  }
-  return ray_ok && !(grp != 0 || exhausted);
-}
-
-template <int MODE>
-__device__ __forceinline__ void ngp_shade_group(const NgpParams& P, const NgpWork& Wk, const RayState& S, uint8_t* keep_out,
-                                                const half8* s_w, unsigned* s_feat,
-                                                const __amdgpu_buffer_rsrc_t grid_rsrc, float enc_lo, float enc_inv,
-                                                int slot, bool ray_ok, int safe_slot, unsigned long long& n_samples) {
-  const int sl = ray_ok ? slot : safe_slot;
-  const size_t si = (size_t)sl * kK + (threadIdx.x & 7);
-  (void)ngp_shade_group_core<MODE>(P, Wk, S, keep_out, s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, ray_ok, safe_slot,
-                                   n_samples, Wk.spos[si], MODE != 0 ? Wk.st_t[si] : 0.f, Wk.exhausted[sl] != 0);
-}
-
-// s_w [kNumFrags * 64] / s_feat [4 * 8 * 64]: the workgroup's LDS areas (MLP weight fragments; feature staging), declared by
-// the kernel so that the modes' instantiations inside one kernel share them.
-template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one pass
-__device__ __forceinline__ void ngp_shade_body(const NgpParams& P, const NgpWork& Wk, int round, int blk, int nblk, half8* s_w,
-                                               unsigned* s_feat) {
-  // (the late rounds hold fewer groups than the grid has waves: those workgroups leave before copying the weights)
-  if (blk > 0 && blk * 32 >= Wk.counters[round * kCtrStride] + 7) return;
-  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
-  const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
-  const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
-  __syncthreads();
-  const int n = Wk.counters[round * kCtrStride];
-  const RayState& S = Wk.st[round & 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rlane = lane >> 3;
-  unsigned long long n_samples = 0;
-  const int n_groups = (n + 7) / 8;
-  for (int g = blk * 4 + wave; g < n_groups; g += nblk * 4) {
-    const int slot = g * 8 + rlane;
-    ngp_shade_group<MODE>(P, Wk, S, Wk.keep[round & 1], s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, slot < n, 0, n_samples);
-  }
-  if (P.stats) {  // one atomic per workgroup: a single counter word sustains ~90 atomics/us
-    __shared__ unsigned long long s_cnt[4];
-    for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
-    if (lane == 0) s_cnt[wave] = n_samples;
-    __syncthreads();
-    const unsigned long long tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (threadIdx.x == 0 && tot) atomicAdd(P.stats + 0, tot);
   }
 }
 
@@ -1037,85 +726,184 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
   exhausted = out;
 }
 
-// Stragglers.  Rays that outlive the wavefront rounds finish here: a WAVE holds 8 of them and repeats the rounds' own two
-// steps - every ray's next K = 8 lattice samples (ngp_march_group: the ray's 8 lanes probe 8 lattice points at a time), then
-// ngp_shade_group on the wave's 8 x 8 samples, the samples handed over in registers - and replaces a ray that has finished
-// by the next one of its share of the list.  The same arithmetic in the same grouping as a wavefront round, so a ray's result
-// does not depend on how many rounds ran before: any PXT_NGP_ROUNDS, 0 included (the whole render in this kernel), gives
-// the same image bit for bit.  Measured (render_both, ms, frames 0 / 100 / 150 / 200 of the orbit; PXT_NGP_TAIL_GRID
-// workgroups): 3 rounds + 1024: 0.63 0.69 0.68 0.69; 1 round + 4096: 0.65 0.68 0.68 0.68; 0 rounds + 1024 / 2048 / 4096 /
-// 8192: 0.85 0.81 0.76 0.79 / 0.75 0.72 0.68 0.69 / 0.69 0.69 0.65 0.67 / 0.72 0.69 0.66 0.67 - the one-kernel render matches
-// the rounds on the long views and loses 10 % on the short ones, and in the tracking loop (bench.py) 0 / 1 rounds lose 6-12 %.
-// (History: the first version was one ray per LANE with a fused march + encode + MLP step per sample: a wave took
-// max-over-64-lanes steps, and a view along the object's soft shell - 10-14 k rays left, frames 100-250 of the synthetic
-// orbit - spent 0.15-0.45 ms in it: render 0.63 -> 1.00 ms.  The second marched with one lane per ray: 0.70-0.72 ms on
-// those views, 0.75-0.80 with one round before it.)
-template <int MODE>
-__device__ __forceinline__ void ngp_tail_body(const NgpParams& P, const NgpWork& Wk, int round, int rays_per_wg, int blk, int nblk,
-                                              half8* s_w, unsigned* s_feat) {
-  const int n = Wk.counters[round * kCtrStride];
-  if (P.stats && blk == 0 && threadIdx.x == 0) {
-    atomicAdd(P.stats + 1, (unsigned long long)Wk.counters[0]);
-    atomicAdd(P.stats + 2, (unsigned long long)n);  // rays left for this kernel
-  }
-  // Workgroups that take part: one per `rays_per_wg` rays, at least gridDim.x / 4.  This kernel's workgroups live as long
-  // as their longest ray, and four of them fill a CU's registers: a full grid of them keeps the OTHER pipeline's next
-  // launches waiting for a slot (its 5-us compaction took 10-90 us beside this kernel), a small one leaves a long list
-  // to too few waves.
+// The render kernel's body: PERSISTENT waves over the ray list of one pipe.
+//
+// A wave holds 8 rays (ray position r = lane >> 3, its 8 lanes k = lane & 7) and repeats
+//   march   ngp_march_group: every ray's next K = 8 occupied lattice samples, lane k ends up with the ray's k-th sample;
+//   shade   the wave's 64 samples: hash-grid gathers (all levels) -> both MLPs on MFMA -> in-order compositing of each
+//           ray's 8 samples (8 consecutive lanes), early termination;
+//   refill  a ray position whose ray terminated or left the box takes the next ray of the wave's share of the list.
+// The gathers of one wave overlap the matrix work and the marching of the others (4 waves per SIMD).  The level loop stays
+// rolled (unrolled, all 128 gathers are hoisted: 256 VGPRs, one wave per SIMD) and runs in two halves of 8 levels through an
+// 8-KB LDS staging area, which keeps Flo / Fhi on static register indices.  What a ray carries from step to step -
+// position t, transmittance, premultiplied colour (+ depth) - lives in registers (replicated in its 8 lanes), its id,
+// direction and SH fragments are loaded / formed once per ray: a step's only memory traffic is the occupancy probes and the
+// table gathers.  A ray's result depends neither on which rays share its wave nor on the grid.
+//
+// A wave's rays: groups wave_id, wave_id + n_waves, ... of 8 consecutive list entries (the 8 passes of a pixel: 64 samples
+// on one line), handed to the wave's 8 ray positions in that order; a position whose ray has finished takes the next
+// one, so that the wave keeps shading 64 samples per step until its share of the list runs out.  (Shares drawn from a shared
+// counter instead, 64 entries per atomic: 0.85-1.4 ms per render against 0.63-0.70 - returning atomics on one word are served
+// one per ~100 ns, and the 4096 waves' first draw alone takes 0.4 ms.  The grid is larger than what is resident instead: the
+// dispatcher is the queue.)
+template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one march
+__device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWork& Wk, int rays_per_wg, int blk, int nblk,
+                                                half8* s_w, unsigned* s_feat) {
+  const int n = Wk.counters[0];
+  if (P.stats && blk == 0 && threadIdx.x == 0) atomicAdd(P.stats + 1, (unsigned long long)n);  // rays that hit the box
+  // Workgroups that take part: one per `rays_per_wg` rays, at least nblk / 4 (a short list spread over few waves is a
+  // long chain of steps per wave).
   const int n_wg = min(nblk, max(nblk / 4, (n + rays_per_wg - 1) / rays_per_wg));
   if (blk >= n_wg || blk * 32 >= n) return;  // (workgroup-uniform)
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
   const float enc_lo = 0.5f - P.aabb_scale * 0.5f, enc_inv = 1.0f / P.aabb_scale;
   __syncthreads();
-  const RayState& S = Wk.st[round & 1];
-  uint8_t* const keep = Wk.keep[round & 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rlane = lane >> 3, k0 = lane & 7;
+  const int rlane = lane >> 3, k = lane & 7;
   unsigned long long n_samples = 0;
-  // A wave's rays: groups wave_id, wave_id + n_waves, ... of 8 consecutive list entries, handed to the wave's 8 ray
-  // positions in that order; a position whose ray has finished takes the next one, so that the wave keeps shading 64
-  // samples per step until its share of the list runs out.  (Shares drawn from a shared counter instead, 64 entries per
-  // atomic: 0.85-1.4 ms per render against 0.63-0.70 - returning atomics on one word are served one per ~100 ns, and the
-  // 4096 waves' first draw alone takes 0.4 ms.  The grid is larger than what is resident instead: the dispatcher is the queue.)
   const int n_waves = n_wg * 4, wave_id = blk * 4 + wave;
   auto stream_slot = [&](int s) { return ((s >> 3) * n_waves + wave_id) * 8 + (s & 7); };
+  // ---- the lane's ray (the same in the 8 lanes of a ray position)
   int cursor = 8;
   int slot = stream_slot(rlane);
   bool alive = slot < n;
-  float t = alive ? S.t[slot] : 0.f;
-  const int safe = wave_id * 8;  // (the workgroup left above unless this exists)
+  float t = 0.f, T0 = 1.f, accd = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rd = make_float4(0.f, 0.f, 1.f, 0.f);
+  unsigned rid = 0u;
+  if (alive) {
+    t = Wk.t0[slot];
+    rid = Wk.rid[slot];
+    rd = Wk.dir[slot];
+  }
+  unsigned shB0[4], shB1[4];
+  {
+    const float rdir[3] = {rd.x, rd.y, rd.z};
+    sh_fragments(rdir, shB0, shB1);
+  }
+  unsigned* const col = s_feat + wave * (8 * 64) + lane;  // the features pass through the lane's own LDS column
+  // gather in ray-fastest lane order: lane 8 a + b fetches the sample of lane 8 b + a, so that adjacent lanes hold
+  // the same step of neighbouring rays (the passes of one pixel: positions a fraction of a step apart on one line)
+  // instead of consecutive steps of one ray: the address unit merges the lanes of a quad that share a line.
+  // Render 0.713 -> 0.676 ms.  (Rays ranked by distance within a step on top of that: 0.688, the ranking costs more.)
+  const int tl = ((lane & 7) << 3) | (lane >> 3);
+  unsigned* const wcol = s_feat + wave * (8 * 64) + tl;
   while (__any(alive)) {
+    // ---- march: the ray's next 8 samples; lane k gets the k-th
     float4 sp;
     float sample_t;
     bool exhausted;
     {
-      const Ray r = ray_from_record(P, Wk.raydir[S.rid[alive ? slot : safe]]);
+      const Ray r = ray_from_record(P, rd);
       ngp_march_group(P, r, alive, t, sp, sample_t, exhausted);
     }
-    alive = ngp_shade_group_core<MODE>(P, Wk, S, keep, s_w, s_feat, grid_rsrc, enc_lo, enc_inv, slot, alive, safe, n_samples,
-                                       sp, sample_t, exhausted);
-    // refill the free positions, lowest first
-    const unsigned long long dead = __ballot(!alive && k0 == 0);  // bit 8 r: ray position r is free
+    // ---- shade
+    const float dt = alive ? sp.w : 0.f;
+    const bool valid = dt != 0.f;
+    unsigned Flo[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, Fhi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    float logit = 0.f, rgbv[3] = {0.f, 0.f, 0.f};
+    // rays that crossed the box without meeting an occupied cell arrive with eight empty slots,
+    // and neighbouring rays share that fate: whole waves skip the MLPs (wave-uniform branch)
+    if (__any(valid)) {
+      // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
+      float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
+      ux = __shfl(ux, tl, 64); uy = __shfl(uy, tl, 64); uz = __shfl(uz, tl, 64);
+#pragma unroll 4
+      for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
+      __builtin_amdgcn_wave_barrier();  // (the next step's first-half writes must not overtake these reads)
+      ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
+    }
+    // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
+    float alpha = 0.f;
+    if (valid) alpha = 1.0f - expf(-expf(logit) * dt);
+    float depth = 0.f;
+    if (MODE != 0) depth = (sample_t * rd.w) * P.depth_scale;
+    if (MODE == 1) rgbv[0] = rgbv[1] = rgbv[2] = depth;
+    // inclusive product scan of (1 - alpha) over the 8 lanes of the ray
+    float pinc = 1.0f - alpha;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      const float o = __shfl_up(pinc, m, 8);
+      if (k >= m) pinc = pinc * o;
+    }
+    float pexc = __shfl_up(pinc, 1, 8);
+    if (k == 0) pexc = 1.0f;
+    const float T_before = T0 * pexc, T_after = T0 * pinc;
+    // the first sample after which T drops below the threshold ends the ray (it is included)
+    const bool ends = valid && (T_after < P.min_T);
+    const unsigned long long bal = __ballot(ends);
+    const unsigned grp = (unsigned)((bal >> (rlane * 8)) & 0xFFull);
+    const int k_term = grp ? (__ffs((int)grp) - 1) : 8;
+    const bool contributes = valid && k <= k_term;
+    const float wgt = contributes ? alpha * T_before : 0.f;
+    float cr = wgt * rgbv[0], cg = wgt * rgbv[1], cb = wgt * rgbv[2], ca = wgt, cd = wgt * depth;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      cr += __shfl_xor(cr, m, 8);
+      cg += __shfl_xor(cg, m, 8);
+      cb += __shfl_xor(cb, m, 8);
+      ca += __shfl_xor(ca, m, 8);
+      if (MODE == 2) cd += __shfl_xor(cd, m, 8);
+    }
+    if (contributes) n_samples += 1;
+    // last valid sample's T_after (or the terminating one) is the ray's new transmittance
+    const unsigned long long vb = __ballot(valid);
+    const unsigned vgrp = (unsigned)((vb >> (rlane * 8)) & 0xFFull);
+    const int n_valid = __popc(vgrp);
+    const int k_last = grp ? k_term : n_valid - 1;
+    const float T_new = (k_last >= 0) ? __shfl(T_after, rlane * 8 + max(k_last, 0), 64) : T0;
+    if (alive) {
+      acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
+      if (MODE == 2) accd = accd + cd;
+      const bool terminated = grp != 0;
+      if (terminated || exhausted) {  // close the ray: one lane stores
+        if (k == 0) {
+          if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
+          float4 o = acc;
+          if (terminated) {
+            o.x /= o.w; o.y /= o.w; o.z /= o.w; o.w = 1.0f;
+          }
+          Wk.sppbuf[rid] = o;
+        }
+        alive = false;
+      } else {
+        T0 = T_new;
+      }
+    }
+    // ---- refill the free positions, lowest first
+    const unsigned long long dead = __ballot(!alive && k == 0);  // bit 8 r: ray position r is free
     if (dead) {
       const int rank = __popcll(dead & ((1ull << (rlane * 8)) - 1ull));
       if (!alive) {
         const int ns = stream_slot(cursor + rank);
         if (ns < n) {
-          slot = ns;
           alive = true;
-          t = S.t[slot];
+          t = Wk.t0[ns];
+          rid = Wk.rid[ns];
+          rd = Wk.dir[ns];
+          T0 = 1.f;
+          acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          accd = 0.f;
         }
       }
       cursor += __popcll(dead);
+      const float rdir[3] = {rd.x, rd.y, rd.z};
+      sh_fragments(rdir, shB0, shB1);  // (all lanes: the fragments are formed with cross-lane swaps)
     }
   }
   if (P.stats) {
     for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
-    if (lane == 0 && n_samples) {
-      atomicAdd(P.stats + 0, n_samples);
-      atomicAdd(P.stats + 3, n_samples);  // ... of which composited here, not by the rounds' shade launches
-    }
+    if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
   }
 }
 
@@ -1149,7 +937,7 @@ struct NgpCounterList { int* p[4]; int n; };
 __device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWork& Wk, const NgpCounterList& zl, int blk) {
   if (blk == 0)
     for (int w = 0; w < zl.n; ++w)
-      for (int i = threadIdx.x; i < (kMaxRounds + 2) * kCtrStride; i += 256) zl.p[w][i] = 0;
+      for (int i = threadIdx.x; i < kCtrWords; i += 256) zl.p[w][i] = 0;
   // One lane per pixel: it reads the pixel's spp finished rays (contiguous: 16 B x spp, whole lines per lane)
   // and adds them in pass order - the fixed order of a sequential mean.  All passes of a pixel share one ray
   // (snap_to_pixel_centers), so a pixel whose ray misses the box has no finished rays to read: nothing
@@ -1219,45 +1007,21 @@ __device__ __forceinline__ void ngp_resolve_body(const NgpParams& P, const NgpWo
   if (P.out_nz && P.mode != 0) P.out_nz[pix] = (((long long)(depth_x * 255.0f) & 255) != 0) ? 1 : 0;
 }
 
-// ---- the launches: a STAGED CHAIN on one stream (round 6).
-//
-// A render is cut into PIPES (one for a small render, two halves of the ray enumeration otherwise); a chain carries the
-// pipes of one render, of a frame's two renders (the mask's Depth at the query camera + the reference image's Shade at the
-// reference camera, pixtrack/pose_trackers/pixloc_tracker_r9.py:145-152,207-214) or of K objects tracked in lock-step.
-// A pipe's stages depend on each other - generate + march, shade, compact + march, shade, ..., stragglers - but pipes do
-// not, and the two kinds of stage want different things of the chip: the march is a chain of dependent occupancy loads
-// (latency), the shade kernel is bound by the issue of its gathers.  Rounds 2-5 ran the halves as two chains on two HIP
-// streams (a third stream for a frame's second render) and left the overlap to how HIP deals streams to hardware queues:
-// the same command measured 396 and 544 frames/s on two boxes of one pool.  Here the overlap is
-// written down: the pipes are dealt to two PHASES one stage apart, and ONE launch carries a stage of every pipe - phase
-// A's shade beside phase B's march, then A's compaction + march beside B's shade, ... - with the workgroups of the launch
-// dealt to the pipes in an interleaved pattern (8 consecutive workgroups - one per XCD - to a pipe, then the next pipe),
-// so that what is resident at any time is a mix of both kinds.  No side stream, no event, nothing for a queue
-// assignment to decide; and a ray's result never depended on which rays share its launches: every image is bit for bit
-// what the separate launches produced.
-constexpr int kMaxChainPipes = 2 * PXT_NGP_MAX_BATCH;
-constexpr int kMaxSlots = 128;
-enum NgpRole : unsigned char {
-  kRoleIdle = 0, kRoleInitMarch, kRoleInitCompact, kRoleCompactMarch, kRoleCompact, kRoleShade
-};
+// ---- the launches.  blockIdx.y = pipe: a render is cut into pipes (slices of its ray enumeration, one by default), a chain
+// carries the pipes of one render, of a frame's two renders (the mask's Depth at the query camera + the reference image's
+// Shade at the reference camera, pixtrack/pose_trackers/pixloc_tracker_r9.py:145-152,207-214) or of K objects tracked in
+// lock-step - every launch carries all of them.  The pipes' parameter records travel by value in the kernel-argument segment
+// while they fit (<= 4: a render, a frame's pair), else they sit in device memory (uploaded from a pinned ring ahead of the
+// chain).  Read-only for the whole chain and addressed uniformly per workgroup: scalar loads either way.
+// (By value they MUST be the kernel's first parameter: the kernels address them through the kernel-argument segment
+// pointer - indexing the by-value aggregate itself makes the compiler copy all of it to scratch first, 3 KB per lane.  In
+// memory the pointer is a __restrict__ kernel parameter, which is what lets the compiler keep the loads scalar.)
+constexpr int kMaxChainPipes = 4 * PXT_NGP_MAX_BATCH;  // (pxt_ngp::kMaxPipes per render)
 struct NgpBatchItem {
   NgpParams P;
   NgpWork W;
   NgpCounterList zl;
 };
-// One launch of the chain (kernel argument).  A pipe with multiplicity m runs m * rows * 8 workgroups: chunk c = 8
-// consecutive workgroups belongs to slot c % n_slots, a pipe owns m slots.
-struct NgpStage {
-  int n_slots, rows;
-  unsigned char slot_pipe[kMaxSlots], slot_sub[kMaxSlots];
-  unsigned char mult[kMaxChainPipes], role[kMaxChainPipes], round[kMaxChainPipes];
-};
-// The pipes' parameter records: by value in the kernel-argument segment while they fit (<= 4 pipes: a render, a frame's
-// pair), else in device memory (K objects in lock-step; uploaded from a pinned ring ahead of the chain).  Read-only for
-// the whole chain and addressed uniformly per workgroup: scalar loads either way.
-// (By value they MUST be the kernel's first parameter: the kernels address them through the kernel-argument segment
-// pointer - indexing the by-value aggregate itself makes the compiler copy all of it to scratch first, 3 KB per lane.  In
-// memory the pointer is a __restrict__ kernel parameter, which is what lets the compiler keep the loads scalar.)
 template <int NV>
 struct NgpItemsByValue {
   NgpBatchItem it[NV];
@@ -1266,66 +1030,34 @@ __device__ __forceinline__ const NgpBatchItem& ngp_kernarg_item(int i) {
   return ((const NgpBatchItem*)__builtin_amdgcn_kernarg_segment_ptr())[i];
 }
 
-// MODES: 0 / 1 / 2 = every pipe of the chain renders in that mode; 3 = per pipe (P.mode; a frame's Depth + Shade pair).
-template <int MODES>
-__device__ __forceinline__ void ngp_stage_impl(const NgpBatchItem& it, int role, int round, int blk, int nblk, half8* s_w,
-                                               unsigned* s_feat) {
-  const int mode = MODES == 3 ? it.P.mode : MODES;
-  switch (role) {
-    case kRoleInitMarch: ngp_compact_march_body<true>(it.P, it.W, round, blk, nblk); break;
-    case kRoleInitCompact: ngp_compact_body<true>(it.P, it.W, round, blk, nblk); break;
-    case kRoleCompactMarch: ngp_compact_march_body<false>(it.P, it.W, round, blk, nblk); break;
-    case kRoleCompact: ngp_compact_body<false>(it.P, it.W, round, blk, nblk); break;
-    case kRoleShade:
-      if (mode == 0) ngp_shade_body<0>(it.P, it.W, round, blk, nblk, s_w, s_feat);
-      else if (mode == 1) ngp_shade_body<1>(it.P, it.W, round, blk, nblk, s_w, s_feat);
-      else ngp_shade_body<2>(it.P, it.W, round, blk, nblk, s_w, s_feat);
-      break;
-    default: break;
-  }
+__global__ __launch_bounds__(256) void ngp_raygen_kernel_v(const NgpItemsByValue<4> items) {
+  const NgpBatchItem& it = ngp_kernarg_item(blockIdx.y);
+  ngp_raygen_body(it.P, it.W, blockIdx.x, gridDim.x);
 }
-#define PXT_NGP_STAGE_PROLOGUE                                                              \
-  __shared__ half8 s_w[kNumFrags * 64];                                                     \
-  __shared__ unsigned s_feat[4 * 8 * 64];                                                   \
-  const int chunk = blockIdx.x >> 3;                                                        \
-  const int slot = chunk % st.n_slots;                                                      \
-  const int pipe = st.slot_pipe[slot];                                                      \
-  const int m = st.mult[pipe];                                                              \
-  const int blk = ((chunk / st.n_slots) * m + st.slot_sub[slot]) * 8 + (blockIdx.x & 7);    \
-  const int nblk = st.rows * m * 8;
-template <int MODES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_stage_kernel_v(const NgpItemsByValue<4> items,
-                                                                                                  const NgpStage st) {
-  PXT_NGP_STAGE_PROLOGUE
-  ngp_stage_impl<MODES>(ngp_kernarg_item(pipe), st.role[pipe], st.round[pipe], blk, nblk, s_w, s_feat);
-}
-template <int MODES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_stage_kernel_m(
-    const NgpBatchItem* __restrict__ items, const NgpStage st) {
-  PXT_NGP_STAGE_PROLOGUE
-  ngp_stage_impl<MODES>(items[pipe], st.role[pipe], st.round[pipe], blk, nblk, s_w, s_feat);
+__global__ __launch_bounds__(256) void ngp_raygen_kernel_m(const NgpBatchItem* __restrict__ items) {
+  const NgpBatchItem& it = items[blockIdx.y];
+  ngp_raygen_body(it.P, it.W, blockIdx.x, gridDim.x);
 }
 
-// The stragglers of every pipe of the chain in one launch: blockIdx.y = pipe.  (Its own kernel: the straggler loop holds
-// the march AND the shade state of a wave, ~10 VGPRs more than the stage kernel's widest stage takes.)
+// MODES: 0 / 1 / 2 = every pipe of the chain renders in that mode; 3 = per pipe (P.mode; a frame's Depth + Shade pair).
 template <int MODES>
-__device__ __forceinline__ void ngp_tail_impl(const NgpBatchItem& it, int round, int rays_per_wg) {
+__device__ __forceinline__ void ngp_render_impl(const NgpBatchItem& it, int rays_per_wg) {
   __shared__ half8 s_w[kNumFrags * 64];
   __shared__ unsigned s_feat[4 * 8 * 64];
   const int mode = MODES == 3 ? it.P.mode : MODES;
-  if (mode == 0) ngp_tail_body<0>(it.P, it.W, round, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
-  else if (mode == 1) ngp_tail_body<1>(it.P, it.W, round, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
-  else ngp_tail_body<2>(it.P, it.W, round, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
+  if (mode == 0) ngp_render_body<0>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
+  else if (mode == 1) ngp_render_body<1>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
+  else ngp_render_body<2>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
 }
 template <int MODES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_tail_kernel_v(const NgpItemsByValue<4> items,
-                                                                                                 int round, int rays_per_wg) {
-  ngp_tail_impl<MODES>(ngp_kernarg_item(blockIdx.y), round, rays_per_wg);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_render_kernel_v(const NgpItemsByValue<4> items,
+                                                                                                   int rays_per_wg) {
+  ngp_render_impl<MODES>(ngp_kernarg_item(blockIdx.y), rays_per_wg);
 }
 template <int MODES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_tail_kernel_m(
-    const NgpBatchItem* __restrict__ items, int round, int rays_per_wg) {
-  ngp_tail_impl<MODES>(items[blockIdx.y], round, rays_per_wg);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_render_kernel_m(
+    const NgpBatchItem* __restrict__ items, int rays_per_wg) {
+  ngp_render_impl<MODES>(items[blockIdx.y], rays_per_wg);
 }
 
 // blockIdx.y = render (the items here are per RENDER: the whole view, the shared per-ray result buffers, every counter block)
@@ -1559,15 +1291,13 @@ extern "C" int pxt_ngp_query(pxt_ngp* ctx, const float* pos, const float* dir, i
   return PXT_OK;
 }
 
-// Carves the wavefront scratch for `rays` rays out of one allocation (grown on demand).  Per-pipe buffers (live-ray state,
-// samples) hold the pipe's whole slice of the rays (every ray of a slice may hit the box): `cap` = the largest slice; the
-// per-ray result buffers indexed by ray id (finished passes, direction records) are shared by the pipes of the render.
-// (The first version sized the per-pipe buffers for half the rays whatever the number of pipes: a one-pipe render - any
-// render below 2^19 rays - whose camera sees the box in more than half of its pixels wrote past them.)
+// Carves the renderer's scratch for `rays` rays out of one allocation (grown on demand).  Per-pipe: the ray list (id,
+// start, direction) sized for the pipe's whole slice of the rays (every ray of a slice may hit the box: `cap` = the largest
+// slice) and a counter block; the per-ray result buffers indexed by ray id are shared by the pipes of the render.
 static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
   size_t cap = (rays + (size_t)n_pipe - 1) / (size_t)n_pipe + 2 * kTile;
   if (ctx->scratch && ctx->scratch_rays >= rays && ctx->scratch_cap >= cap && ctx->scratch_pipes >= n_pipe) return PXT_OK;
-  // grow only: a context that alternates between pipe counts (bench: the isolated one-pipe pass) keeps the larger layout
+  // grow only: a context that alternates between pipe counts keeps the larger layout
   cap = std::max(cap, ctx->scratch_cap);
   n_pipe = std::max(n_pipe, ctx->scratch_pipes);
   rays = std::max(rays, ctx->scratch_rays);
@@ -1578,43 +1308,25 @@ static int ensure_scratch(pxt_ngp* ctx, size_t rays, int n_pipe) {
     ctx->scratch = nullptr;
   }
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  const int kP = n_pipe;
-  const size_t half = cap;
-  const size_t samples = half * kK;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = al(off + bytes); return o; };
-  struct Offs {
-    size_t rid[2], t[2], T[2], acc[2], accd[2], cnt, spos, stt, exh, keep;
-  } o[pxt_ngp::kMaxPipes];
-  for (int w = 0; w < kP; ++w) {
-    for (int i = 0; i < 2; ++i) {
-      o[w].rid[i] = take(half * 4); o[w].t[i] = take(half * 4); o[w].T[i] = take(half * 4);
-      o[w].acc[i] = take(half * 16); o[w].accd[i] = take(half * 4);
-    }
-    o[w].cnt = take((kMaxRounds + 2) * kCtrStride * sizeof(int));
-    o[w].spos = take(samples * 16); o[w].stt = take(samples * 4);
-    o[w].exh = take(half); o[w].keep = take(2 * al(half));
+  struct Offs { size_t rid, t0, dir, cnt; } o[pxt_ngp::kMaxPipes];
+  for (int w = 0; w < n_pipe; ++w) {
+    o[w].rid = take(cap * 4); o[w].t0 = take(cap * 4); o[w].dir = take(cap * 16);
+    o[w].cnt = take(kCtrWords * sizeof(int));
   }
-  const size_t o_sppd = take(rays * 4), o_spp = take(rays * 16), o_rdir = take(rays * 16);
+  const size_t o_sppd = take(rays * 4), o_spp = take(rays * 16);
   hipError_t e = hipMalloc(&ctx->scratch, off);
   if (e != hipSuccess) { set_last_error("hipMalloc(ngp scratch)", e); ctx->scratch_rays = 0; return PXT_E_HIP; }
   char* b = (char*)ctx->scratch;
-  for (int w = 0; w < kP; ++w) {
+  for (int w = 0; w < n_pipe; ++w) {
     NgpWork& W = ctx->work[w];
-    for (int i = 0; i < 2; ++i) {
-      W.st[i].rid = (unsigned*)(b + o[w].rid[i]); W.st[i].t = (float*)(b + o[w].t[i]);
-      W.st[i].T = (float*)(b + o[w].T[i]); W.st[i].acc = (float4*)(b + o[w].acc[i]);
-      W.st[i].accd = (float*)(b + o[w].accd[i]);
-    }
+    W.rid = (unsigned*)(b + o[w].rid);
+    W.t0 = (float*)(b + o[w].t0);
+    W.dir = (float4*)(b + o[w].dir);
     W.counters = (int*)(b + o[w].cnt);
-    W.spos = (float4*)(b + o[w].spos);
-    W.st_t = (float*)(b + o[w].stt);
-    W.exhausted = (uint8_t*)(b + o[w].exh);
-    W.keep[0] = (uint8_t*)(b + o[w].keep);
-    W.keep[1] = W.keep[0] + al(half);
     W.sppbuf = (float4*)(b + o_spp);
     W.sppbuf_d = (float*)(b + o_sppd);
-    W.raydir = (float4*)(b + o_rdir);
   }
   ctx->scratch_rays = rays;
   ctx->scratch_cap = cap;
@@ -1651,7 +1363,7 @@ static int fill_view(const pxt_ngp* ctx, const pxt_ngp_view* v, int mode, float*
   return PXT_OK;
 }
 
-// ---- the staged chain (see ngp_stage_kernel): host side.
+// ---- a chain of K renders: raygen -> render -> resolve, each ONE launch for all pipes of all K renders.
 namespace {
 
 struct ChainRender {
@@ -1665,35 +1377,6 @@ int env_int(const char* name, int dflt, int lo, int hi) {
   return e ? std::min(std::max(atoi(e), lo), hi) : dflt;
 }
 
-// Workgroups per pipe and stage, wavefront rounds before the straggler stage.  One render / a frame's pair: the grids the
-// single launches had per pipeline (grid-stride kernels: full grids measured best, rounds 3-5).  K >= 3 objects in
-// lock-step: a launch's first object would fill the chip alone with those (profiles/r05_experiments.md #16: 512 / 1024 per
-// object measured best of 128 ... 2048) - per half-object pipe half of that - and six rounds (a round of the chain is one
-// launch for all objects, and the config/*.sh objects keep more rays alive than the benchmark object).
-struct ChainTune {
-  int g_init, g_march, g_shade, g_compact, g_tail, tail_div, n_rounds;
-};
-ChainTune chain_tune(int n_renders, int pipes_per_render) {
-  static const int e_init = env_int("PXT_NGP_G_INIT", 0, 0, 8192), e_march = env_int("PXT_NGP_G_MARCH", 0, 0, 8192),
-                   e_shade = env_int("PXT_NGP_G_SHADE", 0, 0, 8192), e_compact = env_int("PXT_NGP_G_COMPACT", 0, 0, 8192),
-                   e_tail = env_int("PXT_NGP_TAIL_GRID", 0, 0, 8192), e_div = env_int("PXT_NGP_TAIL_DIV", 64, 1, 1 << 20),
-                   e_rounds = env_int("PXT_NGP_ROUNDS", -1, -1, kMaxRounds),
-                   e_brounds = env_int("PXT_NGP_BATCH_ROUNDS", -1, -1, kMaxRounds);
-  ChainTune t;
-  if (n_renders <= 2) {
-    t = {4096, 2048, 2048, 1024, 1024, e_div, e_rounds >= 0 ? e_rounds : kRounds};
-  } else {
-    const int d = pipes_per_render > 1 ? 2 : 1;
-    t = {1024 / d, 512 / d, 1024 / d, 1024 / d, 1024 / d, e_div, e_brounds >= 0 ? e_brounds : (e_rounds >= 0 ? e_rounds : kBatchRounds)};
-  }
-  if (e_init) t.g_init = e_init;
-  if (e_march) t.g_march = e_march;
-  if (e_shade) t.g_shade = e_shade;
-  if (e_compact) t.g_compact = e_compact;
-  if (e_tail) t.g_tail = e_tail;
-  return t;
-}
-
 struct NgpStageSlot {
   NgpBatchItem* host = nullptr;
   hipEvent_t copied = nullptr;
@@ -1701,65 +1384,38 @@ struct NgpStageSlot {
 constexpr int kNgpStageSlots = 4;
 constexpr int kChainItems = kMaxChainPipes + PXT_NGP_MAX_BATCH;  // pipe records, then one record per render (resolve)
 
-// (items: by value when `pv` is given, else the device records `pm`)
-void launch_stage(int modes, const NgpItemsByValue<4>* pv, const NgpBatchItem* pm, const NgpStage& st, hipStream_t s) {
-  const dim3 grid(st.n_slots * st.rows * 8), blk(256);
-#define PXT_LAUNCH_STAGE(M)                                                                  \
-  if (pv) hipLaunchKernelGGL(ngp_stage_kernel_v<M>, grid, blk, 0, s, *pv, st);               \
-  else hipLaunchKernelGGL(ngp_stage_kernel_m<M>, grid, blk, 0, s, pm, st);
-  switch (modes) {
-    case 0: PXT_LAUNCH_STAGE(0) break;
-    case 1: PXT_LAUNCH_STAGE(1) break;
-    case 2: PXT_LAUNCH_STAGE(2) break;
-    default: PXT_LAUNCH_STAGE(3) break;
-  }
-#undef PXT_LAUNCH_STAGE
-}
-void launch_tail(int modes, const NgpItemsByValue<4>* pv, const NgpBatchItem* pm, dim3 grid, int round, int rays_per_wg,
-                 hipStream_t s) {
+void launch_render(int modes, const NgpItemsByValue<4>* pv, const NgpBatchItem* pm, dim3 grid, int rays_per_wg, hipStream_t s) {
   const dim3 blk(256);
-#define PXT_LAUNCH_TAIL(M)                                                                               \
-  if (pv) hipLaunchKernelGGL(ngp_tail_kernel_v<M>, grid, blk, 0, s, *pv, round, rays_per_wg);            \
-  else hipLaunchKernelGGL(ngp_tail_kernel_m<M>, grid, blk, 0, s, pm, round, rays_per_wg);
+#define PXT_LAUNCH_RENDER(M)                                                                       \
+  if (pv) hipLaunchKernelGGL(ngp_render_kernel_v<M>, grid, blk, 0, s, *pv, rays_per_wg);           \
+  else hipLaunchKernelGGL(ngp_render_kernel_m<M>, grid, blk, 0, s, pm, rays_per_wg);
   switch (modes) {
-    case 0: PXT_LAUNCH_TAIL(0) break;
-    case 1: PXT_LAUNCH_TAIL(1) break;
-    case 2: PXT_LAUNCH_TAIL(2) break;
-    default: PXT_LAUNCH_TAIL(3) break;
+    case 0: PXT_LAUNCH_RENDER(0) break;
+    case 1: PXT_LAUNCH_RENDER(1) break;
+    case 2: PXT_LAUNCH_RENDER(2) break;
+    default: PXT_LAUNCH_RENDER(3) break;
   }
-#undef PXT_LAUNCH_TAIL
+#undef PXT_LAUNCH_RENDER
 }
 
-// The stage of a pipe `step` launches after its first: generate + march, then per round shade and compaction (+ the next
-// round's march), the stragglers last.  (n_rounds = 0: generate + compact, then the straggler stage does the whole render.)
-void stage_of(int step, int n_rounds, unsigned char& role, unsigned char& round) {
-  role = kRoleIdle;
-  round = 0;
-  if (step < 0) return;
-  if (step == 0) { role = n_rounds > 0 ? kRoleInitMarch : kRoleInitCompact; return; }
-  const int r = (step - 1) >> 1;
-  if (r >= n_rounds) return;
-  round = (unsigned char)r;
-  if ((step - 1) & 1) role = (r + 1 < n_rounds) ? kRoleCompactMarch : kRoleCompact;
-  else role = kRoleShade;
-}
-
-// The chain for K renders on stream s0.  ws_dev: device memory for the parameter records when they do not fit the
-// kernel-argument segment (more than 4 pipes), else unused.
+// ws_dev: device memory for the parameter records when they do not fit the kernel-argument segment (more than 4 pipes).
 int run_chain(ChainRender* R, int K, hipStream_t s0, void* ws_dev) {
-  static const int env_pipes = env_int("PXT_NGP_PIPES", 2, 1, pxt_ngp::kMaxPipes);
-  static const int env_batch_pipes = env_int("PXT_NGP_BATCH_PIPES", 2, 1, 2);
-  static const int env_skew = env_int("PXT_NGP_SKEW", 1, 0, 1);
-  struct Pipe { int render, w, phase; };
+  // Workgroups of the render kernel per pipe (PXT_NGP_GRID) and rays per workgroup below which fewer take part
+  // (PXT_NGP_GRID_DIV): measured on the benchmark view (640 x 480 x 8 spp, ~345 k rays in the list, 4 waves per SIMD = 1024
+  // resident workgroups): 2048 / 3072 / 4096 / 6144 / 8192 workgroups = 0.75 / 0.71 / 0.68 / 0.71 / 0.74 ms per render
+  // (profiles/r06_experiments.md).  The grid is the queue: more waves than are resident, each with a short share.
+  static const int g_render = env_int("PXT_NGP_GRID", 4096, 64, 16384), g_div = env_int("PXT_NGP_GRID_DIV", 64, 1, 1 << 20),
+                   g_raygen = env_int("PXT_NGP_GRID_RAYGEN", 1024, 64, 8192);
+  static const int env_pipes = env_int("PXT_NGP_PIPES", 1, 1, pxt_ngp::kMaxPipes);
+  struct Pipe { int render, w; };
   Pipe pipes[kMaxChainPipes];
   int n_pipes = 0, n_per[PXT_NGP_MAX_BATCH];
   for (int k = 0; k < K; ++k) {
     pxt_ngp* ctx = R[k].ctx;
-    const int want = K <= 2 ? (ctx->pipelines > 0 ? ctx->pipelines : env_pipes) : env_batch_pipes;
-    n_per[k] = R[k].rays >= ((size_t)1 << 19) ? std::min(std::max(want, 1), pxt_ngp::kMaxPipes) : 1;
+    n_per[k] = std::min(std::max(ctx->pipelines > 0 ? ctx->pipelines : env_pipes, 1), pxt_ngp::kMaxPipes);
     if (n_pipes + n_per[k] > kMaxChainPipes) return PXT_E_ARG;
     if (const int rc = ensure_scratch(ctx, R[k].rays, n_per[k])) return rc;
-    for (int w = 0; w < n_per[k]; ++w, ++n_pipes) pipes[n_pipes] = {k, w, env_skew ? (n_pipes & 1) : 0};
+    for (int w = 0; w < n_per[k]; ++w, ++n_pipes) pipes[n_pipes] = {k, w};
   }
   const bool by_value = n_pipes <= 4;
   if (!by_value && !ws_dev) return PXT_E_ARG;
@@ -1767,7 +1423,7 @@ int run_chain(ChainRender* R, int K, hipStream_t s0, void* ws_dev) {
   static thread_local NgpStageSlot stage[16][kNgpStageSlots];
   static thread_local int stage_next[16] = {0};
   NgpItemsByValue<4> pv{}, rv{};  // (by_value: pipes / renders)
-  NgpBatchItem* rec = nullptr;  // (!by_value: the pinned staging block, pipes then renders)
+  NgpBatchItem* rec = nullptr;    // (!by_value: the pinned staging block, pipes then renders)
   NgpStageSlot* slot = nullptr;
   if (!by_value) {
     int dev_id = 0;
@@ -1797,7 +1453,7 @@ int run_chain(ChainRender* R, int K, hipStream_t s0, void* ws_dev) {
     for (int w = 0; w < 4; ++w) ri.zl.p[w] = w < ri.zl.n ? ctx->work[w].counters : nullptr;
     if (!ctx->counters_clean)
       for (int w = 0; w < ctx->scratch_pipes; ++w)
-        PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, (kMaxRounds + 2) * kCtrStride * sizeof(int), s0));
+        PXT_HIP_CHECK(hipMemsetAsync(ctx->work[w].counters, 0, kCtrWords * sizeof(int), s0));
     ctx->counters_clean = false;  // (an error return below leaves them to the next render's memsets)
   }
   for (int p = 0; p < n_pipes; ++p) {
@@ -1818,85 +1474,32 @@ int run_chain(ChainRender* R, int K, hipStream_t s0, void* ws_dev) {
     pm = (const NgpBatchItem*)ws_dev;
     rm = pm + n_pipes;
   }
-  const ChainTune tune = chain_tune(K, n_per[0]);
-  const int n_rounds = tune.n_rounds;
-  const int max_phase = (n_pipes > 1 && env_skew) ? 1 : 0;
-  const int last_step = 2 * n_rounds;               // a pipe's last stage before the stragglers
-  const int j_end = last_step + max_phase;          // (the stragglers of every pipe follow in ONE launch: a straggler
-                                                    // workgroup lives as long as its longest ray; two launches = two waits)
+  const dim3 blk(256);
+  if (by_value) hipLaunchKernelGGL(ngp_raygen_kernel_v, dim3(g_raygen, n_pipes), blk, 0, s0, pv);
+  else hipLaunchKernelGGL(ngp_raygen_kernel_m, dim3(g_raygen, n_pipes), blk, 0, s0, pm);
+  // the render launch is the one the timing events bracket (bench.py's roofline)
   pxt_ngp* tctx = R[0].ctx;
   const bool timed = K == 1 && tctx->timing > 0 && (tctx->renders++ % tctx->timing) == 0;
-  for (int j = 0; j <= j_end; ++j) {
-    NgpStage st;
-    std::memset(&st, 0, sizeof(st));
-    int g_of[kMaxChainPipes], g_min = 1 << 30, n_active = 0;
-    bool has_shade = false;
-    for (int p = 0; p < n_pipes; ++p) {
-      unsigned char role, round;
-      stage_of(j - pipes[p].phase, n_rounds, role, round);
-      st.role[p] = role;
-      st.round[p] = round;
-      g_of[p] = 0;
-      if (role == kRoleIdle) continue;
-      g_of[p] = role == kRoleInitMarch ? tune.g_init : role == kRoleCompactMarch ? tune.g_march : role == kRoleShade ? tune.g_shade
-                                                                                                                   : tune.g_compact;
-      g_of[p] = std::max(g_of[p], 64);
-      g_min = std::min(g_min, g_of[p]);
-      has_shade = has_shade || role == kRoleShade;
-      ++n_active;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    if (tctx->pool.empty()) {
+      PXT_HIP_CHECK(hipEventCreate(&e0));
+      PXT_HIP_CHECK(hipEventCreate(&e1));
+    } else {
+      e0 = tctx->pool.back().first;
+      e1 = tctx->pool.back().second;
+      tctx->pool.pop_back();
     }
-    if (!n_active) continue;
-    // slots: a pipe of g workgroups owns m = g / unit of them; unit = the smallest grid of the launch (doubled until the
-    // table holds the slots), the slots of the pipes interleaved in proportion (march-like stages first on ties: their
-    // workgroups are the short ones and should be resident from the start)
-    int unit = std::max(8, g_min / 8 * 8);
-    for (;;) {
-      int tot = 0;
-      for (int p = 0; p < n_pipes; ++p) tot += g_of[p] ? std::max(1, g_of[p] / unit) : 0;
-      if (tot <= kMaxSlots) break;
-      unit *= 2;
-    }
-    st.rows = unit / 8;
-    struct Ent { float pos; int prio, pipe, sub; } ent[kMaxSlots];
-    int n_slots = 0;
-    for (int p = 0; p < n_pipes; ++p) {
-      if (!g_of[p]) continue;
-      const int m = std::min(255, std::max(1, g_of[p] / unit));
-      st.mult[p] = (unsigned char)m;
-      for (int sub = 0; sub < m; ++sub)
-        ent[n_slots++] = {((float)sub + 0.5f) / (float)m, st.role[p] == kRoleShade ? 1 : 0, p, sub};
-    }
-    std::stable_sort(ent, ent + n_slots, [](const Ent& a, const Ent& b) {
-      return a.pos != b.pos ? a.pos < b.pos : a.prio < b.prio;
-    });
-    st.n_slots = n_slots;
-    for (int i = 0; i < n_slots; ++i) {
-      st.slot_pipe[i] = (unsigned char)ent[i].pipe;
-      st.slot_sub[i] = (unsigned char)ent[i].sub;
-    }
-    // the launches that carry a shade stage are the ones the timing events bracket (bench.py's roofline)
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed && has_shade) {
-      if (tctx->pool.empty()) {
-        PXT_HIP_CHECK(hipEventCreate(&e0));
-        PXT_HIP_CHECK(hipEventCreate(&e1));
-      } else {
-        e0 = tctx->pool.back().first;
-        e1 = tctx->pool.back().second;
-        tctx->pool.pop_back();
-      }
-      PXT_HIP_CHECK(hipEventRecord(e0, s0));
-    }
-    launch_stage(modes, by_value ? &pv : nullptr, pm, st, s0);
-    if (e0) {
-      PXT_HIP_CHECK(hipEventRecord(e1, s0));
-      tctx->events.emplace_back(e0, e1);
-    }
+    PXT_HIP_CHECK(hipEventRecord(e0, s0));
   }
-  launch_tail(modes, by_value ? &pv : nullptr, pm, dim3(tune.g_tail, n_pipes), n_rounds, tune.tail_div, s0);
+  launch_render(modes, by_value ? &pv : nullptr, pm, dim3(g_render, n_pipes), g_div, s0);
+  if (e0) {
+    PXT_HIP_CHECK(hipEventRecord(e1, s0));
+    tctx->events.emplace_back(e0, e1);
+  }
   const dim3 rgrid((max_pixels + 255) / 256, K);
-  if (by_value) hipLaunchKernelGGL(ngp_resolve_kernel_v, rgrid, dim3(256), 0, s0, rv);
-  else hipLaunchKernelGGL(ngp_resolve_kernel_m, rgrid, dim3(256), 0, s0, rm);
+  if (by_value) hipLaunchKernelGGL(ngp_resolve_kernel_v, rgrid, blk, 0, s0, rv);
+  else hipLaunchKernelGGL(ngp_resolve_kernel_m, rgrid, blk, 0, s0, rm);
   PXT_HIP_CHECK(hipGetLastError());
   for (int k = 0; k < K; ++k) R[k].ctx->counters_clean = true;
   return PXT_OK;
@@ -1956,10 +1559,10 @@ extern "C" int pxt_ngp_render_frame(pxt_ngp* ctx, const pxt_ngp_view* v, int32_t
 
 extern "C" int64_t pxt_ngp_batch_workspace_bytes(int32_t n_renders) {
   if (n_renders < 1 || n_renders > PXT_NGP_MAX_BATCH) return PXT_E_ARG;
-  return (int64_t)((size_t)3 * n_renders * sizeof(NgpBatchItem) + 255) / 256 * 256;  // <= 2 pipes + 1 resolve record each
+  return (int64_t)((size_t)(pxt_ngp::kMaxPipes + 1) * n_renders * sizeof(NgpBatchItem) + 255) / 256 * 256;  // pipes + 1 resolve record each
 }
 
-// K renders of K contexts - a frame's Depth + Shade pair, or K objects tracked in lock-step - as ONE staged chain.
+// K renders of K contexts - a frame's Depth + Shade pair, or K objects tracked in lock-step - as ONE chain of three launches.
 extern "C" int pxt_ngp_render_frame_batch(pxt_ngp* const* ctxs, const pxt_ngp_view* views, int32_t n_renders,
                                           const int32_t* modes, int32_t camera_from_slot, const pxt_ngp_outputs* outs,
                                           uint64_t* const* stats, void* batch_workspace, void* stream) {

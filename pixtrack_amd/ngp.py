@@ -634,7 +634,6 @@ class Testbed:
         return float(ms.value), int(n.value)
 
     def read_stats(self):
-        """(samples composited, rays that hit the box, rays finished by the straggler kernel, samples composited there) of
-        the last render_device(collect_stats=True)."""
+        """(samples composited, rays that hit the box) of the last render_device(collect_stats=True)."""
         s = self._stats.cpu().tolist()
-        return {"samples": s[0], "rays_hit": s[1], "tail_rays": s[2], "tail_samples": s[3]}
+        return {"samples": s[0], "rays_hit": s[1]}

@@ -34,7 +34,7 @@ def main():
             ms = e0.elapsed_time(e1) / 5
             cov = float((out[..., 3] > 0.5).float().mean())
             print(f"dist={dist} mode={mode.name}: {ms:.3f} ms  samples={st['samples']/1e6:.2f}M rays_hit={st['rays_hit']/1e6:.2f}M "
-                  f"tail_rays={st['tail_rays']} tail_samples={st['tail_samples']/1e6:.2f}M coverage={cov:.2f} {st['samples']/ms/1e6:.2f} Gsamples/s", flush=True)
+                  f"coverage={cov:.2f} {st['samples']/ms/1e6:.2f} Gsamples/s", flush=True)
 
 if __name__ == "__main__":
     main()

@@ -1,9 +1,9 @@
-"""Run-time variants of the hot path must be bit-identical: one / two / three pipes per NeRF render (the stages of the pipes
-share the launches of the render's chain), other workgroup counts per stage of that chain, the two UNet passes on two
-streams vs one batched pass, the bit-plane vs byte-plane mask kernel, the two coarse UNet heads in one launch vs two, the
-first UNet layer fused into the second layer's staging vs its own launch, 0 / 1 / 9 (default 4) wavefront rounds of the
-renderer before its straggler kernel (and other workgroup counts of that kernel).  Each variant is a knob read once per
-process, so every run is a subprocess of scripts/variant_checksum.py; the digests of its outputs are compared."""
+"""Run-time variants of the hot path must be bit-identical: one / two / three / four pipes per NeRF render (slices of the ray
+list, all in the same three launches), other workgroup counts of the persistent render kernel and of the ray generation
+(a ray's result depends neither on the grid nor on which rays share its wave), the two UNet passes on two streams vs one
+batched pass, the bit-plane vs byte-plane mask kernel, the two coarse UNet heads in one launch vs two, the first UNet
+layer fused into the second layer's staging vs its own launch.  Each variant is a knob read once per process, so every
+run is a subprocess of scripts/variant_checksum.py; the digests of its outputs are compared."""
 import os
 import subprocess
 import sys
@@ -27,10 +27,9 @@ def _digests(env_extra):
 
 def test_runtime_variants_are_bit_identical():
     base = _digests({})
-    for knobs in ({"PXT_NGP_PIPES": "1"}, {"PXT_NGP_PIPES": "3"}, {"PXT_UNET_STREAMS": "1"},
+    for knobs in ({"PXT_NGP_PIPES": "2"}, {"PXT_NGP_PIPES": "3"}, {"PXT_UNET_STREAMS": "1"},
                   {"PXT_MASK_BYTES": "1"}, {"PXT_UNET_FUSE_FIRST": "0"}, {"PXT_UNET_MERGE_HEADS": "0"},
-                  {"PXT_NGP_G_SHADE": "768", "PXT_NGP_G_MARCH": "256", "PXT_NGP_G_INIT": "1536", "PXT_NGP_G_COMPACT": "64"},
-                  {"PXT_NGP_G_SHADE": "4096", "PXT_NGP_G_MARCH": "8192", "PXT_NGP_PIPES": "4"},
-                  {"PXT_NGP_ROUNDS": "0", "PXT_NGP_TAIL_GRID": "4096"},
-                  {"PXT_NGP_ROUNDS": "1", "PXT_NGP_TAIL_DIV": "1"}, {"PXT_NGP_ROUNDS": "9", "PXT_NGP_TAIL_GRID": "96"}):
+                  {"PXT_NGP_GRID": "96", "PXT_NGP_GRID_RAYGEN": "64"},
+                  {"PXT_NGP_GRID": "1024", "PXT_NGP_GRID_DIV": "1"},
+                  {"PXT_NGP_GRID": "16384", "PXT_NGP_GRID_DIV": "4096", "PXT_NGP_PIPES": "4", "PXT_NGP_GRID_RAYGEN": "8192"}):
         assert _digests(knobs) == base, knobs
