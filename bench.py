@@ -53,8 +53,8 @@ PROFILE_COMMITS = {"r04": "57b838f", "r03": "a686fc1", "r02": "2a1bccf"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
 # the dominant kernel: gathers + both MLPs of a round's samples (Shade + Depth of the same rays: MODE 2)
-GATHER_KERNEL = "ngp_shade_kernel<2> (hash-grid gathers + MLPs of its own samples)"
-GATHER_KERNEL_PMC = "pxt::ngp_shade_kernel<2>"
+GATHER_KERNEL = "ngp_render_kernel<2> (a whole render: persistent waves marching their rays, hash-grid gathers + both MLPs + compositing)"
+GATHER_KERNEL_PMC = "pxt::ngp_render_kernel_v<2>"
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -391,7 +391,7 @@ def refshape_stage_block(tr, run_frame, lo, hi, dev):
     render-ahead off, then the live UNet / LM rooflines over [mid, hi) - where a real-asset frame's time goes."""
     mid = (lo + hi) // 2
     timer = StageTimer()
-    for attr in ("render_device", "render_both_device", "render_frame_device"):
+    for attr in ("render_device", "render_both_device", "render_frame_device", "render_frame_pair_device"):
         timer.wrap(tr.testbed, attr, "nerf_render")
     timer.wrap(tr.localizer.extractor.model, "forward_packed_batch", "unet")
     timer.wrap(tr.localizer.refiner, "refine_pose_using_features", "lm")
@@ -410,8 +410,8 @@ def refshape_stage_block(tr, run_frame, lo, hi, dev):
     roof = stage_rooflines(tr, None, None, mid, hi, dev, run_frame=run_frame)
     dom = max(stage, key=stage.get) if stage else None
     return {"stage_ms_per_frame": stage, "dominant_stage": dom, **roof,
-            "what": f"untimed: HIP-event stage times over {mid - lo} frames (render-ahead off; the two renders of a frame run side by "
-                    "side, so `nerf_render` counts their overlapped launches twice), then the UNet call / LM launch with events"}
+            "what": f"untimed: HIP-event stage times over {mid - lo} frames (render-ahead off; `nerf_render` = the frame's two renders as "
+                    "one chain of three launches), then the UNet call / LM launch with events"}
 
 
 def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
@@ -459,7 +459,7 @@ def ycb_policy_extra(dev, n=70, lead=10, refshape=False):
     if refshape:
         block = refshape_stage_block(tr, lambda i: tr.refine((f"{i + 1:06d}-color.png", frames[i], gts[i], cam)), n, n + n_diag, dev)
     what = ("the YCB policy (configs[2]) on the synthetic unit-cube object, 640x480, 5600 points, reference at 0.3 x: "
-            "two renders of different cameras + two UNet passes of different sizes per frame, each pair side by side")
+            "two renders of different cameras (ONE chain of launches) + two UNet passes of different sizes per frame")
     if refshape:
         what = ("the YCB policy with the reference's own camera shapes: SfM camera 3072x3072 f 2700 x 0.3 -> 921x921 "
                 "reference render + UNet pass, query 640x480 with fx 1066.778 / fy 1067.487, c (319.5, 239.5)")
@@ -567,7 +567,7 @@ def run_hd(args, rank, ws, dev, coll_dev, numa_node):
     stage_hd = None
     if mine:
         timer = StageTimer()
-        for attr in ("render_device", "render_both_device", "render_frame_device"):
+        for attr in ("render_device", "render_both_device", "render_frame_device", "render_frame_pair_device"):
             timer.wrap(tracker.testbed, attr, "nerf_render")
         timer.wrap(tracker.localizer.extractor.model, "forward_packed_batch", "unet")
         timer.wrap(tracker.localizer.extractor.model, "forward_packed", "unet")
@@ -929,6 +929,7 @@ def main():
     timer.wrap(tracker.testbed, "render_device", "nerf_render")
     timer.wrap(tracker.testbed, "render_both_device", "nerf_render")
     timer.wrap(tracker.testbed, "render_frame_device", "nerf_render")
+    timer.wrap(tracker.testbed, "render_frame_pair_device", "nerf_render")
     timer.wrap(tracker.localizer.extractor.model, "forward_packed_batch", "unet")
     timer.wrap(tracker.localizer.refiner, "refine_pose_using_features", "lm")
     timer.wrap(tracker.localizer.refiner, "interp_sparse_observations", "sample")
@@ -949,7 +950,7 @@ def main():
     ref_id_start = tracker.reference_ids[0]  # (the CPU baseline tracks the same first frames with the same reference)
     tracker.testbed.stats_accum.zero_()
     n_renders0 = tracker.testbed.n_renders
-    # HIP events around the gather-kernel launches (GATHER_KERNEL) of every 4th render: live over the timed
+    # HIP events around the render-kernel launch (GATHER_KERNEL) of every 4th render: live over the timed
     # region, sampled so that the marker packets do not slow what they measure
     tracker.testbed.timing_enable(4)
 
@@ -988,21 +989,9 @@ def main():
         tracker.run_single_frame((names[i], frames[i]))
     torch.cuda.synchronize()
     timer.enabled = False
-    # (2) the dominant kernel in isolation: one render pipeline (no overlapping second slice),
-    #     events around every gather-kernel launch, nothing else instrumented.
-    tracker.testbed.set_pipelines(1)
-    tracker.testbed.timing_enable(1)
-    tracker.testbed.stats_accum.zero_()
-    n_renders1 = tracker.testbed.n_renders
-    for i in range(n_timed_end + n_stage, n_timed_end + n_diag):
+    for i in range(n_timed_end + n_stage, n_timed_end + n_diag):  # (frames kept in step with the earlier rounds' passes)
         tracker.run_single_frame((names[i], frames[i]))
     torch.cuda.synchronize()
-    tracker.testbed.timing_enable(0)
-    tracker.testbed.set_pipelines(0)
-    iso_ms, iso_launches = tracker.testbed.timing_read()
-    iso_stats = tracker.testbed.stats_accum.cpu().tolist()
-    iso_samples = iso_stats[0] - iso_stats[3]
-    iso_renders = tracker.testbed.n_renders - n_renders1
     tracker.render_ahead = render_ahead
     # (3) live rooflines of the other two stages (the UNet is ~47 % of the frame, the LM ~6 %)
     roofline_stages = stage_rooflines(tracker, frames, names, n_timed_end + n_diag, n_timed_end + n_diag + n_roof, dev)
@@ -1019,17 +1008,13 @@ def main():
     if rank != 0:
         return
     stage = timer.totals_ms()
-    # dominant kernel: the round's gather kernel - ngp_shade_kernel<MODE>, which gathers the hash-grid features
-    # of its own samples, runs both MLPs on them and composites; kRounds launches per render and pipeline.
-    # ALGORITHMIC bytes per launch = composited samples per launch x 512 B; samples the
-    # rounds evaluate past a ray's termination are waste and are not credited.
+    # dominant kernel: ngp_render_kernel<MODE> - ONE launch per render: persistent waves march their rays, gather the
+    # hash-grid features of their samples, run both MLPs on them and composite (since round 6 nothing else runs beside it:
+    # the launch's duration is the kernel's own).  ALGORITHMIC bytes per launch = composited samples per render x 512 B
+    # (SURVEY 8d); samples a step evaluates past a ray's termination are waste and are not credited.
     enc_avg_ms = enc_ms / max(enc_launches, 1)          # over the timed (sampled) launches
-    # gather launches per render (the wavefront rounds x the renderer's pipeline count), from the sampled renders
-    sampled_renders = (n_renders + 3) // 4
-    launches_total = int(round(enc_launches / max(sampled_renders, 1))) * n_renders
-    # (samples composited by the straggler kernel - the same per-wave march + shade steps in another kernel - are not the
-    # timed launches' work)
-    samples_per_launch = (stats[0] - stats[3]) / max(launches_total, 1)
+    launches_total = n_renders
+    samples_per_launch = stats[0] / max(launches_total, 1)
     achieved = samples_per_launch * NERF_BYTES_PER_SAMPLE / (enc_avg_ms * 1e-3) / 1e9 if enc_avg_ms > 0 else 0.0
     # accuracy vs the synthetic ground truth over the timed frames (reported, not the metric)
     rot_err, tr_err = [], []
@@ -1044,24 +1029,20 @@ def main():
     # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes of this command
     # (FETCH_SIZE and WRITE_SIZE need separate runs, so they cannot be taken live here)
     traffic, traffic_src = None, None
-    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (5, 4, 3, 2)) if q.exists()), None)
+    pmc = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_traffic.json" for r in (6, 5, 4, 3, 2)) if q.exists()), None)
     static_commit = None
     if pmc is not None:
         recs = json.loads(pmc.read_text())
         static_commit = (recs.get("_meta") or {}).get("collected_at_commit") or PROFILE_COMMITS.get(pmc.name[:3])
-        rec = (recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
-               or recs.get("void pxt::ngp_shade_kernel<2, true>"))  # (the round-2 name of the same kernel)
+        rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
         if rec:
             traffic = round((rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / 1e6, 2)
             traffic_src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, MB per launch)"
-    iso_avg_ms = iso_ms / max(iso_launches, 1)
-    iso_spl = iso_samples / max(iso_launches, 1)  # one pipeline, every launch timed
-    iso_achieved = iso_spl * NERF_BYTES_PER_SAMPLE / (iso_avg_ms * 1e-3) / 1e9 if iso_avg_ms > 0 else 0.0
     # What actually binds the kernel (rocprofv3 TCP / TCC counter passes of this command, scripts/collect_profiles.sh):
     # not HBM bytes - the fabric side moves ~0.35 x the algorithmic bytes - but the L1's miss path: requests to the L2
     # x their latency.  `l2` prices the kernel against the L2's own peak as well.
     l2 = None
-    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (5, 4, 3)) if q.exists()), None)
+    l2f = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_l2.json" for r in (6, 5, 4, 3)) if q.exists()), None)
     if l2f is not None:
         recs = json.loads(l2f.read_text())
         rec = recs.get(GATHER_KERNEL_PMC) or recs.get("void " + GATHER_KERNEL_PMC)
@@ -1088,20 +1069,15 @@ def main():
                 "avg_launch_ms": round(enc_avg_ms, 5), "launches_timed": enc_launches, "launches": launches_total,
                 "samples_per_launch": round(samples_per_launch, 1), "bytes_per_sample": NERF_BYTES_PER_SAMPLE,
                 "samples_per_render": round(stats[0] / max(n_renders, 1), 1),
-                "straggler_samples_per_render": round(stats[3] / max(n_renders, 1), 1),
-                "note": ("timed region: the render runs as two overlapping pipelines, so a launch shares the chip "
-                         "with the other slice's march/shade and its duration is not the kernel's isolated speed"),
-                "binding_resource": ("the ISSUE of the gathers (128 gather instructions per 64 samples, a quad of lanes per clock of "
-                                     "the CU's address unit: ~0.31 ms per render against ~0.41 measured, L1 busy ~89 %; the L1 / L2 "
-                                     "misses are the last quarter - profiles/r05_experiments.md #23, #24), NOT HBM "
-                                     "bytes: `bound` keeps the contract's hbm|mfma vocabulary and prices the ALGORITHMIC "
-                                     "gather bytes against the HBM peak; `traffic` (fabric side) is ~0.35 x that, `l2` "
-                                     "prices the L2 requests against the L2's peak"),
-                "l2": l2,
-                "isolated": {"what": f"same kernel, one pipeline, untimed pass over {n_diag - n_diag // 2} further frames",
-                             "achieved": round(iso_achieved, 2), "frac": round(iso_achieved / HBM_PEAK_GBS, 5),
-                             "avg_launch_ms": round(iso_avg_ms, 5), "launches": iso_launches,
-                             "samples_per_launch": round(iso_spl, 1)}}
+                "rays_in_the_box_per_render": round(stats[1] / max(n_renders, 1), 1),
+                "note": ("one launch = one render (a frame's mask + reference image in one march); timed with HIP events on "
+                         "the render's own stream over every 4th render of the timed region; nothing runs beside it"),
+                "binding_resource": ("gather ISSUE and VALU together (128 gather instructions per 64 samples at a quad of lanes "
+                                     "per clock of the CU's address unit; ~2500 VALU instructions per wave step), NOT HBM bytes: "
+                                     "`bound` keeps the contract's hbm|mfma vocabulary and prices the ALGORITHMIC gather bytes "
+                                     "against the HBM peak; `traffic` is the fabric side (tables cache-resident), `l2` prices the "
+                                     "L2 requests against the L2's peak (DESIGN.md 3.3)"),
+                "l2": l2}
     out = {
         "metric": "tracked frames/sec at 640x480 (full NeRF render + UNet + LM loop)",
         "value": round(total_frames / elapsed, 3),
@@ -1142,14 +1118,14 @@ def main():
     # other kernels' utilisation from the committed rocprofv3 SQ counter pass of this command
     # (profiles/r02_pmc_sq.json; scripts/pmc_sq_summary.py): matrix-pipe busy of the UNet convolutions,
     # VALU busy of the march (a serial DDA per ray: latency- and tail-bound, not VALU-bound)
-    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (5, 4, 3, 2)) if q.exists()), None)
+    sq = next((q for q in (ROOT / "profiles" / f"r0{r}_pmc_sq.json" for r in (6, 5, 4, 3, 2)) if q.exists()), None)
     if sq is not None:
         rec = json.loads(sq.read_text())
         pick = {}
         for name, r in rec.items():
             if name == "_meta":
                 continue
-            if "conv3x3_v" in name or "ngp_compact_march" in name or "ngp_shade" in name or "lm_refine" in name:
+            if "conv3x3_v" in name or "ngp_r" in name or "lm_refine" in name:
                 pick[name.replace("void pxt::", "").replace("pxt::", "")] = {
                     k: round(r[k], 4) for k in ("mfma_busy", "valu_busy", "mean_waves_per_simd") if k in r}
         out["kernel_utilisation"] = {"source": f"profiles/{sq.name} (rocprofv3 --pmc SQ_*, same command)", "static": True,

@@ -132,9 +132,11 @@ int pxt_lm_refine_cam(const float* p3d, const uint8_t* point_mask, int32_t n_poi
  * (pxt_lm_workspace_bytes() each, all different) and optional camera record - and is solved by its own share of the
  * grid: workgroup i works on problem i mod K, so the problems never wait for each other and an iteration's
  * inter-workgroup exchange and single-lane solve are paid once per iteration for all K.  conf_host is shared;
- * conf_host->n_workgroups is the grid PER PROBLEM (0 = library default: 256 / K rounded down to a multiple of 8, at
- * most 128).  A problem's result is bit-identical to pxt_lm_refine_cam with the same n_workgroups (the fixed-order
- * folds depend on the number of workgroups only).  batch_workspace: device, pxt_lm_batch_workspace_bytes(K); it holds
+ * conf_host->n_workgroups is the grid PER PROBLEM; 0 = the library's default: 256 / K rounded down to a multiple of 8 (at
+ * most 128), raised to what one round of 8-lane point groups needs for the largest problem (ceil(n_points / 64), a multiple
+ * of 8, at most 128).  Either way the grid is then capped so that all K x n_workgroups workgroups are resident at once
+ * (one 8-wave workgroup per CU).  A problem's result is bit-identical to pxt_lm_refine_cam with the same EFFECTIVE grid
+ * (the fixed-order folds depend on the number of workgroups only): pass an explicit n_workgroups <= resident / K to pin it.  batch_workspace: device, pxt_lm_batch_workspace_bytes(K); it holds
  * the K parameter records, copied there from pinned staging memory ahead of the launch in `stream`. */
 #define PXT_LM_MAX_BATCH 16
 typedef struct {
@@ -337,7 +339,9 @@ typedef struct {
 /* out_rgba: float32 [height][width][4], linear colour (render(..., linear=True)). */
 int pxt_ngp_render(pxt_ngp* ctx, const pxt_ngp_view* view_host, float* out_rgba,
                    uint64_t* stats /* device, 4 counters (added to) or NULL: [0] samples composited, [1] rays that hit the
-                                      render box; [2], [3] unused since ABI 11 */, void* stream);
+                                      render box, [2] wave steps that shaded samples (64 sample slots each), [3] hash-grid
+                                      levels of those steps fetched as one 4 x 4 x 4 box per wave (of 16 per step) */,
+                   void* stream);
 
 /* Shade AND Depth of the SAME view in one march: bit-for-bit what two pxt_ngp_render calls
  * (mode 0, then mode 1) of this view produce, with the per-sample gathers and the density

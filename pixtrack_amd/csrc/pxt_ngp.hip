@@ -71,6 +71,7 @@ struct NgpParams {
   float bg[4];
   float min_T;
   int W, H, spp, mode;
+  int coop;            // wave-cooperative corner fetch of the coarse levels (ngp_render_body); PXT_NGP_COOP=0 turns it off (A/B)
   int srgb_to_linear;  // Shade: a finished ray's colour goes through srgb_to_linear before the spp mean (model.linear_colors == 0)
   float* out;        // float RGBA of the render's own mode (mode 2: the Shade image); may be null when an 8-bit output stands in
   float* out_depth;  // mode 2: the Depth image (optional)
@@ -371,6 +372,7 @@ __device__ inline void ngp_eval(const NgpParams& P, const half8* s_w, int lane, 
 // ===========================================================================
 constexpr int kK = 8;          // samples per ray per step
 constexpr int kCtrWords = 16;  // ints per counter block (one 64-B line per pipe)
+
 
 struct Ray {
   float o[3], d[3], idir[3];
@@ -685,6 +687,20 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
       word |= __shfl_xor(word, 1, 8);
       word |= __shfl_xor(word, 2, 8);
       word |= __shfl_xor(word, 4, 8);
+      // The common trip - a ray inside the object: a fresh step, all 8 lattice points occupied and inside the box - has a
+      // known outcome (lane j takes point j, the ray moves on to the 9th point), and the passes of a pixel share that
+      // fate: when EVERY marching lane of the wave is in it, the general walk below (~150 VALU instructions of a kernel
+      // that is VALU-bound) is skipped.  The same values, by construction.
+      if (__all(!busy || (k == 0 && word == 0x88888888u && ge_tmax == 0u && pending == -INFINITY))) {
+        if (busy) {
+          ts = tj;
+          have = 1;
+          k = kK;
+          t = tt[8];
+          busy = false;
+        }
+        continue;
+      }
       int cur = 8;
 #pragma unroll
       for (int i = 7; i >= 0; --i) cur = (tt[i] >= pending) ? i : cur;
@@ -726,6 +742,70 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
   exhausted = out;
 }
 
+// min / max over the 64 lanes of a wave, returned to every lane: four DPP steps inside the 16-lane rows (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror), two row broadcasts, one readlane.
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_minmax(float v) {
+  auto step = [&](int ctrl, int row_mask) {
+    const int iv = __builtin_bit_cast(int, v);
+    int o;
+    if (ctrl == 0) o = __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if (ctrl == 1) o = __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if (ctrl == 2) o = __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    else if (ctrl == 3) o = __builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xF, 0xF, false);  // row_mirror
+    else if (ctrl == 4) o = __builtin_amdgcn_update_dpp(iv, iv, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    else o = __builtin_amdgcn_update_dpp(iv, iv, 0x143, 0xC, 0xF, false);                 // row_bcast31 -> rows 2, 3
+    const float f = __builtin_bit_cast(float, o);
+    v = IS_MAX ? fmaxf(v, f) : fminf(v, f);
+    (void)row_mask;
+  };
+  step(0, 0); step(1, 0); step(2, 0); step(3, 0); step(4, 0); step(5, 0);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// ---- wave-cooperative corner fetch (round 6; north_star's "LDS-staged hash-grid lookups" at wave granularity).
+// The 64 samples of a wave step usually lie on ONE line - the 8 passes of a pixel share their ray, and 8 consecutive steps of
+// it span a stretch of ~0.015 of the unit cube - so at a coarse level all of them sit in a few neighbouring cells, and the
+// 64 x 8 corner gathers of the level fetch the same dozen entries over and over: 8 gather instructions at ~16 clocks of the
+// CU's address unit each, which is what binds this kernel.  When the stretch spans at most 3 cells per axis
+// of a level, the wave fetches the 4 x 4 x 4 lattice box around it with ONE gather instruction (lane = lattice point, dense
+// index or hash as the level demands) straight into a 256-byte LDS patch (buffer_load ... lds: no VGPR, no wait until
+// use), and every sample reads its 8 corners from the patch with ds_read_b32 at constant offsets.  Same entries, same
+// trilinear arithmetic: every feature keeps its bits.
+// The lattice point of this lane in the box whose low corner is (lox, loy, loz), as a byte offset into the level's table.
+__device__ __forceinline__ int ngp_patch_point_offset(const NgpLevel& Lv, int lane, unsigned lox, unsigned loy, unsigned loz) {
+  const unsigned lx = lox + (unsigned)(lane & 3), ly = loy + (unsigned)((lane >> 2) & 3), lz = loz + (unsigned)(lane >> 4);
+  unsigned idx;
+  if (Lv.hashed) idx = (lx ^ (ly * 2654435761u) ^ (lz * 805459861u)) & (Lv.size - 1u);
+  else idx = min(lx + ly * Lv.res + lz * Lv.res * Lv.res, Lv.size - 1u);
+  return (int)(idx << 2);
+}
+// One level's features of this lane's sample from the wave's patch (the arithmetic of ngp_encode_level_uniform).
+__device__ __forceinline__ unsigned ngp_encode_level_patch(const unsigned* patch, const NgpLevel& Lv, float ux, float uy, float uz,
+                                                           unsigned lox, unsigned loy, unsigned loz, bool in_box) {
+#pragma clang fp contract(fast)  // (as ngp_encode_level_uniform)
+  const float qx = ux * Lv.scale + 0.5f, qy = uy * Lv.scale + 0.5f, qz = uz * Lv.scale + 0.5f;
+  const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+  const float ax = qx - fx, ay = qy - fy, az = qz - fz;
+  const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
+  // (a lane without a sample holds position 0 - outside the box: it reads the box's first cell, its result is masked)
+  const unsigned local = in_box ? (gx - lox) + 4u * (gy - loy) + 16u * (gz - loz) : 0u;
+  const unsigned* c0 = patch + local;
+  const unsigned vals[8] = {c0[0], c0[1], c0[4], c0[5], c0[16], c0[17], c0[20], c0[21]};
+  float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float w = 1.0f;
+    w = w * ((c & 1) ? ax : (1.0f - ax));
+    w = w * ((c & 2) ? ay : (1.0f - ay));
+    w = w * ((c & 4) ? az : (1.0f - az));
+    const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
+    f0 += w * (float)hv[0];
+    f1 += w * (float)hv[1];
+  }
+  return pack_h2(f0, f1);
+}
+
 // The render kernel's body: PERSISTENT waves over the ray list of one pipe.
 //
 // A wave holds 8 rays (ray position r = lane >> 3, its 8 lanes k = lane & 7) and repeats
@@ -745,10 +825,12 @@ __device__ __forceinline__ void ngp_march_group(const NgpParams& P, const Ray& r
 // one, so that the wave keeps shading 64 samples per step until its share of the list runs out.  (Shares drawn from a shared
 // counter instead, 64 entries per atomic: 0.85-1.4 ms per render against 0.63-0.70 - returning atomics on one word are served
 // one per ~100 ns, and the 4096 waves' first draw alone takes 0.4 ms.  The grid is larger than what is resident instead: the
-// dispatcher is the queue.)
+// dispatcher is the queue.  A wave's share as CONSECUTIVE groups of the list - neighbouring pixels, whose lines run through the
+// same coarse cells - loses to it: 0.70-0.80 ms against 0.65 with 2048 ... 16384 workgroups; the cost of a ray varies along
+// the list and the interleaved shares even it out.)
 template <int MODE>  // 0 colour, 1 depth, 2 colour AND depth of the same rays in one march
 __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWork& Wk, int rays_per_wg, int blk, int nblk,
-                                                half8* s_w, unsigned* s_feat) {
+                                                half8* s_w, unsigned* s_feat, float* s_rays) {
   const int n = Wk.counters[0];
   if (P.stats && blk == 0 && threadIdx.x == 0) atomicAdd(P.stats + 1, (unsigned long long)n);  // rays that hit the box
   // Workgroups that take part: one per `rays_per_wg` rays, at least nblk / 4 (a short list spread over few waves is a
@@ -762,25 +844,27 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rlane = lane >> 3, k = lane & 7;
   unsigned long long n_samples = 0;
+  int n_steps = 0, n_box_levels = 0;  // (wave-uniform) shade steps of this wave, levels it fetched as a box
   const int n_waves = n_wg * 4, wave_id = blk * 4 + wave;
   auto stream_slot = [&](int s) { return ((s >> 3) * n_waves + wave_id) * 8 + (s & 7); };
   // ---- the lane's ray (the same in the 8 lanes of a ray position)
   int cursor = 8;
   int slot = stream_slot(rlane);
   bool alive = slot < n;
-  float t = 0.f, T0 = 1.f, accd = 0.f;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // What a ray accumulates - transmittance, premultiplied colour, depth - and its id are only touched between the MLPs and
+  // the next march: they live in LDS (8 dwords per ray position; the 8 lanes of a ray read one address), not in registers
+  // that would be dead weight across the gathers (the kernel sits at the 128-VGPR line of 4 waves per SIMD).
+  float* const s_ray = s_rays + (wave * 8 + rlane) * 8;  // [T, acc.x, acc.y, acc.z, acc.w, depth, ray id, -]
+  float t = 0.f;
   float4 rd = make_float4(0.f, 0.f, 1.f, 0.f);
-  unsigned rid = 0u;
   if (alive) {
     t = Wk.t0[slot];
-    rid = Wk.rid[slot];
     rd = Wk.dir[slot];
   }
-  unsigned shB0[4], shB1[4];
-  {
-    const float rdir[3] = {rd.x, rd.y, rd.z};
-    sh_fragments(rdir, shB0, shB1);
+  if (k == 0) {
+    s_ray[0] = 1.f;
+    s_ray[1] = s_ray[2] = s_ray[3] = s_ray[4] = s_ray[5] = 0.f;
+    s_ray[6] = __builtin_bit_cast(float, alive ? Wk.rid[slot] : 0u);
   }
   unsigned* const col = s_feat + wave * (8 * 64) + lane;  // the features pass through the lane's own LDS column
   // gather in ray-fastest lane order: lane 8 a + b fetches the sample of lane 8 b + a, so that adjacent lanes hold
@@ -809,18 +893,92 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
       // every lane gathers (empty slots hold position 0: in range), the result is masked afterwards
       float ux = (sp.x - enc_lo) * enc_inv, uy = (sp.y - enc_lo) * enc_inv, uz = (sp.z - enc_lo) * enc_inv;
       ux = __shfl(ux, tl, 64); uy = __shfl(uy, tl, 64); uz = __shfl(uz, tl, 64);
-#pragma unroll 4
-      for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l], ux, uy, uz);
-      __builtin_amdgcn_wave_barrier();
+      const unsigned long long vmask = __ballot(valid);
+      const bool valid_t = (vmask >> tl) & 1ull;  // (of the sample this lane gathers for)
+      ++n_steps;
+      // ---- which levels the wave can fetch cooperatively: the lanes with a sample share ONE ray (the passes of a pixel),
+      // and the stretch between its first and last sample of this step spans < 2 cells of the level per axis (then at most
+      // 3 cells, 4 lattice points).  The stretch's ends are two of the samples themselves, formed with the march's own
+      // arithmetic, and cell coordinates are monotone along the line: the box of the ends' cells holds every sample's.
+      float coop_scale = 0.f;          // levels with scale <= coop_scale are fetched as a box
+      float emin[3] = {0.f, 0.f, 0.f}; // the stretch's low corner in encoder coordinates
+      if (P.coop) {
+        const int first = __ffsll((long long)vmask) - 1;
+        const float d0[3] = {__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rd.x), first)),
+                             __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rd.y), first)),
+                             __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rd.z), first))};
+        if (__all(!valid || (rd.x == d0[0] && rd.y == d0[1] && rd.z == d0[2]))) {
+          const float tlo = wave_minmax<false>(valid ? sample_t : INFINITY), thi = wave_minmax<true>(valid ? sample_t : -INFINITY);
+          float ext = 0.f;
 #pragma unroll
-      for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-      for (int l = 0; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l + 8], ux, uy, uz);
-      __builtin_amdgcn_wave_barrier();
+          for (int a = 0; a < 3; ++a) {
+            const float o = P.cam_dev ? P.cam_dev[4 * a + 3] : P.cam[4 * a + 3];
+            const float ea = ((o + tlo * d0[a]) - enc_lo) * enc_inv, eb = ((o + thi * d0[a]) - enc_lo) * enc_inv;
+            // (wave-uniform values: kept in scalar registers)
+            emin[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(ea, eb))));
+            ext = fmaxf(ext, fabsf(eb - ea));
+          }
+          // scale x extent <= 1.98: the cell coordinates of the two ends differ by at most 2 (their fp32 error is < 0.002
+          // up to the finest level's 8192 cells)
+          coop_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.98f / ext)));
+        }
+      }
 #pragma unroll
-      for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
-      __builtin_amdgcn_wave_barrier();  // (the next step's first-half writes must not overtake these reads)
+      for (int half = 0; half < 2; ++half) {
+        const int l0 = 8 * half;
+        int n_coop = 0;
+        if (P.coop) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the rows' last readers are done before a fetch lands in them)
+          while (n_coop < 8 && P.lv[l0 + n_coop].scale <= coop_scale) {
+            const NgpLevel& Lv = P.lv[l0 + n_coop];
+            unsigned lo[3];
+            {
+#pragma clang fp contract(fast)  // (the lanes' own q = u * scale + 0.5 is contracted: ngp_encode_level_uniform)
+              lo[0] = (unsigned)(int)floorf(emin[0] * Lv.scale + 0.5f);
+              lo[1] = (unsigned)(int)floorf(emin[1] * Lv.scale + 0.5f);
+              lo[2] = (unsigned)(int)floorf(emin[2] * Lv.scale + 0.5f);
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grid_rsrc, (__attribute__((address_space(3))) void*)(s_feat + wave * (8 * 64) + n_coop * 64),
+                                                     4, ngp_patch_point_offset(Lv, lane, lo[0], lo[1], lo[2]), (int)(Lv.offset * 4u), 0, 0);
+            ++n_coop;
+          }
+          n_box_levels += n_coop;
+        }
+        // the other levels: 8 corner gathers per lane
+#pragma unroll 4
+        for (int l = n_coop; l < 8; ++l) wcol[l * 64] = ngp_encode_level_uniform(grid_rsrc, P.lv[l0 + l], ux, uy, uz);
+        if (n_coop) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patches have landed
+          __builtin_amdgcn_wave_barrier();
+          for (int l = 0; l < n_coop; ++l) {
+            const NgpLevel& Lv = P.lv[l0 + l];
+            unsigned lo[3];
+            {
+#pragma clang fp contract(fast)
+              lo[0] = (unsigned)(int)floorf(emin[0] * Lv.scale + 0.5f);
+              lo[1] = (unsigned)(int)floorf(emin[1] * Lv.scale + 0.5f);
+              lo[2] = (unsigned)(int)floorf(emin[2] * Lv.scale + 0.5f);
+            }
+            const unsigned pk = ngp_encode_level_patch(s_feat + wave * (8 * 64) + l * 64, Lv, ux, uy, uz, lo[0], lo[1], lo[2], valid_t);
+            __builtin_amdgcn_wave_barrier();  // every lane has read the patch before a feature replaces part of it
+            wcol[l * 64] = pk;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (half == 0) {
+#pragma unroll
+          for (int l = 0; l < 8; ++l) Flo[l] = valid ? col[l * 64] : 0u;
+        } else {
+#pragma unroll
+          for (int l = 0; l < 8; ++l) Fhi[l] = valid ? col[l * 64] : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();  // (the next writers of the rows must not overtake these reads)
+      }
+      // (the SH fragments of the ray's direction are formed here, per step, instead of living in 8 registers across the
+      // march and the gathers: ~60 VALU instructions of a step's ~2500)
+      unsigned shB0[4], shB1[4];
+      const float rdir[3] = {rd.x, rd.y, rd.z};
+      sh_fragments(rdir, shB0, shB1);
       ngp_mlp<MODE == 1>(s_w, lane, Flo, Fhi, shB0, shB1, logit, rgbv);
     }
     // ---- in-order compositing of the ray's K samples (8 consecutive lanes) ----
@@ -838,6 +996,7 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
     }
     float pexc = __shfl_up(pinc, 1, 8);
     if (k == 0) pexc = 1.0f;
+    const float T0 = s_ray[0];
     const float T_before = T0 * pexc, T_after = T0 * pinc;
     // the first sample after which T drops below the threshold ends the ray (it is included)
     const bool ends = valid && (T_after < P.min_T);
@@ -863,22 +1022,26 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
     const int k_last = grp ? k_term : n_valid - 1;
     const float T_new = (k_last >= 0) ? __shfl(T_after, rlane * 8 + max(k_last, 0), 64) : T0;
     if (alive) {
-      acc.x += cr; acc.y += cg; acc.z += cb; acc.w += ca;
-      if (MODE == 2) accd = accd + cd;
       const bool terminated = grp != 0;
-      if (terminated || exhausted) {  // close the ray: one lane stores
-        if (k == 0) {
+      const bool closes = terminated || exhausted;
+      if (k == 0) {  // one lane per ray keeps the books
+        float4 acc = make_float4(s_ray[1] + cr, s_ray[2] + cg, s_ray[3] + cb, s_ray[4] + ca);
+        float accd = 0.f;
+        if (MODE == 2) accd = s_ray[5] + cd;
+        if (closes) {
+          const unsigned rid = __builtin_bit_cast(unsigned, s_ray[6]);
           if (MODE == 2) Wk.sppbuf_d[rid] = terminated ? accd / acc.w : accd;
-          float4 o = acc;
           if (terminated) {
-            o.x /= o.w; o.y /= o.w; o.z /= o.w; o.w = 1.0f;
+            acc.x /= acc.w; acc.y /= acc.w; acc.z /= acc.w; acc.w = 1.0f;
           }
-          Wk.sppbuf[rid] = o;
+          Wk.sppbuf[rid] = acc;
+        } else {
+          s_ray[0] = T_new;
+          s_ray[1] = acc.x; s_ray[2] = acc.y; s_ray[3] = acc.z; s_ray[4] = acc.w;
+          if (MODE == 2) s_ray[5] = accd;
         }
-        alive = false;
-      } else {
-        T0 = T_new;
       }
+      if (closes) alive = false;
     }
     // ---- refill the free positions, lowest first
     const unsigned long long dead = __ballot(!alive && k == 0);  // bit 8 r: ray position r is free
@@ -889,21 +1052,31 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
         if (ns < n) {
           alive = true;
           t = Wk.t0[ns];
-          rid = Wk.rid[ns];
           rd = Wk.dir[ns];
-          T0 = 1.f;
-          acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          accd = 0.f;
+          if (k == 0) {
+            s_ray[0] = 1.f;
+            s_ray[1] = s_ray[2] = s_ray[3] = s_ray[4] = s_ray[5] = 0.f;
+            s_ray[6] = __builtin_bit_cast(float, Wk.rid[ns]);
+          }
         }
       }
       cursor += __popcll(dead);
-      const float rdir[3] = {rd.x, rd.y, rd.z};
-      sh_fragments(rdir, shB0, shB1);  // (all lanes: the fragments are formed with cross-lane swaps)
     }
   }
-  if (P.stats) {
+  if (P.stats) {  // one atomic per workgroup and counter: a single counter word sustains only ~90 atomics/us
+    __shared__ unsigned long long s_cnt[4][3];
     for (int m = 32; m >= 1; m >>= 1) n_samples += __shfl_xor(n_samples, m, 64);
-    if (lane == 0 && n_samples) atomicAdd(P.stats + 0, n_samples);
+    if (lane == 0) {
+      s_cnt[wave][0] = n_samples;
+      s_cnt[wave][1] = (unsigned long long)n_steps;
+      s_cnt[wave][2] = (unsigned long long)n_box_levels;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const unsigned long long tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+      // [0] samples composited, [2] wave steps that shaded samples (64 sample slots each), [3] levels of them fetched as a box
+      if (tot) atomicAdd(P.stats + (threadIdx.x == 0 ? 0 : threadIdx.x + 1), tot);
+    }
   }
 }
 
@@ -1044,10 +1217,11 @@ template <int MODES>
 __device__ __forceinline__ void ngp_render_impl(const NgpBatchItem& it, int rays_per_wg) {
   __shared__ half8 s_w[kNumFrags * 64];
   __shared__ unsigned s_feat[4 * 8 * 64];
+  __shared__ float s_rays[4 * 8 * 8];
   const int mode = MODES == 3 ? it.P.mode : MODES;
-  if (mode == 0) ngp_render_body<0>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
-  else if (mode == 1) ngp_render_body<1>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
-  else ngp_render_body<2>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat);
+  if (mode == 0) ngp_render_body<0>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat, s_rays);
+  else if (mode == 1) ngp_render_body<1>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat, s_rays);
+  else ngp_render_body<2>(it.P, it.W, rays_per_wg, blockIdx.x, gridDim.x, s_w, s_feat, s_rays);
 }
 template <int MODES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_render_kernel_v(const NgpItemsByValue<4> items,
@@ -1276,6 +1450,8 @@ static void fill_model(const pxt_ngp* ctx, NgpParams& P) {
   P.cone_angle = ctx->model.cone_angle;
   P.depth_scale = ctx->model.depth_scale;
   P.srgb_to_linear = ctx->model.linear_colors ? 0 : 1;
+  static const int coop_rt = [] { const char* e = getenv("PXT_NGP_COOP"); return e ? atoi(e) : 1; }();
+  P.coop = coop_rt;
   P.dt_lo = (float)(std::sqrt(3.0) / 1024.0);
   P.dt_hi = P.dt_lo * (float)(1 << (P.cascades - 1)) * (float)(1024 / kGrid);
 }

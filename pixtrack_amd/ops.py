@@ -243,6 +243,8 @@ def _sample_sparse(p3d, T, fmaps, channels, cameras, ndist, pad, normalize, outs
     n_levels = len(fmaps)
     if len(outs) != n_levels or len(cameras) != 10 * n_levels or len(T) != 12:
         raise _lib.PxtError("sample_sparse: one out tensor and 10 camera floats per level, T of 12 floats")
+    if windows is not None and len(windows) != 4 * n_levels:
+        raise _lib.PxtError("sample_sparse: windows holds (x0, y0, full_w, full_h) per level")
     _f32c(p3d, "p3d")
     n = int(p3d.shape[0])
     arr = (_lib.SampleLevel * n_levels)()
@@ -257,8 +259,6 @@ def _sample_sparse(p3d, T, fmaps, channels, cameras, ndist, pad, normalize, outs
         arr[i].ndist = int(ndist[i])
         if windows is not None:  # (x0, y0, full_w, full_h) per level: the map is a window of the full level
             arr[i].x0, arr[i].y0, arr[i].full_w, arr[i].full_h = (int(x) for x in windows[4 * i:4 * i + 4])
-    if windows is not None and len(windows) != 4 * n_levels:
-        raise _lib.PxtError("sample_sparse: windows holds (x0, y0, full_w, full_h) per level")
     if valid.dtype != torch.uint8 or valid.numel() != n:
         raise _lib.PxtError("sample_sparse: valid must be uint8 [n_points]")
     T12 = (C.c_float * 12)(*[float(x) for x in T])

@@ -236,11 +236,12 @@ class MultiObjectTracker:
                 if bytes(pr["conf"]) != bytes(conf):
                     raise _lib.PxtError("lock-step trackers must share the optimizer configuration")
             conf.n_workgroups = self.lm_workgroups
-            if len(self.groups) > 1 and conf.n_workgroups <= 0:
+            if len(self.groups) > 1:
                 # the groups' launches may run side by side: together they must fit the device's resident workgroups
-                # (one 8-wave workgroup per CU: pxt_lm.hip), or both would sit partly resident and time out
-                cus = _device_cus()
-                conf.n_workgroups = max(8, cus // (len(self.groups) * len(probs)) // 8 * 8)
+                # (one 8-wave workgroup per CU: pxt_lm.hip), or both would sit partly resident and time out - also when the
+                # caller asked for a grid per problem (lm_workgroups > 0: clamped to the groups' share)
+                share = max(8, _device_cus() // (len(self.groups) * len(probs)) // 8 * 8)
+                conf.n_workgroups = share if conf.n_workgroups <= 0 else min(conf.n_workgroups, share)
             handles = PixTrackOptimizer.refine_levels_batch(probs, conf, self._lm_batch_ws(grp), pool_key=grp.index)
         self._mark("lm_enqueued")
         it = iter(handles)

@@ -180,7 +180,10 @@ class PoseTrackerRefiner:
                         y0 = max(0, int(np.floor(v[inside].min()) - m) // 16 * 16)
                         x1 = min(W, -(-(int(np.ceil(u[inside].max())) + 1 + m) // 16) * 16)
                         y1 = min(H, -(-(int(np.ceil(v[inside].max())) + 1 + m) // 16) * 16)
-                        if (x1 - x0) * (y1 - y0) <= (1.0 - self.WINDOW_MIN_SAVING) * W * H and x1 - x0 >= 64 and y1 - y0 >= 64:
+                        # (the crop itself must pass through the extractor unresized too: with resize_by = "max_force" a crop
+                        # smaller than conf.resize would be force-upscaled and the window arithmetic would be off)
+                        if (x1 - x0) * (y1 - y0) <= (1.0 - self.WINDOW_MIN_SAVING) * W * H and x1 - x0 >= 64 and y1 - y0 >= 64 \
+                                and ex.target_size(y1 - y0, x1 - x0, 1)[:2] == (y1 - y0, x1 - x0):
                             out = (reference_image[y0:y1, x0:x1].contiguous(), (x0, y0, W, H))
         self._window_memo = (reference_image, pose, out[0], out[1])
         return out

@@ -1,0 +1,109 @@
+"""How much room does the 1e-3 rad / 1e-3 parity bar leave?  (VERDICT r5 next #4.)
+
+The reference's stop rule (pixtrack/optimizers/pixtrack_optimizer.py:5-18: dt < 5e-3 AND dR < 0.05 deg, or |grad| < 1e-4)
+ends a level while the last update is still as large as a few 1e-4; two implementations of the same arithmetic whose fp32
+sums are ordered differently may therefore stop one iteration apart, and a level's result moves by up to the size of that
+last update.  This script measures the spread instead of assuming it:
+
+  A  HIP (default grid) against oracle/lm_oracle.py (the CPU restatement), SEEDS scenes of synthetic.make_lm_scene at
+     320 x 240 and 640 x 480, N = 2048 points, the three damping constant sets of tests/test_lm_gpu.py;
+  B  HIP against HIP with another persistent grid (32 and 128 workgroups: the lock-step batch's and the solo launch's)
+     - the same kernel, only the order of the cross-workgroup fold differs.
+
+Per comparison: p50 / p90 / p99 / max of the rotation (rad) and translation differences of the FINAL pose, and how often
+the per-level iteration counts differ.  Output: one JSON document (profiles/r06_parity_margin.json).
+
+    python scripts/parity_margin.py [n_seeds] > profiles/r06_parity_margin.json
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+
+from oracle import lm_oracle as O
+from pixtrack_amd import _lib
+from pixtrack_amd.optimizer import LevelPack, PixTrackOptimizer, cstride_for
+from pixtrack_amd.synthetic import make_lm_scene
+
+CONSTS = [[-2.0] * 6, [-1.5, -2.5, -2.0, -1.8, -2.2, -2.0], [-2.0, -2.0, -1.0, -3.0, -2.0, -1.5]]
+
+
+def pack_level(scene, level, device):
+    fq = scene.feats_query[level]
+    Cc = fq.shape[0] - 1
+    cs = cstride_for(Cc)
+    h, w = fq.shape[1:]
+    fmap = torch.zeros(h, w, cs)
+    fmap[..., :Cc] = O.l2_normalize(fq[:-1], dim=0).permute(1, 2, 0)
+    fmap[..., Cc] = fq[-1]
+    fr = scene.feats_ref[level]
+    fref = torch.zeros(fr.shape[0], cs)
+    fref[:, :Cc] = O.l2_normalize(fr[:, :-1], dim=1)
+    fref[:, Cc] = fr[:, -1]
+    return fmap.to(device).contiguous(), fref.to(device).contiguous(), Cc, scene.camera.scale(scene.scales[level])
+
+
+def hip_refine(sc, lam, device, grid, ws):
+    opt = PixTrackOptimizer(dict(num_iters=150, pad=1, n_workgroups=grid))
+    packs = []
+    for level in reversed(range(3)):
+        fmap, fref, Cc, cam = pack_level(sc, level, device)
+        packs.append(LevelPack(fmap, fref, Cc, cam, lam[level]))
+    p3d = torch.from_numpy(sc.p3d).float().to(device)
+    res = PixTrackOptimizer.refine_levels(p3d, packs, sc.T_init, opt.native_conf(), ws).result()
+    return res.T.R.double().cpu(), res.T.t.double().cpu(), [int(i) for i in res.iters], bool(res.failed)
+
+
+def summary(rot, tra, iters_differ):
+    q = lambda a, p: float(np.percentile(np.asarray(a), p))
+    return {"n": len(rot), "rot_rad": {"p50": q(rot, 50), "p90": q(rot, 90), "p99": q(rot, 99), "max": float(np.max(rot))},
+            "trans": {"p50": q(tra, 50), "p90": q(tra, 90), "p99": q(tra, 99), "max": float(np.max(tra))},
+            "runs_whose_iteration_counts_differ": int(np.sum(iters_differ)),
+            "runs_beyond_5e-4": int(np.sum((np.asarray(rot) > 5e-4) | (np.asarray(tra) > 5e-4))),
+            "runs_beyond_1e-3": int(np.sum((np.asarray(rot) > 1e-3) | (np.asarray(tra) > 1e-3)))}
+
+
+def main():
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    device = torch.device("cuda:0")
+    ws = torch.zeros(int(_lib.lib().pxt_lm_workspace_bytes()), dtype=torch.uint8, device=device)
+    lam = [O.damping_lambda(torch.as_tensor(c, dtype=torch.float32)) for c in CONSTS]
+    out = {"what": __doc__.split("\n")[0], "seeds": n_seeds, "n_points": 2048,
+           "stop_rule": "dt < 5e-3 and dR < 0.05 deg, or |grad| < 1e-4 (pixtrack/optimizers/pixtrack_optimizer.py:5-18)"}
+    t_all = time.time()
+    for (w, h) in ((320, 240), (640, 480)):
+        A = {"rot": [], "tra": [], "it": []}
+        B = {g: {"rot": [], "tra": [], "it": []} for g in (32, 128)}
+        failed = 0
+        for s in range(n_seeds):
+            sc = make_lm_scene(seed=5000 + s, width=w, height=h, n_points=2048, sigma_px=2.0)
+            log = O.LMLog()
+            ref = O.refine_pose_using_features(sc.feats_query, sc.scales, sc.camera._data, torch.from_numpy(sc.R_init),
+                                               torch.from_numpy(sc.t_init), sc.feats_ref, torch.from_numpy(sc.p3d), lam,
+                                               O.LMConf(), log=log)
+            R0, t0, it0, f0 = hip_refine(sc, lam, device, 0, ws)
+            if not ref["success"] or f0:
+                failed += 1
+                continue
+            A["rot"].append(O.rotation_angle_rad(R0, ref["R"]))
+            A["tra"].append(float((t0 - ref["t"]).norm()))
+            A["it"].append(list(log.num_iters) != it0)
+            for g in B:
+                Rg, tg, itg, fg = hip_refine(sc, lam, device, g, ws)
+                B[g]["rot"].append(O.rotation_angle_rad(Rg, R0))
+                B[g]["tra"].append(float((tg - t0).norm()))
+                B[g]["it"].append(itg != it0)
+        out[f"{w}x{h}"] = {"hip_vs_oracle": summary(A["rot"], A["tra"], A["it"]),
+                           **{f"hip_grid{g}_vs_hip_default": summary(B[g]["rot"], B[g]["tra"], B[g]["it"]) for g in B},
+                           "scenes_skipped_failed": failed}
+    out["seconds"] = round(time.time() - t_all, 1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,6 @@ def test_runtime_variants_are_bit_identical():
     for knobs in ({"PXT_NGP_PIPES": "2"}, {"PXT_NGP_PIPES": "3"}, {"PXT_UNET_STREAMS": "1"},
                   {"PXT_MASK_BYTES": "1"}, {"PXT_UNET_FUSE_FIRST": "0"}, {"PXT_UNET_MERGE_HEADS": "0"},
                   {"PXT_NGP_GRID": "96", "PXT_NGP_GRID_RAYGEN": "64"},
-                  {"PXT_NGP_GRID": "1024", "PXT_NGP_GRID_DIV": "1"},
+                  {"PXT_NGP_GRID": "1024", "PXT_NGP_GRID_DIV": "1"}, {"PXT_NGP_COOP": "0"},
                   {"PXT_NGP_GRID": "16384", "PXT_NGP_GRID_DIV": "4096", "PXT_NGP_PIPES": "4", "PXT_NGP_GRID_RAYGEN": "8192"}):
         assert _digests(knobs) == base, knobs
