@@ -49,7 +49,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 # commits at which the committed rocprofv3 PMC summaries were collected (files without a `_meta` record)
-PROFILE_COMMITS = {"r04": "57b838f", "r03": "a686fc1", "r02": "2a1bccf"}
+PROFILE_COMMITS = {"r06": "e164c99", "r05": "0f536bf", "r04": "57b838f", "r03": "a686fc1", "r02": "2a1bccf"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
 # the dominant kernel: gathers + both MLPs of a round's samples (Shade + Depth of the same rays: MODE 2)
@@ -378,6 +378,9 @@ def other_config_extra(argv, timeout_s=420):
             rec["solo_aggregate_frames_per_s"] = line["solo_runs"]["aggregate_frames_per_s"]
             rec["lockstep_speedup"] = line["solo_runs"]["lockstep_speedup"]
             rec["max_abs_pose_difference_vs_solo"] = max(line["solo_runs"]["max_abs_pose_difference_vs_lockstep"])
+            vb = line.get("value_bit_identical") or {}
+            rec["value_bit_identical"] = {k: vb.get(k) for k in ("frames_per_s", "bit_identical_to_solo_runs", "tracked_ok")}
+            rec["max_rot_err_vs_gt_rad"] = line.get("max_rot_err_vs_gt_rad")
             st = line.get("roofline_stages") or {}
             rec["unet_batched"] = {k: st["unet"][k] for k in ("images_per_call", "ms_per_image_pair", "achieved", "frac")} if "unet" in st else None
             rec["lm_batched"] = {k: st["lm"][k] for k in ("problems_per_launch", "kernel_us", "us_per_problem")} if "lm" in st else None
@@ -735,6 +738,46 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
                 "max_rot_err_vs_gt_rad_solo": solo_err, "max_rot_err_vs_gt_rad_lockstep": lock_err,
                 "what": "untimed second pass: the same frames tracked by one-object trackers one after the other (aggregate = "
                         "all frames / summed time); pose difference = largest |element| difference of the 12 pose floats"}
+        # third pass: the lock-step configuration whose poses are BIT-identical to one-object runs (every image planned as a
+        # batch of one; the LM grid of both sides 32 workgroups per problem - the solo default of 128 x 8 problems does not
+        # fit the 256 resident workgroups of a persistent launch) - timed like `value`, then checked against eight solo runs
+        grid_bit = 32
+
+        def fresh_grid(u):
+            tr = fresh(u)
+            for opt in tr.localizer.optimizer:
+                opt.conf.n_workgroups = grid_bit
+            return tr
+
+        tb = [fresh_grid(u) for u in units]
+        multi_b = MultiObjectTracker(tb, lm_workgroups=grid_bit, per_image_plan=True, n_groups=args.groups)
+        gc.collect()
+        gc.disable()
+        for i in range(args.warmup):
+            multi_b.run_single_frames([(names[i], frames[u][i]) for u in units])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.warmup, n):
+            multi_b.run_single_frames([(names[i], frames[u][i]) for u in units])
+        torch.cuda.synchronize()
+        el_b = time.perf_counter() - t1
+        gc.enable()
+        worst, ok_b = 0.0, 0
+        for u, trb in zip(units, tb):
+            tr = fresh_grid(u)
+            for i in range(n):
+                tr.run_single_frame((names[i], frames[u][i]))
+            torch.cuda.synchronize()
+            a = parallel.pack_pose_records(tr.pose_history, names[:n])
+            b = parallel.pack_pose_records(trb.pose_history, names[:n])
+            worst = max(worst, float((a - b).abs().max()))
+            ok_b += sum(1 for nm in timed if _tracked(trb.pose_history[nm]))
+            del tr
+        solo["value_bit_identical"] = {
+            "frames_per_s": round(len(units) * args.steps / el_b, 2), "tracked_ok": ok_b, "lm_workgroups_per_problem": grid_bit,
+            "unet_per_image_plan": True, "bit_identical_to_solo_runs": worst == 0.0, "max_abs_pose_record_difference": worst,
+            "what": "lock-step with every image planned as a batch of one and both sides' LM grid at 32 workgroups per problem: "
+                    "poses, decisions and costs compared with eight one-object runs of the same frames, all frames (warm-up included)"}
     if rank != 0:
         return
     rot, tra, per_obj = [], [], {}
@@ -776,6 +819,8 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
         "mean_rot_err_vs_gt_rad": round(float(np.mean(rot)), 6) if rot else None,
         "mean_trans_err_vs_gt": round(float(np.mean(tra)), 6) if tra else None,
         "per_object_error_vs_synthetic_gt": per_obj,
+        "value_bit_identical": (solo or {}).pop("value_bit_identical", None),
+        "max_rot_err_vs_gt_rad": {k: v["max_rot_err_rad"] for k, v in per_obj.items()},
         "roofline": None, "roofline_stages": stages, "solo_runs": solo,
         "cpu_baseline": {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                          "sample": "reported with the frames640 workload only"},
@@ -1072,8 +1117,9 @@ def main():
                 "rays_in_the_box_per_render": round(stats[1] / max(n_renders, 1), 1),
                 "note": ("one launch = one render (a frame's mask + reference image in one march); timed with HIP events on "
                          "the render's own stream over every 4th render of the timed region; nothing runs beside it"),
-                "binding_resource": ("gather ISSUE and VALU together (128 gather instructions per 64 samples at a quad of lanes "
-                                     "per clock of the CU's address unit; ~2500 VALU instructions per wave step), NOT HBM bytes: "
+                "binding_resource": ("VALU issue (~3100 VALU instructions per wave step of 64 sample slots, VALU busy 0.74-0.78 at 3.3 waves "
+                                     "per SIMD; the gathers - 7.9 M vector-memory reads per render after the box fetch - come second), "
+                                     "NOT HBM bytes: "
                                      "`bound` keeps the contract's hbm|mfma vocabulary and prices the ALGORITHMIC gather bytes "
                                      "against the HBM peak; `traffic` is the fabric side (tables cache-resident), `l2` prices the "
                                      "L2 requests against the L2's peak (DESIGN.md 3.3)"),

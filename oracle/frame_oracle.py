@@ -178,6 +178,23 @@ def track_frame(assets: Dict, R: np.ndarray, t: np.ndarray, query_image: np.ndar
                 n_points=len(ids), log=log)
 
 
+def covisibility(model3d) -> Dict[int, Dict[int, int]]:
+    """extract_covisibility (pixtrack/utils/hloc_utils.py:28-47): {image id: {other image id: number of shared 3-D
+    points}}, the inner dictionaries in the order the shared points' tracks are met (nearest_reference's ties keep it)."""
+    out = {}
+    for image_id, image in model3d.dbs.items():
+        counts: Dict[int, int] = {}
+        for pid in image.point3D_ids:
+            if pid == -1:
+                continue
+            for other in model3d.points3D[int(pid)].image_ids:
+                if int(other) != image_id:
+                    counts[int(other)] = counts.get(int(other), 0) + 1
+        if counts:
+            out[image_id] = counts
+    return out
+
+
 def nearest_reference(model3d, covis, curr_ref: int, R_qry: np.ndarray, n_shared: int = 50) -> int:
     """update_reference_ids (pixloc_tracker_r9.py:120-143): the current reference and its covisible images
     (> 50 shared points) ranked by the geodesic distance of their rotation to the current pose; K = 1."""
@@ -197,9 +214,13 @@ def track_sequence(assets: Dict, frames, spp: int = 8, covis=None, lm_conf: Opti
     """PixLocPoseTrackerR9.refine over CONSECUTIVE frames (pixloc_tracker_r9.py:216-275): what is carried from one
     frame to the next is the pose (updated only by an accepted frame, :258-265), the success flag (a failed frame
     makes the next one run UNMASKED at the scales last set, :218-225), the cost threshold (1.1 x the first frame's
-    cost, frozen, :251-256) and the reference id (:120-143; here it must not change - the features of a frame are
-    extracted for the reference ids in force BEFORE the update, :160-203, a case the frame fixtures leave out).
-    ``frames``: float32 HWC 0..255.  Returns one record per frame."""
+    cost, frozen, :251-256) and the reference id (:120-143).  With ``covis`` (covisibility(model3d)) the reference id
+    follows the reference's policy: every frame after the first renders a new dynamic reference (THRESH = 0, :171-203),
+    extracts its sparse features at the 3-D points of the reference id IN FORCE (create_dynamic_reference_image,
+    :153-158) and only then moves the id to the covisible image (> 50 shared points) whose rotation is nearest to the
+    frame's start pose (update_reference_ids, :120-143) - so a switch takes effect one frame later; the refinement
+    reads its points from the stored features (pixloc_pose_refiners.py:243-250).  Without ``covis`` the id stays the
+    upright reference.  ``frames``: float32 HWC 0..255.  Returns one record per frame."""
     model3d = assets["model3d"]
     ref_id = model3d.name2id[assets["upright_ref_img"]]
     im = model3d.dbs[ref_id]
@@ -212,17 +233,18 @@ def track_sequence(assets: Dict, frames, spp: int = 8, covis=None, lm_conf: Opti
             multiscale, cold = (4, 1), False
         elif success:
             multiscale, use_mask = (1,), True
-        if i > 0 and covis is not None:
-            assert nearest_reference(model3d, covis, ref_id, np.asarray(R)) == ref_id, "reference switch: not covered"
         keep = {}
         res = track_frame(assets, R, t, np.asarray(frame, np.float32), ref_id, multiscale=multiscale, use_mask=use_mask,
                           lm_conf=lm_conf, spp=spp, keep=keep)
+        ref_used = ref_id
+        if i > 0 and covis is not None:  # (after this frame's features were taken at the old id's points)
+            ref_id = nearest_reference(model3d, covis, ref_id, np.asarray(R))
         cost = res["cost"]
         if thr is None:
             thr = cost + 0.1 * cost
         ok = bool(res["success"] and cost <= thr)
         rec = dict(frame=i, multiscale=tuple(multiscale), masked=use_mask, lm_success=bool(res["success"]), success=ok,
-                   cost=cost, cost_threshold=thr, R_start=np.asarray(R, np.float64).copy(),
+                   cost=cost, cost_threshold=thr, ref_id=ref_used, R_start=np.asarray(R, np.float64).copy(),
                    t_start=np.asarray(t, np.float64).copy(), iters=list(res["iters"]), n_points=res["n_points"],
                    R=res["R"].numpy() if res["R"] is not None else None,
                    t=res["t"].numpy() if res["t"] is not None else None,

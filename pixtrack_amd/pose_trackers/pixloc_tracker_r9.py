@@ -1,15 +1,13 @@
 """PixLocPoseTrackerR9 -- the production tracker and its CLI
 (reference pixtrack/pose_trackers/pixloc_tracker_r9.py:32-318).
 
-Per-frame policy kept from the reference: cold start refines at image scales
-[4, 1] from the upright reference pose; afterwards scale [1] with the query masked by the
-dilated NeRF depth silhouette of the previous pose; the reference view is re-rendered with
-the NeRF at the current pose every frame (the THRESH = 0 dynamic-reference cache never
+Per-frame policy kept from the reference: cold start refines at image scales [4, 1] from the upright
+reference pose; afterwards scale [1] with the query masked by the dilated NeRF depth silhouette of the previous pose; the
+reference view is re-rendered with the NeRF at the current pose every frame (the THRESH = 0 dynamic-reference cache never
 hits, Appendix D.2); success = optimiser success AND cost <= 1.1 x first-frame cost.
 
-Device residency (the MI355X-first part): the NeRF frames, the mask, the query image, both
-feature pyramids and the sparse reference features never leave HBM; one small device->host
-copy per LM call returns the pose and the iteration log.
+Device residency (the MI355X-first part): the NeRF frames, the mask, the query image, both feature pyramids and the sparse
+reference features never leave HBM; the LM kernel writes the pose and the iteration log into pinned host memory.
 
 CLI (unchanged): --object_path P --query DIR --out_dir DIR [--frames N] [--debug 0/1/2];
 env UPRIGHT_REF_IMG, OBJ_AABB; outputs poses.pkl, trackers.pkl.
@@ -101,29 +99,21 @@ class PixLocPoseTrackerR9(PoseTracker):
             snapshot = str(Path(object_path) / "pixtrack/instant-ngp/snapshots/weights.msgpack")
         self.testbed = initialize_ingp(snapshot, self._render_aabb(assets), device=self.device)
         self.localizer.refiner.warm_reference_points()  # static per-reference tables, off the frame path
-        self.dynamic_id = None
-        self.hits = 0
-        self.misses = 0
-        self.cache_hit = False
-        self.cost_threshold = None
-        self.relocalization_count = 0
+        self.dynamic_id, self.cache_hit, self.cost_threshold, self.camera = None, False, None, None
+        self.hits = self.misses = self.relocalization_count = 0
         self.success = True
-        self.camera = None
         self.spp = 8  # run_vis_on_poses.py:29
-        # The mask (Depth, query camera) and the reference image (Shade, SfM camera 1 x
-        # reference_scale) are rendered at the same pose each frame; when the two cameras coincide
-        # (same size and fx: all get_nerf_image reads) one march yields both, bit for bit.
-        self.fuse_identical_views = True
         self.batch_frame_images = True  # reference render + masked query in one batched UNet pass
         self._fused_reference = None  # (pose object, uint8 image) handed from get_mask to get_reference_image
-        self._ref_cam_cache = None
-        self._coincide_cache = None
+        self._ref_cam_cache = self._coincide_cache = None
         self.keep_feature_history = False  # the reference leaks one entry per frame (Appendix D.2)
         self.steady_multiscale = [1]  # image scales of a tracked (non-cold-start) frame (:223)
         # A frame's mask (Depth, query camera) and reference image (Shade, SfM camera 1 x reference_scale) are rendered at
-        # the same pose: ONE march when the two cameras coincide, else both renders as ONE chain of launches
-        # (Testbed.render_frame_pair_device); the renderer's last kernel writes the 8-bit reference image and the mask's
-        # `!= 0` plane itself.  The next frame's renders need only this frame's pose: with `render_ahead` they are enqueued
+        # the same pose: ONE march when the two cameras coincide (fuse_identical_views; same size and fx: all
+        # get_nerf_image reads), else both renders as ONE chain of launches (Testbed.render_frame_pair_device); the
+        # renderer's last kernel writes the 8-bit reference image and the mask's `!= 0` plane itself.
+        self.fuse_identical_views = True
+        # The next frame's renders need only this frame's pose: with `render_ahead` they are enqueued
         # BEHIND this frame's LM launch, their camera taken from the slot(s) the LM kernel's epilogue fills, instead of
         # after the host has read the result, run the policy and converted the pose (~0.1 ms of GPU idle per frame).  They
         # are consumed only if the host, once it knows the pose, arrives at the same 12 camera floats; otherwise (failed
@@ -132,10 +122,9 @@ class PixLocPoseTrackerR9(PoseTracker):
         self._ahead_cam = None   # the pinned camera record the LM epilogue of this frame writes
         self._ahead = None       # the render queued behind the last LM launch
         self._ahead_ok = None    # ... once verified: (pose object it is valid for, mask, uint8 reference image)
-        self.renders_ahead_used = 0
-        self.renders_ahead_dropped = 0   # camera record never arrived within the poll bound
-        self.renders_ahead_rejected = 0  # host and device disagree on a camera bit
-        self.renders_ahead_stale = 0     # view settings changed between enqueue and use
+        # queued renders: consumed / camera record never arrived within the poll bound / host and device disagree on a camera
+        # bit / view settings changed between enqueue and use
+        self.renders_ahead_used = self.renders_ahead_dropped = self.renders_ahead_rejected = self.renders_ahead_stale = 0
 
     # ------------------------------------------------------------------ per-variant set-up
     def _initial_reference_ids(self, assets):
@@ -158,18 +147,13 @@ class PixLocPoseTrackerR9(PoseTracker):
         self.relocalization_count += 1
 
     def start_segment(self, pose_init: Pose):
-        """Cold start of a frame SEGMENT that does not begin at the video's first frame (BASELINE
-        configs[4]: one video cut into per-GPU segments).  The reference has no such entry point - its
-        only cold start is the upright reference pose of frame 0 (:95-106) - so a segment head needs a
-        pose from outside (a relocaliser; the synthetic runs pass a perturbed ground truth).  What
-        follows is the reference's cold-start policy: image scales [4, 1], no mask, nearest reference
-        image by rotation, cost threshold frozen again from this segment's first frame."""
-        self.pose = pose_init
-        self.cold_start = True
-        self.success = True
-        self.cost_threshold = None
-        self.dynamic_id = None
-        self.cache_hit = False
+        """Cold start of a frame SEGMENT that does not begin at the video's first frame (BASELINE configs[4]: one video cut
+        into per-GPU segments).  The reference has no such entry point - its only cold start is the upright reference pose
+        of frame 0 (:95-106) - so a segment head needs a pose from outside (a relocaliser; the synthetic runs pass a
+        perturbed ground truth).  What follows is the reference's cold-start policy: image scales [4, 1], no mask, nearest
+        reference image by rotation, cost threshold frozen again from this segment's first frame."""
+        self.pose, self.cold_start, self.success = pose_init, True, True
+        self.cost_threshold, self.dynamic_id, self.cache_hit = None, None, False
         R_qry = pose_init.numpy()[0]
         dbs = self.localizer.model3d.dbs
         self.reference_ids = sorted(dbs, key=lambda r: geodesic_distance_for_rotations(R_qry, dbs[r].qvec2rotmat()))[:1]
@@ -212,19 +196,15 @@ class PixLocPoseTrackerR9(PoseTracker):
             self._ref_cam_cache = (key, PixCamera.from_colmap(self.localizer.model3d.cameras[1]).scale(key))
         return self._ref_cam_cache[1]
 
-    @staticmethod
-    def _view_key(cam):
-        """(width, height, fx): all that get_nerf_image reads from a camera (run_vis_on_poses.py:30-36)."""
-        return int(cam.size[0]), int(cam.size[1]), float(cam.f[0])
-
     def _views_coincide(self) -> bool:
+        """Mask and reference cameras agree in (width, height, fx) - all that get_nerf_image reads from a camera
+        (run_vis_on_poses.py:30-36); the answer only changes with the camera object or the reference scale."""
         if not self.fuse_identical_views or self.camera is None:
             return False
-        # per-frame call: the answer only changes with the camera object or the reference scale
         key = (id(self.camera), float(self.reference_scale))
         if self._coincide_cache is None or self._coincide_cache[0] != key:
-            qk = self._view_key(self.camera)
-            self._coincide_cache = (key, self._view_key(self._reference_camera()) == qk, qk)
+            vk = lambda cam: (int(cam.size[0]), int(cam.size[1]), float(cam.f[0]))
+            self._coincide_cache = (key, vk(self._reference_camera()) == vk(self.camera))
         return self._coincide_cache[1]
 
     def get_reference_image(self, pose) -> torch.Tensor:
@@ -270,9 +250,8 @@ class PixLocPoseTrackerR9(PoseTracker):
         if self._ahead_ok is not None and self._ahead_ok[0] is pose:
             _, mask, ref_u8, views = self._ahead_ok
             self._ahead_ok = None
-            # the queued render also baked in focal length, size, spp, lens, render box, background and minimum
-            # transmittance as they were when it was enqueued: it stands in for this frame's render only if
-            # they are what this frame would use
+            # (it also baked in focal length, size, spp, lens, render box, background and minimum transmittance as they were
+            # when it was enqueued: it stands in for this frame's render only if they are what this frame would use)
             if views == self._ahead_views_now():
                 self._fused_reference = (pose, ref_u8)
                 self.renders_ahead_used += 1
@@ -310,11 +289,17 @@ class PixLocPoseTrackerR9(PoseTracker):
             ref_u8, nz = out["rgb_u8"], out["depth_nz"]
         else:
             nz, ref_u8 = tb.render_frame_pair_device(views[0], views[1], spp, from_slot=from_slot)
-        mask = torch.empty(height, width, dtype=torch.uint8, device=self.device)
-        ops.depth_mask_plane(nz, 1, 5, mask)  # erode 5x5 once, dilate 5x5 five times (:211-213)
+        mask = self._mask_of(nz)
         if pose is not None:
             self._fused_reference = (pose, ref_u8)
         return mask, ref_u8
+
+    def _mask_of(self, nz):
+        """get_mask's morphology on the `uint8(depth * 255) != 0` plane a render wrote: erode 5x5 once, dilate 5x5 five
+        times (:211-213)."""
+        mask = torch.empty(nz.shape[0], nz.shape[1], dtype=torch.uint8, device=self.device)
+        ops.depth_mask_plane(nz, 1, 5, mask)
+        return mask
 
     def _lm_camera(self):
         """What the refiner hands to the LM launch of a frame whose next render will be queued behind it: the pose ->
@@ -341,21 +326,14 @@ class PixLocPoseTrackerR9(PoseTracker):
         Testbed.render_frame_batch_device): (width, height, spp) of this tracker's one-march mask + reference render with
         the testbed's view set for it - or None when the frame's render is not of that kind (two different cameras), in
         which case _render_ahead() is to be called as usual."""
-        import math
-
         if not self._views_coincide():
             return None
-        width, height, fl_x = self._coincide_cache[2]
-        self.testbed.fov = math.atan(width / (fl_x * 2)) * 2 * 180 / np.pi
+        width, height, self.testbed.fov = self._frame_views()[0]
         return int(width), int(height), int(self.spp)
 
     def _render_ahead_accept(self, out):
         """What _render_ahead() does after its render, for a render that was part of a batched chain."""
-        views = self._ahead_views_now()
-        nz, ref_u8 = out["depth_nz"], out["rgb_u8"]
-        mask = torch.empty(nz.shape[0], nz.shape[1], dtype=torch.uint8, device=self.device)
-        ops.depth_mask_plane(nz, 1, 5, mask)  # erode 5x5 once, dilate 5x5 five times (:211-213)
-        self._ahead = ([self._ahead_cam], mask, ref_u8, views)
+        self._ahead = ([self._ahead_cam], self._mask_of(out["depth_nz"]), out["rgb_u8"], self._ahead_views_now())
 
     def _ahead_views_now(self):
         """What a render queued now bakes in besides the camera pose, per render of the frame: focal length, lens, render
@@ -424,8 +402,8 @@ class PixLocPoseTrackerR9(PoseTracker):
             refiner.conf.multiscale = list(self.steady_multiscale)
             refiner.query_mask = self.get_mask(self.pose)  # multiplied inside the first conv
 
-        # The masked query is fully known here, before the reference render is encoded: announce
-        # it so both images of the frame go through the UNet in one batched pass.
+        # The masked query is fully known here, before the reference render is encoded: announce it so both images of
+        # the frame go through the UNet in one batched pass.
         if not lockstep and self.batch_frame_images and refiner.conf.multiscale == [1]:
             refiner.feature_extractor.stage(query_image, 1, refiner.query_mask, True)
         else:
@@ -484,9 +462,7 @@ class PixLocPoseTrackerR9(PoseTracker):
         return success
 
     def get_query_frame_iterator(self, image_folder, max_frames):
-        if isinstance(image_folder, (ArrayIterator, ImageIterator)):
-            return image_folder
-        return ImageIterator(image_folder, max_frames)
+        return image_folder if isinstance(image_folder, (ArrayIterator, ImageIterator)) else ImageIterator(image_folder, max_frames)
 
     def save_poses(self, pixloc_pickles: bool = False):
         """poses.pkl (reference :281-284).  ``pixloc_pickles`` writes Pose/Camera under pixloc's

@@ -16,10 +16,17 @@ from the synthetic ground truth over 60 steps, profiles/r05_bench_objects8.json)
 size: does the ORACLE drift as the HIP path does?  The answer (per-frame errors against ground truth of both paths) is
 printed by tests/test_objects8_golden_gpu.py and recorded in DESIGN.md section 6.
 
+``--switch``: roncelli_blankk for 40 frames -> tests/golden/roncelli_switch40.npz: around frame 35 the orbit's rotation
+comes nearer to the neighbouring mapping image than to the upright one and update_reference_ids
+(pixloc_tracker_r9.py:120-143) moves the reference id - one frame later the refinement runs on ANOTHER image's 3-D
+points (the thin slab's large face, seen at a grazing angle).  The reference-switch path had no oracle fixture until
+round 6; it is also where the HIP track of this box stalls at full size (profiles/r06_drift_probe_roncelli_blankk.log).
+
 CPU only; one process per object.
 
     python scripts/make_objects8_golden.py            # the eight 3-frame records
     python scripts/make_objects8_golden.py --seq      # + the two 12-frame sequences
+    python scripts/make_objects8_golden.py --switch   # only the 40-frame reference-switch sequence
 """
 import multiprocessing as mp
 import sys
@@ -34,6 +41,7 @@ OUT = ROOT / "tests" / "golden" / "objects8_160x120.npz"
 OUT_SEQ = ROOT / "tests" / "golden" / "objects8_seq12.npz"
 SPP, N_POINTS, SEED0 = 2, 3000, 1100
 SEQ_OBJECTS, SEQ_FRAMES = ("bottle", "roncelli_blankk"), 12
+OUT_SWITCH, SWITCH_OBJECT, SWITCH_FRAMES = ROOT / "tests" / "golden" / "roncelli_switch40.npz", "roncelli_blankk", 40
 
 
 def size_of(name):
@@ -47,7 +55,6 @@ def track_object(job):
     torch.set_num_threads(1)
     from oracle import frame_oracle as FO
     from oracle import ngp_oracle as NO
-    from pixtrack_amd.model3d import extract_covisibility
     from pixtrack_amd.synthetic import make_tracking_assets
 
     W, H = size_of(name)
@@ -62,7 +69,7 @@ def track_object(job):
         u8 = FO.to_u8(rgba).astype(np.float32)
         sigma = first_sigma if i == 0 else 2.0
         frames.append(np.clip(np.rint(u8 + rng.normal(size=u8.shape) * sigma), 0, 255).astype(np.uint8))
-    covis = extract_covisibility(assets["model3d"])
+    covis = FO.covisibility(assets["model3d"])
     recs = FO.track_sequence(assets, [f.astype(np.float32) for f in frames], spp=SPP, covis=covis)
     out = {"width": W, "height": H, "seed": SEED0 + k, "n_frames": n_frames, "first_sigma": first_sigma,
            "queries": np.stack(frames), "gt_R": np.stack([g[0] for g in assets["gt_poses"]]),
@@ -76,13 +83,14 @@ def track_object(job):
         out[f"f{i}_cost"] = r["cost"]
         out[f"f{i}_cost_threshold"] = r["cost_threshold"]
         out[f"f{i}_iters"] = np.array(r["iters"])
+        out[f"f{i}_ref_id"], out[f"f{i}_n_points"] = r["ref_id"], r["n_points"]
         out[f"f{i}_R_start"], out[f"f{i}_t_start"] = r["R_start"], r["t_start"]
         if r["R"] is not None:
             out[f"f{i}_R"], out[f"f{i}_t"] = r["R"], r["t"]
             Rg, tg = assets["gt_poses"][i]
             rot = float(np.arccos(np.clip((np.trace(r["R"] @ Rg.T) - 1) / 2, -1, 1)))
             out[f"f{i}_rot_err_gt"], out[f"f{i}_trans_err_gt"] = rot, float(np.linalg.norm(r["t"] - tg))
-        if r["mask"] is not None:
+        if r["mask"] is not None and n_frames <= SEQ_FRAMES:
             out[f"f{i}_mask_bits"] = np.packbits(r["mask"].astype(np.uint8))
             out[f"f{i}_depth_fragile_count"] = int(FO.fragile_depth_pixels(r["depth_rgba"]).sum())
             out[f"f{i}_depth_u8_nonzero_bits"] = np.packbits((FO.to_u8(r["depth_rgba"])[..., 0] != 0).astype(np.uint8))
@@ -91,7 +99,7 @@ def track_object(job):
                                                 r["t_start"], qcam, 1, SPP), return_stats=True)
             out[f"f{i}_depth_samples"], out[f"f{i}_depth_rays_hit"] = st["samples"], st["rays_hit"]
         log.append((i, r["multiscale"], r["masked"], r["lm_success"], r["success"], round(r["cost"], 5),
-                    round(out.get(f"f{i}_rot_err_gt", float("nan")), 5), r["iters"]))
+                    round(out.get(f"f{i}_rot_err_gt", float("nan")), 5), r["iters"], "ref", r["ref_id"], r["n_points"]))
     return name, out, log, round(time.time() - t_all, 1)
 
 
@@ -99,6 +107,16 @@ def main():
     from pixtrack_amd import parallel
 
     objs = parallel.load_object_configs()
+    if "--switch" in sys.argv:
+        k = [o["name"] for o in objs].index(SWITCH_OBJECT)
+        name, rec, log, secs = track_object((k, SWITCH_OBJECT, objs[k]["aabb"], SWITCH_FRAMES, 12.0))
+        for line in log:
+            print("   ", *line)
+        ids = [int(rec[f"f{i}_ref_id"]) for i in range(SWITCH_FRAMES)]
+        assert len(set(ids)) >= 2 and all(rec[f"f{i}_success"] for i in range(SWITCH_FRAMES)), ids
+        np.savez_compressed(OUT_SWITCH, spp=SPP, n_points=N_POINTS, **{f"{name}/{key}": v for key, v in rec.items()})
+        print("wrote", OUT_SWITCH, round(OUT_SWITCH.stat().st_size / 1e6, 2), "MB,", secs, "s; reference ids", ids)
+        return
     seq = "--seq" in sys.argv
     jobs = [(k, o["name"], o["aabb"], 3, 12.0) for k, o in enumerate(objs)]
     if seq:

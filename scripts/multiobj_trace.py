@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def fam(n):
-    for key, name in (("lm_refine_batch", "lm_batch"), ("lm_refine", "lm"), ("ngp_shade", "ngp_shade"), ("ngp_tail", "ngp_tail"),
+    for key, name in (("lm_refine_batch", "lm_batch"), ("lm_refine", "lm"), ("ngp_render_kernel", "ngp_render"), ("ngp_raygen", "ngp_raygen"),
                       ("ngp_", "ngp_other"), ("conv3x3", "conv"), ("conv_first", "conv"), ("head_", "heads"),
                       ("splitk", "conv_splitk"), ("maxpool", "conv_pool"), ("sample_sparse", "sample"), ("depth_mask", "mask")):
         if key in n:

@@ -6,7 +6,7 @@ rows = c.execute("select name,start,end,queue_id from kernels order by start").f
 idx = [i for i, r in enumerate(rows) if "ngp_resolve" in r[0]]
 a = idx[-2] + 1; b = idx[-1]
 rows = rows[a:b + 1]
-first = next(i for i, r in enumerate(rows) if "ngp_compact_kernel<true>" in r[0] or "ngp_compact_march_kernel<true" in r[0])
+first = next(i for i, r in enumerate(rows) if "ngp_raygen_kernel" in r[0])
 rows = rows[first:]
 t0 = rows[0][1]
 qs = sorted({r[3] for r in rows})

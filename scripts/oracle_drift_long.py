@@ -25,6 +25,9 @@ import numpy as np
 def main():
     name, n_frames = sys.argv[1], int(sys.argv[2])
     W, H, SPP = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (640, 480, 8)
+    # a 6th argument: the seed of synthetic.render_query_frames' torch generator (the bench's is 5) - the oracle then tracks
+    # the noise realisation the HIP run saw instead of its own numpy one
+    torch_seed = int(sys.argv[6]) if len(sys.argv) > 6 else None
     import torch
 
     torch.set_num_threads(2)
@@ -39,24 +42,36 @@ def main():
     ngp = FO.ngp_model(assets["snapshot"])
     qcam = FO.colmap_camera_to_pix(assets["query_camera"])
     rng = np.random.default_rng(1002 + u + 177)
+    tgen = torch.Generator(device="cpu").manual_seed(torch_seed) if torch_seed is not None else None
     model3d = assets["model3d"]
     ref_id = model3d.name2id[assets["upright_ref_img"]]
     im = model3d.dbs[ref_id]
     R, t = im.qvec2rotmat(), np.asarray(im.tvec, np.float64)
     cold, success, thr, multiscale = True, True, None, (1,)
-    print(f"# {name} box {objs[u]['aabb']} {W}x{H} spp {SPP} frames {n_frames} procs {NO.DEFAULT_PROCS}", flush=True)
-    print("# frame masked lm_ok tracked cost thr rot_err_gt_rad trans_err_gt iters seconds", flush=True)
+    # the reference id follows update_reference_ids (pixloc_tracker_r9.py:120-143; FO.track_sequence's note) unless the
+    # 7th argument is "pinned" (the id stays the upright reference: what this script did before the policy was restated)
+    covis = None if (len(sys.argv) > 7 and sys.argv[7] == "pinned") else FO.covisibility(model3d)
+    print(f"# {name} box {objs[u]['aabb']} {W}x{H} spp {SPP} frames {n_frames} procs {NO.DEFAULT_PROCS}"
+          + (f" noise: torch generator seed {torch_seed} (the HIP run's realisation)" if tgen is not None else " noise: numpy (own realisation)") + (" reference id: pinned" if covis is None else " reference id: update_reference_ids"), flush=True)
+    print("# frame masked lm_ok tracked cost thr rot_err_gt_rad trans_err_gt iters seconds ref_id n_points", flush=True)
     for i, (Rg, tg) in enumerate(assets["gt_poses"]):
         t0 = time.time()
         rgba = NO.render(ngp, FO.nerf_view(assets["snapshot"], assets["nerf2sfm"], assets["aabb"], Rg, tg, qcam, 0, SPP))
         u8 = FO.to_u8(rgba).astype(np.float32)
-        frame = np.clip(np.rint(u8 + rng.normal(size=u8.shape) * (24.0 if i == 0 else 2.0)), 0, 255).astype(np.float32)
+        sigma = 24.0 if i == 0 else 2.0
+        if tgen is not None:  # (torch's clamp-then-round of render_query_frames; the same draws in the same order)
+            frame = (torch.from_numpy(u8[..., :3].copy()) + torch.randn(u8[..., :3].shape, generator=tgen) * sigma).clamp_(0, 255).round_().numpy()
+        else:
+            frame = np.clip(np.rint(u8 + rng.normal(size=u8.shape) * sigma), 0, 255).astype(np.float32)
         use_mask = False
         if cold:
             multiscale, cold = (4, 1), False
         elif success:
             multiscale, use_mask = (1,), True
         res = FO.track_frame(assets, R, t, frame, ref_id, multiscale=multiscale, use_mask=use_mask, spp=SPP)
+        ref_used = ref_id
+        if i > 0 and covis is not None:
+            ref_id = FO.nearest_reference(model3d, covis, ref_id, np.asarray(R))
         cost = res["cost"]
         if thr is None:
             thr = cost + 0.1 * cost
@@ -67,7 +82,7 @@ def main():
         rot = float(np.arccos(np.clip((np.trace(R @ Rg.T) - 1) / 2, -1, 1)))
         tra = float(np.linalg.norm(t - tg))
         print(i, int(use_mask), int(bool(res["success"])), int(ok), f"{cost:.5f} {thr:.5f} {rot:.5f} {tra:.5f}",
-              "/".join(str(v) for v in res["iters"]), round(time.time() - t0, 1), flush=True)
+              "/".join(str(v) for v in res["iters"]), round(time.time() - t0, 1), ref_used, res["n_points"], flush=True)
 
 
 if __name__ == "__main__":

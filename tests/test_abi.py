@@ -77,7 +77,7 @@ def test_product_path_refuses_cpu_tensors():
 
 
 def test_the_timing_instrument_build_still_compiles(tmp_path):
-    """-DPXT_EXP_STAMPS=1 (in-kernel s_memtime stamps read by scripts/{conv,march,lm}_stamps.py) is the one
+    """-DPXT_EXP_STAMPS=1 (in-kernel s_memtime stamps read by scripts/{conv,lm}_stamps.py) is the one
     compile-time switch left in csrc/; it is compiled here so that it cannot rot unnoticed.  (The other round-2
     experiment forks - level-major encoder, dense levels in LDS, x-pair gathers - were deleted in round 3.)"""
     import shutil

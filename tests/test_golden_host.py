@@ -87,3 +87,31 @@ def test_model3d_queries():
     assert set(inv.get(1, [])) == set(sel)
     cov = extract_covisibility(m)
     assert set(cov) == {1, 2, 3, 4}
+
+
+def test_oracle_reference_id_policy_equals_the_hosts():
+    """oracle/frame_oracle.covisibility + nearest_reference (the restatement of update_reference_ids,
+    pixloc_tracker_r9.py:120-143) against the host's extract_covisibility + its vectorised ranking, along an orbit of the
+    thin-slab box (config/roncelli_blankk.sh) that crosses from the upright reference to its neighbour - the switch behind
+    the stall of profiles/r06_drift_probe_roncelli_blankk.log."""
+    from oracle import frame_oracle as FO
+    from pixtrack_amd import parallel
+    from pixtrack_amd.model3d import extract_covisibility
+    from pixtrack_amd.synthetic import make_tracking_assets
+    from pixtrack_amd.utils.pose_utils import geodesic_distances_to
+
+    obj = next(o for o in parallel.load_object_configs() if o["name"] == "roncelli_blankk")
+    assets = make_tracking_assets(seed=1008, width=160, height=120, n_frames=60, aabb=obj["aabb"], n_points=1500)
+    m = assets["model3d"]
+    cov_o, cov_h = FO.covisibility(m), extract_covisibility(m)
+    assert {k: v for k, v in cov_h.items() if v} == cov_o
+    assert all(list(cov_h[k]) == list(cov_o[k]) for k in cov_o)  # (same insertion order: the ranking's ties keep it)
+    ref_o = ref_h = m.name2id[assets["upright_ref_img"]]
+    seen = set()
+    for Rg, _ in assets["gt_poses"]:
+        ref_o = FO.nearest_reference(m, cov_o, ref_o, Rg)
+        ids = list(dict.fromkeys([ref_h] + [k for k, v in cov_h[ref_h].items() if v > 50]))
+        ref_h = ids[int(np.argmin(geodesic_distances_to(Rg, np.stack([m.dbs[r].qvec2rotmat() for r in ids]))))]
+        assert ref_o == ref_h
+        seen.add(ref_o)
+    assert len(seen) >= 2  # the orbit does leave the upright reference
