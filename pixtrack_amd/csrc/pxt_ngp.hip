@@ -190,6 +190,29 @@ __device__ inline unsigned ngp_encode_level(const unsigned* __restrict__ grid, c
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned uint2_t;
+typedef __attribute__((ext_vector_type(2))) float float2_t;
+// The trilinear sum of 8 packed (f0, f1) fp16 corners - corner c = x + 2 y + 4 z, weight ((1 * wx) * wy) * wz, f += w * v in
+// corner order: the arithmetic of ngp_encode_level, with the eight weights formed as FOUR packed products of (x-pair) x
+// (y) x (z) - v_pk_mul_f32 - instead of twelve scalar ones.  Every product has the same operands, every sum the same order:
+// the same bits.
+__device__ __forceinline__ unsigned ngp_trilinear_pk(const unsigned (&vals)[8], float ax, float ay, float az) {
+#pragma clang fp contract(fast)  // (as ngp_encode_level: the f += w * v chain may contract)
+  const float2_t wx = {1.0f - ax, ax};
+  const float wy0 = 1.0f - ay, wz0 = 1.0f - az;
+  const float2_t wxy[2] = {wx * wy0, wx * ay};
+  float2_t f = {0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 8; c += 2) {
+    const float2_t w = wxy[(c >> 1) & 1] * ((c & 4) ? az : wz0);  // corners c (x = 0) and c + 1 (x = 1)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const half2_t hv = __builtin_bit_cast(half2_t, vals[c + x]);
+      const float2_t v = {(float)hv[0], (float)hv[1]};
+      f += w[x] * v;
+    }
+  }
+  return pack_h2(f[0], f[1]);
+}
 // The same level, for a caller whose level is wave-uniform (the shade kernel's rolled level loop): identical indices and
 // arithmetic, with the integer work pared down - the two y and two z hash products (or row / plane
 // offsets) are formed once and shared by the 8 corners (v_mul_lo_u32 is quarter rate), and the gathers
@@ -204,37 +227,29 @@ __device__ inline unsigned ngp_encode_level_uniform(const __amdgpu_buffer_rsrc_t
   const unsigned gx = (unsigned)(int)fx, gy = (unsigned)(int)fy, gz = (unsigned)(int)fz;
   unsigned vals[8];
   const int base = (int)(Lv.offset * 4u);
+  // byte offsets formed directly: ((a ^ b ^ c) & m) << 2 == ((a << 2) ^ (b << 2) ^ (c << 2)) & (m << 2), and a product's
+  // shift is a product by 4 x the constant (mod 2^32) - eight shifts per level less
+  const unsigned gx4[2] = {gx << 2, (gx << 2) + 4u};
   if (Lv.hashed) {
-    const unsigned mask = Lv.size - 1u;
-    const unsigned hy[2] = {gy * 2654435761u, gy * 2654435761u + 2654435761u};
-    const unsigned hz[2] = {gz * 805459861u, gz * 805459861u + 805459861u};
+    const unsigned mask4 = (Lv.size - 1u) << 2;
+    const unsigned hy[2] = {gy * (2654435761u * 4u), gy * (2654435761u * 4u) + 2654435761u * 4u};
+    const unsigned hz[2] = {gz * (805459861u * 4u), gz * (805459861u * 4u) + 805459861u * 4u};
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const unsigned idx = ((gx + (c & 1)) ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask;
-      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
+      const unsigned off = (gx4[c & 1] ^ hy[(c >> 1) & 1] ^ hz[(c >> 2) & 1]) & mask4;
+      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)off, base, 0);
     }
   } else {
-    const unsigned r2 = Lv.res * Lv.res;
-    const unsigned ry[2] = {gy * Lv.res, gy * Lv.res + Lv.res};
-    const unsigned rz[2] = {gz * r2, gz * r2 + r2};
+    const unsigned r4 = Lv.res * 4u, r24 = Lv.res * Lv.res * 4u, last4 = (Lv.size - 1u) << 2;
+    const unsigned ry[2] = {gy * r4, gy * r4 + r4};
+    const unsigned rz[2] = {gz * r24, gz * r24 + r24};
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const unsigned idx = min((gx + (c & 1)) + ry[(c >> 1) & 1] + rz[(c >> 2) & 1], Lv.size - 1u);
-      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)(idx << 2), base, 0);
+      const unsigned off = min(gx4[c & 1] + ry[(c >> 1) & 1] + rz[(c >> 2) & 1], last4);
+      vals[c] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(grid, (int)off, base, 0);
     }
   }
-  float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float w = 1.0f;
-    w = w * ((c & 1) ? ax : (1.0f - ax));
-    w = w * ((c & 2) ? ay : (1.0f - ay));
-    w = w * ((c & 4) ? az : (1.0f - az));
-    const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
-    f0 += w * (float)hv[0];
-    f1 += w * (float)hv[1];
-  }
-  return pack_h2(f0, f1);
+  return ngp_trilinear_pk(vals, ax, ay, az);
 }
 
 // Both MLPs for the wave's 64 samples (lane = sample).  Flo/Fhi: this lane's 32 encoded
@@ -792,18 +807,7 @@ __device__ __forceinline__ unsigned ngp_encode_level_patch(const unsigned* patch
   const unsigned local = in_box ? (gx - lox) + 4u * (gy - loy) + 16u * (gz - loz) : 0u;
   const unsigned* c0 = patch + local;
   const unsigned vals[8] = {c0[0], c0[1], c0[4], c0[5], c0[16], c0[17], c0[20], c0[21]};
-  float f0 = 0.f, f1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float w = 1.0f;
-    w = w * ((c & 1) ? ax : (1.0f - ax));
-    w = w * ((c & 2) ? ay : (1.0f - ay));
-    w = w * ((c & 4) ? az : (1.0f - az));
-    const half2_t hv = __builtin_bit_cast(half2_t, vals[c]);
-    f0 += w * (float)hv[0];
-    f1 += w * (float)hv[1];
-  }
-  return pack_h2(f0, f1);
+  return ngp_trilinear_pk(vals, ax, ay, az);
 }
 
 // The render kernel's body: PERSISTENT waves over the ray list of one pipe.

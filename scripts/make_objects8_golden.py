@@ -16,7 +16,7 @@ from the synthetic ground truth over 60 steps, profiles/r05_bench_objects8.json)
 size: does the ORACLE drift as the HIP path does?  The answer (per-frame errors against ground truth of both paths) is
 printed by tests/test_objects8_golden_gpu.py and recorded in DESIGN.md section 6.
 
-``--switch``: roncelli_blankk for 40 frames -> tests/golden/roncelli_switch40.npz: around frame 35 the orbit's rotation
+``--switch``: roncelli_blankk for 48 frames -> tests/golden/roncelli_switch48.npz: around frame 38 the orbit's rotation
 comes nearer to the neighbouring mapping image than to the upright one and update_reference_ids
 (pixloc_tracker_r9.py:120-143) moves the reference id - one frame later the refinement runs on ANOTHER image's 3-D
 points (the thin slab's large face, seen at a grazing angle).  The reference-switch path had no oracle fixture until
@@ -26,7 +26,7 @@ CPU only; one process per object.
 
     python scripts/make_objects8_golden.py            # the eight 3-frame records
     python scripts/make_objects8_golden.py --seq      # + the two 12-frame sequences
-    python scripts/make_objects8_golden.py --switch   # only the 40-frame reference-switch sequence
+    python scripts/make_objects8_golden.py --switch   # only the 48-frame reference-switch sequence
 """
 import multiprocessing as mp
 import sys
@@ -41,7 +41,7 @@ OUT = ROOT / "tests" / "golden" / "objects8_160x120.npz"
 OUT_SEQ = ROOT / "tests" / "golden" / "objects8_seq12.npz"
 SPP, N_POINTS, SEED0 = 2, 3000, 1100
 SEQ_OBJECTS, SEQ_FRAMES = ("bottle", "roncelli_blankk"), 12
-OUT_SWITCH, SWITCH_OBJECT, SWITCH_FRAMES = ROOT / "tests" / "golden" / "roncelli_switch40.npz", "roncelli_blankk", 40
+OUT_SWITCH, SWITCH_OBJECT, SWITCH_FRAMES = ROOT / "tests" / "golden" / "roncelli_switch48.npz", "roncelli_blankk", 48
 
 
 def size_of(name):
@@ -109,11 +109,14 @@ def main():
     objs = parallel.load_object_configs()
     if "--switch" in sys.argv:
         k = [o["name"] for o in objs].index(SWITCH_OBJECT)
-        name, rec, log, secs = track_object((k, SWITCH_OBJECT, objs[k]["aabb"], SWITCH_FRAMES, 12.0))
+        name, rec, log, secs = track_object((k, SWITCH_OBJECT, objs[k]["aabb"], SWITCH_FRAMES, 24.0))  # (sigma 24 on the cold start: the gate's margin, as in bench.py --config objects8)
         for line in log:
             print("   ", *line)
         ids = [int(rec[f"f{i}_ref_id"]) for i in range(SWITCH_FRAMES)]
-        assert len(set(ids)) >= 2 and all(rec[f"f{i}_success"] for i in range(SWITCH_FRAMES)), ids
+        assert len(set(ids)) >= 2, ids
+        # no frame within 5 % of the cost gate: the HIP path's costs differ from the oracle's in the fourth digit (fp16
+        # activations), a decision must not hang on that
+        assert all(abs(float(rec[f"f{i}_cost"]) / float(rec[f"f{i}_cost_threshold"]) - 1.0) > 0.05 for i in range(1, SWITCH_FRAMES))
         np.savez_compressed(OUT_SWITCH, spp=SPP, n_points=N_POINTS, **{f"{name}/{key}": v for key, v in rec.items()})
         print("wrote", OUT_SWITCH, round(OUT_SWITCH.stat().st_size / 1e6, 2), "MB,", secs, "s; reference ids", ids)
         return

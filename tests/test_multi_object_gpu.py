@@ -68,8 +68,10 @@ def test_lockstep_equals_solo_runs(device, per_image_plan, lm_grid, n_groups):
             assert np.array_equal(got.view(np.uint64), solo[j].view(np.uint64)), (ks[j], np.abs(got - solo[j]).max())
         else:
             # (a different split-K partition moves an fp32 sum by an ulp, the fp16 activation behind it by one in 2^11,
-            # and the LM converges to a pose a few 1e-4 away: measured 8e-5 .. 4e-4 per object; the oracle bound is 1e-3)
-            assert np.abs(got[:, :12] - solo[j][:, :12]).max() < 2e-3, (ks[j], np.abs(got - solo[j]).max())
+            # and the LM converges to a pose a few 1e-4 away: measured 8e-5 .. 4e-4 per object.  The LM's own summation
+            # order - 32 instead of 128 workgroups - moves a pose by <= 1.3e-7 rad, profiles/r06_parity_margin.json: the
+            # bound is the oracle bar, 1e-3, not twice it)
+            assert np.abs(got[:, :12] - solo[j][:, :12]).max() < 1e-3, (ks[j], np.abs(got - solo[j]).max())
             assert np.array_equal(got[:, 12], solo[j][:, 12])
 
 

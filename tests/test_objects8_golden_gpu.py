@@ -25,6 +25,7 @@ from pixtrack_amd.utils.pose_utils import geodesic_distance_for_rotations
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).parent / "golden" / "objects8_160x120.npz"
 GOLDEN_SEQ = Path(__file__).parent / "golden" / "objects8_seq12.npz"
+GOLDEN_SWITCH = Path(__file__).parent / "golden" / "roncelli_switch48.npz"
 OBJECTS = parallel.load_object_configs()
 ROT_TOL, TRANS_TOL = 1e-3, 1e-3
 
@@ -124,3 +125,47 @@ def test_twelve_frames_of_the_two_drifting_boxes_follow_the_oracle(device, name,
         print(f"\n{name}: frame | HIP vs oracle rot, trans | error vs ground truth HIP, oracle (rad)")
         for r in rows:
             print("   %2d | %.2e %.2e | %.4f %.4f" % r)
+
+
+def test_reference_switch_follows_the_oracle(device, capsys):
+    """update_reference_ids (pixloc_tracker_r9.py:120-143) moves the reference id to the mapping image whose rotation is
+    nearest to the frame's start pose; the frame's sparse features were taken BEFORE the move, so the switch takes effect one
+    frame later (:153-158, :196-203; pixloc_pose_refiners.py:243-250).  tests/golden/roncelli_switch48.npz: 48 oracle frames of
+    the thin slab across such a switch (116 -> 1368 points).  The HIP tracker, every frame from the oracle's start pose, must
+    hold the same id on every frame, refine on the same number of points and land within the tolerance of the oracle."""
+    g = np.load(GOLDEN_SWITCH)
+    name = "roncelli_blankk"
+    obj = next(o for o in OBJECTS if o["name"] == name)
+    n = int(g[f"{name}/n_frames"])
+    tr, assets = _tracker(g, name, obj, device, n)
+    ids, worst, rows = [], (0.0, 0.0), []
+    for i in range(n):
+        q = torch.from_numpy(g[f"{name}/queries"][i].astype(np.float32)).to(device)
+        if i > 0:
+            tr.pose = Pose.from_Rt(np.asarray(g[f"{name}/f{i}_R_start"], np.float64), np.asarray(g[f"{name}/f{i}_t_start"], np.float64))
+        ids.append(int(tr.reference_ids[0]))
+        assert ids[-1] == int(g[f"{name}/f{i}_ref_id"]), (i, ids)
+        assert int(tr.localizer.refiner._points_of([ids[-1]])[1].shape[0]) == int(g[f"{name}/f{i}_n_points"]), i
+        tr.run_single_frame((f"{i:06d}.png", q))
+        ret = tr.pose_history[f"{i:06d}.png"]
+        assert tr.success == bool(g[f"{name}/f{i}_success"]), (name, i)
+        Rr, tt = ret["T_refined"].numpy()
+        rot = geodesic_distance_for_rotations(Rr, g[f"{name}/f{i}_R"])
+        tra = float(np.linalg.norm(tt - g[f"{name}/f{i}_t"]))
+        worst = (max(worst[0], rot), max(worst[1], tra))
+        # The bar, 1e-3 rad / 1e-3, holds wherever the oracle's own track is healthy.  From frame ~43 on this track stalls
+        # (the oracle is 0.05-0.13 rad from ground truth: the LM sits on a flat cost at 160 x 120 and stops on the step-size
+        # rule, DESIGN.md section 6); there the same fp16-level feature differences move the stopping point along the
+        # valley - mostly along the viewing axis: measured 3.8e-4 rad / 1.4e-3 at frame 44, 5.5e-4 rad / 4.2e-3 at frame 47
+        # (camera distance 4.6) - and the test holds rotation to 3e-3 and translation to 1e-2.  (At 640 x 480, 2575 points,
+        # the stalled frames agree to 1.7e-4 rad / 3.7e-4: profiles/r06_drift_probe_roncelli_blankk.log.)
+        stalled = float(g[f"{name}/f{i}_rot_err_gt"]) > 0.05
+        rows.append((i, ids[-1], rot, tra, float(g[f"{name}/f{i}_rot_err_gt"])))
+        assert rot < (3 if stalled else 1) * ROT_TOL and tra < (10 if stalled else 1) * TRANS_TOL, (name, i, ids[-1], rot, tra, stalled)
+    assert len(set(ids)) >= 2, ids  # the sequence does cross a switch
+    first_switch = next(i for i in range(1, n) if ids[i] != ids[i - 1])
+    assert rows[first_switch][4] <= 0.05  # the first frame refined on the new image's points is checked at the full bar
+    with capsys.disabled():
+        print(f"\n{name} across the reference switch: frame, reference id | HIP vs oracle rot, trans | oracle error vs ground truth")
+        for r in rows[first_switch - 2:]:
+            print("   %2d %2d | %.2e %.2e | %.4f" % r)
