@@ -747,6 +747,10 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
             tr = fresh(u)
             for opt in tr.localizer.optimizer:
                 opt.conf.n_workgroups = grid_bit
+            # (a one-object tracker encodes a WINDOW of its reference render where that saves >= 35 % of the pixels; in
+            # lock-step a reference of the query's size stays whole so that it rides in the batch: another tile plan,
+            # another fp32 summation order - both sides whole here)
+            tr.localizer.refiner.conf.reference_window = False
             return tr
 
         tb = [fresh_grid(u) for u in units]
@@ -776,7 +780,8 @@ def run_objects8(args, rank, ws, dev, coll_dev, numa_node):
         solo["value_bit_identical"] = {
             "frames_per_s": round(len(units) * args.steps / el_b, 2), "tracked_ok": ok_b, "lm_workgroups_per_problem": grid_bit,
             "unet_per_image_plan": True, "bit_identical_to_solo_runs": worst == 0.0, "max_abs_pose_record_difference": worst,
-            "what": "lock-step with every image planned as a batch of one and both sides' LM grid at 32 workgroups per problem: "
+            "what": "lock-step with every image planned as a batch of one, both sides' LM grid at 32 workgroups per problem and the "
+                    "reference pass on the whole render on both sides: "
                     "poses, decisions and costs compared with eight one-object runs of the same frames, all frames (warm-up included)"}
     if rank != 0:
         return

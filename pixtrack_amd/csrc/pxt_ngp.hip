@@ -412,14 +412,20 @@ __device__ inline void ray_clip(const NgpParams& P, Ray& r) {
 
 // The camera: a kernel argument, or - for a render enqueued before its pose is known on the host - 12 floats in
 // device memory that a one-thread kernel derived from the pose record of the LM kernel ahead of it in the stream.
+// Read with VECTOR loads (the pointer is laundered into a VGPR), never through the scalar cache: with another HIP stream's
+// kernels running beside a render, scalar loads of the camera from the kernel-argument segment returned values of a
+// slightly different camera to single waves (a wave's rays then differ in the 4th digit, profiles/r06_experiments.md
+// section 8: 1 render in 6 beside UNet passes; the same wave's second read was right, the memory itself never changed).
+// Everything else the kernels read by scalar loads is the same in every render of a context; the camera is what moves.
+__device__ __forceinline__ const float* camera_pointer(const NgpParams& P) {
+  const float* c = P.cam_dev ? P.cam_dev : P.cam;
+  asm volatile("" : "+v"(c));
+  return c;
+}
 __device__ inline void load_camera(const NgpParams& P, float* cam) {
-  if (P.cam_dev) {
+  const float* c = camera_pointer(P);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) cam[i] = P.cam_dev[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) cam[i] = P.cam[i];
-  }
+  for (int i = 0; i < 12; ++i) cam[i] = c[i];
 }
 
 __device__ inline Ray make_ray(const NgpParams& P, int px, int py) {
@@ -463,9 +469,10 @@ __device__ inline Ray ray_from_record(const NgpParams& P, const float4 rd) {
   Ray r;
   r.d[0] = rd.x; r.d[1] = rd.y; r.d[2] = rd.z;
   r.zdot = rd.w;
+  const float* c = camera_pointer(P);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    r.o[a] = P.cam_dev ? P.cam_dev[4 * a + 3] : P.cam[4 * a + 3];
+    r.o[a] = c[4 * a + 3];
     r.idir[a] = 1.0f / r.d[a];
   }
   ray_clip(P, r);
@@ -916,7 +923,7 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
           float ext = 0.f;
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            const float o = P.cam_dev ? P.cam_dev[4 * a + 3] : P.cam[4 * a + 3];
+            const float o = camera_pointer(P)[4 * a + 3];
             const float ea = ((o + tlo * d0[a]) - enc_lo) * enc_inv, eb = ((o + thi * d0[a]) - enc_lo) * enc_inv;
             // (wave-uniform values: kept in scalar registers)
             emin[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fminf(ea, eb))));

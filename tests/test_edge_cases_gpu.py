@@ -192,7 +192,7 @@ def test_three_concurrent_trackers_share_one_gpu(device):
     """Several sequences on one GPU, one Python thread + one HIP stream each (scripts/bench_multiseq.py):
     every tracker's persistent LM grid (64 workgroups, its own counters) must stay live beside the other
     trackers' renders, UNets and LM grids - no PXT_E_TIMEOUT, every frame tracked, and each sequence's
-    poses equal - within the parity tolerance, see the note at the assertion - to what it gets when it runs alone."""
+    poses equal, bit for bit, what it gets when it runs alone."""
     import threading
 
     from pixtrack_amd import optimizer
@@ -243,14 +243,10 @@ def test_three_concurrent_trackers_share_one_gpu(device):
             ret = tr.pose_history[f"{i:06d}.png"]
             assert ret["success"], (k, i)
             R, t = ret["T_refined"].numpy()
-            # Round 6, known limitation (INTEGRATION.md "Sharing a GPU"): with three trackers driving the
-            # device from three threads, the first render after a frame's other stages occasionally returns a few dozen
-            # pixels of the 8-bit reference image with other colours than the same render repeated right behind it (depth
-            # plane and sample counts unaffected; never seen with one tracker per process or in lock-step tracking, which
-            # stay bit-identical - tests/test_multi_object_gpu.py), and a pose then differs from the solo run's by up to
-            # ~1e-3.  Not understood yet (scripts/_dbg_conc*.py hold the bisection).  The bar here is the parity tolerance,
-            # not bit-equality.
-            assert np.allclose(R, alone[k][i][0], atol=2e-3) and np.allclose(t, alone[k][i][1], atol=2e-3), (k, i)
+            # Bit for bit the solo run's poses.  (Round 6 found them up to ~1e-3 apart: beside another stream's kernels the
+            # renderer's scalar loads of the camera returned a slightly different camera to single waves - the camera now
+            # travels through vector loads, csrc/pxt_ngp.hip camera_pointer; profiles/r06_experiments.md sections 4 and 8.)
+            assert np.array_equal(R, alone[k][i][0]) and np.array_equal(t, alone[k][i][1]), (k, i, np.abs(R - alone[k][i][0]).max())
 
 
 def test_two_processes_share_one_gpu(tmp_path):
