@@ -304,3 +304,45 @@ def test_two_processes_share_one_gpu(tmp_path):
         else:  # the documented failure mode, and only that one
             assert p.returncode == 3 and "PXTERROR" in out and "status -3" in out, (p.returncode, out[-500:], err[-1500:])
     assert finished >= 1
+
+
+def test_renders_beside_another_streams_unet_passes_keep_their_bits(device):
+    """Round 6's concurrency defect (profiles/r06_experiments.md section 8): with UNet passes running on another HIP stream,
+    about one render in six came back with a few 4 x 2 pixel blocks changed - single waves of the ray generator had read
+    another camera's values through the scalar cache.  240 renders on one stream beside 60 eight-image UNet passes on
+    another: every float and 8-bit plane equals the render made alone."""
+    from pixtrack_amd import parallel
+    from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
+    from pixtrack_amd.synthetic import make_tracking_assets, render_query_frames
+
+    obj = parallel.load_object_configs()[0]
+    assets = make_tracking_assets(seed=1002, width=640, height=480, n_frames=3, aabb=obj["aabb"])
+    tr = PixLocPoseTrackerR9("", "", "", "/tmp", debug=0, device=device, assets=assets)
+    frames = render_query_frames(assets, tr.testbed, first_frame_sigma=24.0)
+    for i in range(3):
+        tr.run_single_frame((f"{i:06d}.png", frames[i]))
+    torch.cuda.synchronize()
+    tb, model, mask = tr.testbed, tr.localizer.extractor.model, tr.localizer.refiner.query_mask
+    ref_u8 = frames[1].clamp(0, 255).to(torch.uint8).contiguous()
+    items = [(ref_u8, None, False), (frames[2].contiguous(), mask, True)] * 4
+    tb.set_nerf_camera_matrix(np.asarray(tr._nerf_pose(tr.pose))[:3, :])
+    w, h, tb.fov = tr._frame_views()[0]
+    s_render, s_unet = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+
+    def render():
+        return {k: v.clone() for k, v in tb.render_frame_device(w, h, 8, mode=2, want_float=True).items() if v is not None}
+
+    with torch.cuda.stream(s_render):
+        alone = render()
+    torch.cuda.synchronize()
+    differing = 0
+    for _ in range(60):
+        with torch.cuda.stream(s_unet):
+            model.set_batch_plan(True)
+            model.forward_packed_batch(items)
+            model.set_batch_plan(False)
+        with torch.cuda.stream(s_render):
+            got = [render() for _ in range(4)]
+        torch.cuda.synchronize()
+        differing += sum(1 for g in got if any(not torch.equal(g[k], alone[k]) for k in alone))
+    assert differing == 0, f"{differing} of 240 renders differ from the render made alone"
