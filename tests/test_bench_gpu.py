@@ -80,7 +80,15 @@ def test_objects8_and_hd_workloads_run(device):
     assert st["unet"]["images_per_call"] == 16 and 0.05 < st["unet"]["frac"] < 1.0 and st["lm"]["problems_per_launch"] == 8
     solo = d["solo_runs"]
     assert len(solo["frames_per_s_per_object"]) == 8 and solo["lockstep_speedup"] > 1.0, solo
-    assert max(solo["max_abs_pose_difference_vs_lockstep"]) < 5e-3, solo
+    # defaults (batch-planned UNet layers, 32 LM workgroups per problem) against solo runs: fp32 summation order only -
+    # the oracle bar (measured <= 6e-4 over 20 steps; the solo passes also encode reference WINDOWS for two objects)
+    # (the thin slab's ill-conditioned LM problem - DESIGN.md section 6 - amplifies the same differences: 2.7e-3 over 20 steps)
+    diffs = solo["max_abs_pose_difference_vs_lockstep"]
+    assert max(x for i, x in enumerate(diffs) if i != 6) < 1e-3 and diffs[6] < 5e-3, solo
+    # ... and the configuration that promises the solo runs' very bits keeps them, checked inside the bench run
+    vb = d["value_bit_identical"]
+    assert vb["bit_identical_to_solo_runs"] is True and vb["max_abs_pose_record_difference"] == 0.0 and vb["tracked_ok"] == 64, vb
+    assert set(d["max_rot_err_vs_gt_rad"]) == set(d["config"]["objects_per_rank"][0])
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "hd", "--steps", "6", "--warmup", "2"],
                          capture_output=True, text=True, timeout=900, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-3000:]
@@ -180,7 +188,20 @@ def test_objects8_every_object_tracks_at_640x480(device, k):
     # axis is weakly observable - 0.04 rad there, 1e-3 .. 1e-2 for the boxes; every frame passes the tracker's own gates)
     # (round 5: the cold-start frame of the objects8 workload carries sigma 24 instead of 12 - the bottle's steady frames
     # were refused by the cost gate otherwise - and the bottle's free rotation about its axis starts from a noisier pose)
+    # (round 6: the CPU oracle tracks the bottle's scene with the same error - 0.04 rising to 0.137 rad at frame 15 and back to
+    # 0.001 by frame 64, profiles/r06_oracle_drift_bottle*.log beside r06_hip_drift_bottle.log: 0.2 rad bounds the
+    # algorithm's own excursion on this scene, it is not slack for the HIP path, which the oracle fixtures hold to 1e-3)
     assert d["mean_rot_err_vs_gt_rad"] < (0.2 if k == 0 else 0.1) and d["mean_trans_err_vs_gt"] < 0.05 and d["value"] > 100.0
+    if k == 0:
+        # the headline's cold-start noise (sigma 12) on the bottle: the cost gate (1.1 x the first frame's cost) refuses one
+        # of these twelve steady frames - the run that made the objects8 workload take sigma 24.  Kept as its own assertion
+        # so that a change of the gate's behaviour stays visible: 11 of 12 measured, 10 .. 12 accepted.
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "objects8", "--object-index", "0", "--steps", "12",
+                              "--warmup", "3", "--no-cpu-baseline", "--first-frame-sigma", "12"], capture_output=True, text=True,
+                             timeout=900, cwd=str(ROOT))
+        assert out.returncode == 0, out.stderr[-3000:]
+        d12 = _last_json(out.stdout)
+        assert d12["frames_total"] == 12 and 10 <= d12["tracked_ok"] <= 12, d12["tracked_ok"]
 
 
 def test_eight_ranks_rehearsal_on_one_gpu(device):
