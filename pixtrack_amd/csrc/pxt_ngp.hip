@@ -412,11 +412,12 @@ __device__ inline void ray_clip(const NgpParams& P, Ray& r) {
 
 // The camera: a kernel argument, or - for a render enqueued before its pose is known on the host - 12 floats in
 // device memory that a one-thread kernel derived from the pose record of the LM kernel ahead of it in the stream.
-// Read with VECTOR loads (the pointer is laundered into a VGPR), never through the scalar cache: with another HIP stream's
-// kernels running beside a render, scalar loads of the camera from the kernel-argument segment returned values of a
-// slightly different camera to single waves (a wave's rays then differ in the 4th digit, profiles/r06_experiments.md
-// section 8: 1 render in 6 beside UNet passes; the same wave's second read was right, the memory itself never changed).
-// Everything else the kernels read by scalar loads is the same in every render of a context; the camera is what moves.
+// The camera's twelve floats are read through a pointer laundered into a VGPR (plain vector loads, no address arithmetic in
+// SGPRs).  Round 6: with another HIP stream's convolution kernels running beside a render, single waves of the ray generator
+// computed their rays from a slightly different camera (4th digit; the same wave's second computation was right, the
+// kernel-argument memory never changed) - 1 render in 6 beside UNet passes.  The build with this form of the loads is clean
+// over 22,000 such renders; the mechanism is NOT established (the defect moves with the instruction stream around the
+// loads: profiles/r06_experiments.md section 8), tests/test_edge_cases_gpu.py holds the regression test.
 __device__ __forceinline__ const float* camera_pointer(const NgpParams& P) {
   const float* c = P.cam_dev ? P.cam_dev : P.cam;
   asm volatile("" : "+v"(c));

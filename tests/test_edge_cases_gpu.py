@@ -244,8 +244,8 @@ def test_three_concurrent_trackers_share_one_gpu(device):
             assert ret["success"], (k, i)
             R, t = ret["T_refined"].numpy()
             # Bit for bit the solo run's poses.  (Round 6 found them up to ~1e-3 apart: beside another stream's kernels the
-            # renderer's scalar loads of the camera returned a slightly different camera to single waves - the camera now
-            # travels through vector loads, csrc/pxt_ngp.hip camera_pointer; profiles/r06_experiments.md sections 4 and 8.)
+            # ray generator computed single waves' rays from a slightly different camera - removed by the way the camera is
+            # loaded, csrc/pxt_ngp.hip camera_pointer; profiles/r06_experiments.md sections 4 and 8.)
             assert np.array_equal(R, alone[k][i][0]) and np.array_equal(t, alone[k][i][1]), (k, i, np.abs(R - alone[k][i][0]).max())
 
 
@@ -308,8 +308,8 @@ def test_two_processes_share_one_gpu(tmp_path):
 
 def test_renders_beside_another_streams_unet_passes_keep_their_bits(device):
     """Round 6's concurrency defect (profiles/r06_experiments.md section 8): with UNet passes running on another HIP stream,
-    about one render in six came back with a few 4 x 2 pixel blocks changed - single waves of the ray generator had read
-    another camera's values through the scalar cache.  240 renders on one stream beside 60 eight-image UNet passes on
+    about one render in six came back with a few 4 x 2 pixel blocks changed - single waves of the ray generator had computed
+    from a slightly different camera (mechanism not established).  240 renders on one stream beside 60 eight-image UNet passes on
     another: every float and 8-bit plane equals the render made alone."""
     from pixtrack_amd import parallel
     from pixtrack_amd.pose_trackers.pixloc_tracker_r9 import PixLocPoseTrackerR9
