@@ -127,3 +127,29 @@ def test_no_convolution_kernel_uses_scratch(tmp_path):
     conv = {n: int(sz) for n, sz in kernels if "conv3x3" in n or "conv_first" in n or "head_mfma" in n}
     assert len(conv) >= 10, sorted(conv)
     assert all(sz == 0 for sz in conv.values()), {n: sz for n, sz in conv.items() if sz}
+
+
+def test_ray_generator_spills_no_sgprs(tmp_path):
+    """Round 6 (profiles/r06_experiments.md section 8): beside another stream's convolution kernels single waves of the ray
+    generator computed their rays slightly wrong - in every build whose ray generator spilled SGPRs into VGPR lanes
+    (v_writelane_b32 / v_readlane_b32), in none that did not.  The mechanism is not established; until it is, a change that
+    brings the spills back must not go unnoticed: the kernel's ISA is checked here (hipcc -S, no GPU needed)."""
+    import subprocess
+
+    from pixtrack_amd import _build
+
+    src = _build.CSRC / "pxt_ngp.hip"
+    out = tmp_path / "ngp.s"
+    subprocess.check_call([_build.HIPCC, *_build.FLAGS, *_build.EXTRA.get("pxt_ngp", []), "--cuda-device-only", "-S", str(src), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    name, spills, seen = None, {}, 0
+    for line in out.read_text().splitlines():
+        if line.startswith("_ZN3pxt") and line.rstrip().endswith(":") or (line.startswith("_ZN3pxt") and ":" in line.split()[0]):
+            name = line.split(":")[0]
+            seen += "ngp_raygen_kernel" in name
+        elif line.startswith(".Lfunc_end"):
+            name = None
+        elif name and "ngp_raygen_kernel" in name and "v_writelane_b32" in line:
+            spills[name] = spills.get(name, 0) + 1
+    assert seen >= 2, "the ray generator kernels were not found in the ISA"
+    assert not spills, spills
