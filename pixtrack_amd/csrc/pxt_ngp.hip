@@ -845,9 +845,14 @@ __device__ __forceinline__ void ngp_render_body(const NgpParams& P, const NgpWor
                                                 half8* s_w, unsigned* s_feat, float* s_rays) {
   const int n = Wk.counters[0];
   if (P.stats && blk == 0 && threadIdx.x == 0) atomicAdd(P.stats + 1, (unsigned long long)n);  // rays that hit the box
-  // Workgroups that take part: one per `rays_per_wg` rays, at least nblk / 4 (a short list spread over few waves is a
-  // long chain of steps per wave).
-  const int n_wg = min(nblk, max(nblk / 4, (n + rays_per_wg - 1) / rays_per_wg));
+  // Workgroups that take part.  Up to the knee (4096 workgroups: the optimum of the 640 x 480 x 8 renders, section 1 of
+  // profiles/r06_experiments.md) one per `rays_per_wg` rays, at least a quarter of the knee (a short list spread over few
+  // waves is a long chain of steps per wave); lists too long for the knee - 1920 x 1080 and 2016 x 1512 renders - get one
+  // workgroup per 21 / 16 x rays_per_wg rays (84 at the default 64) up to the launched grid: +6 % on those renders.
+  const int knee = min(nblk, 4096);
+  const int by_div = (n + rays_per_wg - 1) / rays_per_wg;
+  const int by_div2 = (int)(((long long)n * 16) / ((long long)rays_per_wg * 21));
+  const int n_wg = min(nblk, max(knee / 4, max(min(by_div, knee), by_div2)));
   if (blk >= n_wg || blk * 32 >= n) return;  // (workgroup-uniform)
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) s_w[i] = P.wfrag[i];
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.grid, 0, (int)P.grid_bytes, 0x00020000);
@@ -1592,7 +1597,7 @@ int run_chain(ChainRender* R, int K, hipStream_t s0, void* ws_dev) {
   // (PXT_NGP_GRID_DIV): measured on the benchmark view (640 x 480 x 8 spp, ~345 k rays in the list, 4 waves per SIMD = 1024
   // resident workgroups): 2048 / 3072 / 4096 / 6144 / 8192 workgroups = 0.75 / 0.71 / 0.68 / 0.71 / 0.74 ms per render
   // (profiles/r06_experiments.md).  The grid is the queue: more waves than are resident, each with a short share.
-  static const int g_render = env_int("PXT_NGP_GRID", 4096, 64, 16384), g_div = env_int("PXT_NGP_GRID_DIV", 64, 1, 1 << 20),
+  static const int g_render = env_int("PXT_NGP_GRID", 16384, 64, 16384), g_div = env_int("PXT_NGP_GRID_DIV", 64, 1, 1 << 20),
                    g_raygen = env_int("PXT_NGP_GRID_RAYGEN", 1024, 64, 8192);
   static const int env_pipes = env_int("PXT_NGP_PIPES", 1, 1, pxt_ngp::kMaxPipes);
   struct Pipe { int render, w; };
