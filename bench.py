@@ -49,7 +49,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 # commits at which the committed rocprofv3 PMC summaries were collected (files without a `_meta` record)
-PROFILE_COMMITS = {"r06": "e164c99", "r05": "0f536bf", "r04": "57b838f", "r03": "a686fc1", "r02": "2a1bccf"}
+PROFILE_COMMITS = {"r06": "a77c9a2", "r05": "0f536bf", "r04": "57b838f", "r03": "a686fc1", "r02": "2a1bccf"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NERF_BYTES_PER_SAMPLE = 512.0  # 16 levels x 8 corners x 2 features x 2 B
 # the dominant kernel: gathers + both MLPs of a round's samples (Shade + Depth of the same rays: MODE 2)
